@@ -1,0 +1,231 @@
+"""Host-side ``JaxSimModel`` mirror: immutable model container + parameter classes.
+
+Mirrors the reference's public surface for the step path
+(``src/jaxsim/api/model.py:46-330,674-799``; parameter classes:
+``rbda/contacts/soft.py:24-123``, ``rbda/actuation/common.py:10-19``,
+``terrain/terrain.py:65-124``).  The object is plain Python + NumPy; the device copy
+of the tables lives behind the C-ABI (``include/jaxsim_amd.h``: ``jxs_model_create``)
+and is created lazily the first time a kernel entry point needs it.
+"""
+
+from __future__ import annotations
+
+import contextlib
+import copy
+import dataclasses
+import enum
+import pathlib
+
+import numpy as np
+
+from .kin_dyn_parameters import KinDynParameters
+from .parsers import urdf as urdf_parser
+
+STANDARD_GRAVITY = 9.81  # src/jaxsim/math/__init__.py:14
+
+
+class VelRepr(enum.IntEnum):
+    """Velocity representations (``src/jaxsim/api/common.py:39-47``); values are the C-ABI enum."""
+
+    Inertial = 0
+    Body = 1
+    Mixed = 2
+
+
+@dataclasses.dataclass
+class SoftContactsParams:
+    """``SoftContactsParams`` (``src/jaxsim/rbda/contacts/soft.py:24-123``)."""
+
+    K: float = 1e6
+    D: float = 2000.0
+    mu: float = 0.5
+    p: float = 0.5
+    q: float = 0.5
+
+    @classmethod
+    def build(cls, *, K=1e6, D=2_000, mu=0.5, p=0.5, q=0.5, **kwargs):
+        return cls(K=float(K), D=float(D), mu=float(mu), p=float(p), q=float(q))
+
+    def valid(self) -> bool:
+        return all(v >= 0.0 for v in (self.K, self.D, self.mu, self.p, self.q))
+
+    @classmethod
+    def build_default_from_jaxsim_model(
+        cls,
+        model: "JaxSimModel",
+        *,
+        stiffness=None,
+        damping=None,
+        standard_gravity=STANDARD_GRAVITY,
+        static_friction_coefficient=0.5,
+        max_penetration=0.001,
+        number_of_active_collidable_points_steady_state=1,
+        damping_ratio=1.0,
+        p=0.5,
+        q=0.5,
+    ):
+        """``build_default_from_jaxsim_model`` (``rbda/contacts/common.py:88-168``)."""
+        m = float(np.sum(model.kin_dyn_parameters.link_mass))
+        if stiffness is None:
+            f_average = m * standard_gravity / number_of_active_collidable_points_steady_state
+            stiffness = float(np.clip(f_average / np.power(max_penetration, 1 + p), 0, 1e6))
+        if damping is None:
+            damping = float(np.clip(damping_ratio * 2 * np.sqrt(stiffness * m), 0, 1e4))
+        return cls.build(K=stiffness, D=damping, mu=static_friction_coefficient, p=p, q=q)
+
+
+@dataclasses.dataclass
+class ActuationParams:
+    """``ActuationParams`` (``src/jaxsim/rbda/actuation/common.py:10-19``)."""
+
+    torque_max: float = 3000.0
+    omega_th: float = 30.0
+    omega_max: float = 100.0
+    enable_friction: bool = True
+
+
+@dataclasses.dataclass
+class FlatTerrain:
+    """``FlatTerrain`` (``src/jaxsim/terrain/terrain.py:65-124``): constant height, normal +z."""
+
+    _height: float = 0.0
+
+    @staticmethod
+    def build(height: float = 0.0) -> "FlatTerrain":
+        return FlatTerrain(_height=float(height))
+
+    def height(self, x, y):
+        return np.full(np.shape(x), self._height, dtype=float)
+
+    def normal(self, x, y):
+        n = np.zeros(np.shape(x) + (3,), dtype=float)
+        n[..., 2] = 1.0
+        return n
+
+
+class SoftContacts:
+    """Marker for the Hunt-Crossley soft-contact model (``rbda/contacts/soft.py:126-444``)."""
+
+    @classmethod
+    def build(cls, **kwargs):
+        return cls()
+
+
+class IntegratorType(enum.IntEnum):
+    """``IntegratorType`` (``src/jaxsim/api/model.py:32-40``); only semi-implicit Euler is built."""
+
+    SemiImplicitEuler = 0
+
+
+class JaxSimModel:
+    """Immutable-by-convention model container (``src/jaxsim/api/model.py:46-90``)."""
+
+    def __init__(
+        self,
+        model_name: str,
+        kin_dyn_parameters: KinDynParameters,
+        *,
+        floating_base: bool,
+        time_step: float = 0.001,
+        gravity: float = -STANDARD_GRAVITY,
+        terrain: FlatTerrain | None = None,
+        contact_model=None,
+        contact_params: SoftContactsParams | None = None,
+        actuation_params: ActuationParams | None = None,
+        integrator: IntegratorType = IntegratorType.SemiImplicitEuler,
+    ):
+        self.model_name = model_name
+        self.kin_dyn_parameters = kin_dyn_parameters
+        self._floating_base = bool(floating_base)
+        self.time_step = float(time_step)
+        #: signed z acceleration; ``build_from_model_description`` negates its positive
+        #: argument like the reference (``api/model.py:206``).
+        self.gravity = float(gravity)
+        self.terrain = terrain if terrain is not None else FlatTerrain.build()
+        self.contact_model = contact_model if contact_model is not None else SoftContacts.build()
+        self.contact_params = contact_params if contact_params is not None else SoftContactsParams()
+        self.actuation_params = actuation_params if actuation_params is not None else ActuationParams()
+        self.integrator = integrator
+        self._device = {}  # dtype name -> device handle (see _lib.DeviceModel)
+
+    # -- construction -----------------------------------------------------------------------
+    @staticmethod
+    def build_from_model_description(
+        model_description: str | pathlib.Path,
+        *,
+        model_name: str | None = None,
+        time_step: float | None = None,
+        terrain: FlatTerrain | None = None,
+        contact_model=None,
+        contact_params: SoftContactsParams | None = None,
+        actuation_params: ActuationParams | None = None,
+        integrator: IntegratorType | None = None,
+        gravity: float = STANDARD_GRAVITY,
+    ) -> "JaxSimModel":
+        """Build from a URDF path or string (``src/jaxsim/api/model.py:128-223``).
+
+        ``gravity`` is the positive magnitude; the stored value is ``-gravity``.
+        """
+        desc = urdf_parser.parse_urdf(str(model_description))
+        kdp = KinDynParameters.build(desc)
+        return JaxSimModel(
+            model_name or desc.name,
+            kdp,
+            floating_base=not desc.fixed_base,
+            time_step=0.001 if time_step is None else time_step,
+            gravity=-float(gravity),
+            terrain=terrain,
+            contact_model=contact_model,
+            contact_params=contact_params,
+            actuation_params=actuation_params,
+            integrator=IntegratorType.SemiImplicitEuler if integrator is None else integrator,
+        )
+
+    # -- reference accessors (``src/jaxsim/api/model.py:674-799``) ---------------------------
+    def name(self) -> str:
+        return self.model_name
+
+    def number_of_links(self) -> int:
+        return self.kin_dyn_parameters.number_of_links()
+
+    def number_of_joints(self) -> int:
+        return self.kin_dyn_parameters.number_of_joints()
+
+    def dofs(self) -> int:
+        return self.kin_dyn_parameters.number_of_joints()
+
+    def floating_base(self) -> bool:
+        return self._floating_base
+
+    def base_link(self) -> str:
+        return self.kin_dyn_parameters.link_names[0]
+
+    def link_names(self) -> tuple[str, ...]:
+        return self.kin_dyn_parameters.link_names
+
+    def joint_names(self) -> tuple[str, ...]:
+        return self.kin_dyn_parameters.joint_names
+
+    def frame_names(self) -> tuple[str, ...]:
+        return self.kin_dyn_parameters.frame_names
+
+    def total_mass(self) -> float:
+        return float(np.sum(self.kin_dyn_parameters.link_mass))
+
+    @contextlib.contextmanager
+    def editable(self, validate: bool = True):
+        """The ``with model.editable(validate=False) as model:`` idiom
+        (``src/jaxsim/utils/jaxsim_dataclass.py:28-49``): yields a shallow copy whose
+        fields may be reassigned; device copies are rebuilt on next use."""
+        clone = copy.copy(self)
+        clone._device = {}
+        yield clone
+
+    def _invalidate_device(self) -> None:
+        self._device = {}
+
+    def __setattr__(self, key, value):
+        # Any change of a model-level constant invalidates the cached device tables.
+        if key != "_device" and "_device" in self.__dict__:
+            self.__dict__["_device"] = {}
+        super().__setattr__(key, value)

@@ -1,0 +1,254 @@
+"""URDF generators for the benchmark / test models.
+
+The reference pulls iCub/ErgoCub/ANYmal URDFs from pip packages that are not
+available offline (``tests/conftest.py:277-316``), so the humanoid and the
+quadruped here are **synthetic**: same joint list / topology as the public
+robots (``README.md:50-55`` for the 23 iCub joints) with
+stated, made-up masses, inertias and sole boxes.  The small models re-express
+the reference's own fixtures: box / sphere (``tests/conftest.py:207-274``),
+single pendulum (``:370-476``), the cartpole example and the double-pendulum
+test asset (numeric values only; emitted here as URDF text by our own code).
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+
+def _inertial(mass, com=(0, 0, 0), I=(1e-3, 1e-3, 1e-3), rpy=(0, 0, 0)) -> str:
+    ixx, iyy, izz = I
+    return (
+        f'<inertial><origin xyz="{com[0]} {com[1]} {com[2]}" rpy="{rpy[0]} {rpy[1]} {rpy[2]}"/>'
+        f'<mass value="{mass}"/>'
+        f'<inertia ixx="{ixx}" ixy="0" ixz="0" iyy="{iyy}" iyz="0" izz="{izz}"/></inertial>'
+    )
+
+
+def _box_inertia(m, x, y, z):
+    return (m / 12 * (y * y + z * z), m / 12 * (x * x + z * z), m / 12 * (x * x + y * y))
+
+
+def _box_collision(size, xyz=(0, 0, 0), rpy=(0, 0, 0)) -> str:
+    return (
+        f'<collision><origin xyz="{xyz[0]} {xyz[1]} {xyz[2]}" rpy="{rpy[0]} {rpy[1]} {rpy[2]}"/>'
+        f'<geometry><box size="{size[0]} {size[1]} {size[2]}"/></geometry></collision>'
+    )
+
+
+def _joint(name, jtype, parent, child, xyz, axis, rpy=(0, 0, 0), lower=None, upper=None, damping=0.0, friction=0.0):
+    lim = ""
+    if jtype != "fixed":
+        if lower is not None:
+            lim = f'<limit effort="1000" velocity="100" lower="{lower}" upper="{upper}"/>'
+        else:
+            lim = '<limit effort="1000" velocity="100"/>'
+    dyn = f'<dynamics damping="{damping}" friction="{friction}"/>' if (damping or friction) else ""
+    ax = f'<axis xyz="{axis[0]} {axis[1]} {axis[2]}"/>' if jtype != "fixed" else ""
+    return (
+        f'<joint name="{name}" type="{jtype}"><origin xyz="{xyz[0]} {xyz[1]} {xyz[2]}" '
+        f'rpy="{rpy[0]} {rpy[1]} {rpy[2]}"/><parent link="{parent}"/><child link="{child}"/>{ax}{lim}{dyn}</joint>'
+    )
+
+
+def box_urdf(size=(0.3, 0.2, 0.1), mass=1.0) -> str:
+    """Single-link floating box, 8 corner points (``tests/conftest.py:207-243``)."""
+    x, y, z = size
+    return (
+        '<robot name="box"><link name="box_link">'
+        + _inertial(mass, I=_box_inertia(mass, x, y, z))
+        + _box_collision(size)
+        + "</link></robot>"
+    )
+
+
+def sphere_urdf(radius=0.1, mass=1.0) -> str:
+    """Single-link floating sphere, 50 Fibonacci points (``tests/conftest.py:246-274``)."""
+    I = 2.0 / 5.0 * mass * radius * radius
+    return (
+        '<robot name="sphere"><link name="sphere_link">'
+        + _inertial(mass, I=(I, I, I))
+        + f'<collision><origin xyz="0 0 0" rpy="0 0 0"/><geometry><sphere radius="{radius}"/></geometry></collision>'
+        + "</link></robot>"
+    )
+
+
+def single_pendulum_urdf(length=0.5, mass=1.0, lower=None, upper=None) -> str:
+    """Fixed-base 2-link pendulum about the x axis (``tests/conftest.py:370-476``)."""
+    I = _box_inertia(mass, 0.05, 0.05, length)
+    return (
+        '<robot name="single_pendulum"><link name="world"/>'
+        '<link name="base">' + _inertial(1.0, I=(0.01, 0.01, 0.01)) + "</link>"
+        '<link name="link">' + _inertial(mass, com=(0, 0, -length / 2), I=I) + "</link>"
+        + _joint("world_to_base", "fixed", "world", "base", (0, 0, 1.0), (0, 0, 0))
+        + _joint("pivot", "revolute" if lower is not None else "continuous", "base", "link", (0, 0, 0), (1, 0, 0),
+                 lower=lower, upper=upper)
+        + "</robot>"
+    )
+
+
+def double_pendulum_urdf(with_base_collision: bool = False) -> str:
+    """Fixed base + two independent revolute-x links, joint damping 1.0.
+
+    Same numbers as the reference's ``tests/assets/double_pendulum.sdf`` (base 100 kg,
+    links 1 kg with unit inertia and CoM at z=0.5, joints at (+-0.2, 0, 2) rolled by
+    -3.1415); BASELINE config C1 ("no contacts") strips the base collision box.
+    """
+    coll = _box_collision((0.2, 0.2, 2.15), xyz=(0, 0, 1)) if with_base_collision else ""
+    link = lambda n: f'<link name="{n}">' + _inertial(1.0, com=(0, 0, 0.5), I=(1.0, 1.0, 1.0)) + "</link>"  # noqa: E731
+    return (
+        '<robot name="double_pendulum"><link name="world"/>'
+        '<link name="base_link">' + _inertial(100.0, I=(1.0, 1.0, 1.0)) + coll + "</link>"
+        + link("right_link") + link("left_link")
+        + _joint("fixed_base", "fixed", "world", "base_link", (0, 0, 0), (0, 0, 0))
+        + _joint("right_joint", "revolute", "base_link", "right_link", (0.2, 0, 2), (1, 0, 0),
+                 rpy=(-3.1415, 0, 0), lower=-100, upper=100, damping=1.0)
+        + _joint("left_joint", "revolute", "base_link", "left_link", (-0.2, 0, 2), (1, 0, 0),
+                 rpy=(-3.1415, 0, 0), lower=-100, upper=100, damping=1.0)
+        + "</robot>"
+    )
+
+
+def cartpole_urdf(with_collisions: bool = False) -> str:
+    """rail(0) - prismatic-y -> cart(1) - continuous-x -> pole(2), fixed base.
+
+    Numbers follow the reference example ``examples/assets/cartpole.urdf``; the two
+    massless ``*_frame`` links exercise the frame/lumping path.  BASELINE config C2 is
+    "ABA + integrator only": no collision shapes unless ``with_collisions``.
+    """
+    cart_coll = _box_collision((0.1, 0.2, 0.05)) if with_collisions else ""
+    return (
+        '<robot name="cartpole"><link name="world"/>'
+        '<link name="rail">'
+        + _inertial(5.0, com=(0, 0, 1.2), rpy=(1.5707963267948963, 0, 0),
+                    I=(10.416697916666665, 10.416697916666665, 6.25e-05))
+        + "</link>"
+        '<link name="cart">'
+        + _inertial(1.0, I=(0.0035416666666666674, 0.0010416666666666669, 0.0041666666666666675))
+        + cart_coll + "</link>"
+        '<link name="pole">'
+        + _inertial(0.5, com=(0, 0, 0.5), I=(0.04166979166666667, 0.04166979166666667, 6.25e-06))
+        + "</link>"
+        '<link name="cart_frame"/><link name="rail_frame"/>'
+        + _joint("cart_frame_joint", "fixed", "cart", "cart_frame", (0, 0, 0), (0, 0, 0))
+        + _joint("rail_frame_joint", "fixed", "rail", "rail_frame", (0, 0, 1.2), (0, 0, 0))
+        + _joint("world_to_rail", "fixed", "world", "rail", (0, 0, 0), (0, 0, 0))
+        + _joint("linear", "prismatic", "rail", "cart", (0, 0, 1.2), (0, 1, 0), lower=-2.4, upper=2.4)
+        + _joint("pivot", "continuous", "cart", "pole", (0, 0, 0), (1, 0, 0))
+        + "</robot>"
+    )
+
+
+# ---------------------------------------------------------------------------------------------
+# Synthetic humanoid with the iCub 23-DoF joint list.  SYNTHETIC inertial data.
+# ---------------------------------------------------------------------------------------------
+
+ICUB_JOINTS = (
+    "torso_pitch", "torso_roll", "torso_yaw",
+    "l_shoulder_pitch", "l_shoulder_roll", "l_shoulder_yaw", "l_elbow",
+    "r_shoulder_pitch", "r_shoulder_roll", "r_shoulder_yaw", "r_elbow",
+    "l_hip_pitch", "l_hip_roll", "l_hip_yaw", "l_knee", "l_ankle_pitch", "l_ankle_roll",
+    "r_hip_pitch", "r_hip_roll", "r_hip_yaw", "r_knee", "r_ankle_pitch", "r_ankle_roll",
+)  # fmt: skip
+
+
+def icub23_urdf(sole_boxes_per_foot: int = 2, joint_limit: float = 1.0) -> str:
+    """Synthetic 24-link / 23-DoF floating-base humanoid, total mass ~33 kg.
+
+    ``sole_boxes_per_foot`` boxes per foot, 8 corner points each: 2 -> n_cp = 32 (the
+    stated C3/C4 default), 1 -> n_cp = 16.
+    Standing height of the root link above the soles is ~0.60 m.
+    """
+    out = ['<robot name="icub23_synthetic">']
+
+    def link(name, mass, com, dims, extra=""):
+        out.append(f'<link name="{name}">' + _inertial(mass, com=com, I=_box_inertia(mass, *dims)) + extra + "</link>")
+
+    jl = joint_limit
+    link("root_link", 5.0, (0, 0, 0.0), (0.15, 0.2, 0.12))
+    # torso chain
+    link("torso_1", 1.0, (0, 0, 0.02), (0.08, 0.08, 0.06))
+    link("torso_2", 1.0, (0, 0, 0.02), (0.08, 0.08, 0.06))
+    link("chest", 8.0, (0, 0, 0.12), (0.18, 0.26, 0.25))
+    out.append(_joint("torso_pitch", "revolute", "root_link", "torso_1", (0, 0, 0.08), (0, 1, 0), lower=-jl, upper=jl))
+    out.append(_joint("torso_roll", "revolute", "torso_1", "torso_2", (0, 0, 0.04), (1, 0, 0), lower=-jl, upper=jl))
+    out.append(_joint("torso_yaw", "revolute", "torso_2", "chest", (0, 0, 0.04), (0, 0, 1), lower=-jl, upper=jl))
+    for s, sy in (("l", 1.0), ("r", -1.0)):
+        link(f"{s}_shoulder_1", 0.5, (0, 0.02 * sy, 0), (0.06, 0.06, 0.06))
+        link(f"{s}_shoulder_2", 0.5, (0, 0, -0.02), (0.06, 0.06, 0.06))
+        link(f"{s}_shoulder_3", 1.2, (0, 0, -0.08), (0.06, 0.06, 0.16))
+        link(f"{s}_forearm", 1.0, (0, 0, -0.08), (0.05, 0.05, 0.18))
+        out.append(_joint(f"{s}_shoulder_pitch", "revolute", "chest", f"{s}_shoulder_1", (0, 0.12 * sy, 0.2), (0, 1, 0), lower=-jl, upper=jl))
+        out.append(_joint(f"{s}_shoulder_roll", "revolute", f"{s}_shoulder_1", f"{s}_shoulder_2", (0, 0.05 * sy, 0), (1, 0, 0), lower=-jl, upper=jl))
+        out.append(_joint(f"{s}_shoulder_yaw", "revolute", f"{s}_shoulder_2", f"{s}_shoulder_3", (0, 0, -0.04), (0, 0, 1), lower=-jl, upper=jl))
+        out.append(_joint(f"{s}_elbow", "revolute", f"{s}_shoulder_3", f"{s}_forearm", (0, 0, -0.16), (0, 1, 0), lower=-jl, upper=jl))
+        # legs
+        sole = ""
+        if sole_boxes_per_foot >= 1:
+            if sole_boxes_per_foot == 1:
+                sole = _box_collision((0.18, 0.08, 0.02), xyz=(0.03, 0, -0.05))
+            else:
+                w = 0.18 / sole_boxes_per_foot
+                for k in range(sole_boxes_per_foot):
+                    cx = 0.03 - 0.09 + w * (k + 0.5)
+                    sole += _box_collision((w, 0.08, 0.02), xyz=(cx, 0, -0.05))
+        link(f"{s}_hip_1", 0.8, (0, 0, 0), (0.07, 0.07, 0.07))
+        link(f"{s}_hip_2", 0.8, (0, 0, -0.02), (0.07, 0.07, 0.07))
+        link(f"{s}_upper_leg", 2.5, (0, 0, -0.11), (0.09, 0.09, 0.24))
+        link(f"{s}_lower_leg", 2.0, (0, 0, -0.1), (0.07, 0.07, 0.22))
+        link(f"{s}_ankle_1", 0.5, (0, 0, 0), (0.05, 0.05, 0.05))
+        link(f"{s}_ankle_2", 0.8, (0.03, 0, -0.04), (0.18, 0.08, 0.04), extra=sole)
+        out.append(_joint(f"{s}_hip_pitch", "revolute", "root_link", f"{s}_hip_1", (0, 0.07 * sy, -0.06), (0, 1, 0), lower=-jl, upper=jl))
+        out.append(_joint(f"{s}_hip_roll", "revolute", f"{s}_hip_1", f"{s}_hip_2", (0, 0, -0.02), (1, 0, 0), lower=-jl, upper=jl))
+        out.append(_joint(f"{s}_hip_yaw", "revolute", f"{s}_hip_2", f"{s}_upper_leg", (0, 0, -0.04), (0, 0, 1), lower=-jl, upper=jl))
+        out.append(_joint(f"{s}_knee", "revolute", f"{s}_upper_leg", f"{s}_lower_leg", (0, 0, -0.22), (0, 1, 0), lower=-jl, upper=jl))
+        out.append(_joint(f"{s}_ankle_pitch", "revolute", f"{s}_lower_leg", f"{s}_ankle_1", (0, 0, -0.2), (0, 1, 0), lower=-jl, upper=jl))
+        out.append(_joint(f"{s}_ankle_roll", "revolute", f"{s}_ankle_1", f"{s}_ankle_2", (0, 0, 0), (1, 0, 0), lower=-jl, upper=jl))
+    out.append("</robot>")
+    return "".join(out)
+
+
+def anymal12_urdf(points_per_foot_box: bool = True, joint_limit: float = 1.0) -> str:
+    """Synthetic 13-link / 12-DoF quadruped (4 x HAA-x / HFE-y / KFE-y), ~50 kg."""
+    out = ['<robot name="anymal12_synthetic">']
+    out.append('<link name="base">' + _inertial(30.0, I=_box_inertia(30.0, 0.6, 0.3, 0.2)) + "</link>")
+    jl = joint_limit
+    for leg, sx, sy in (("LF", 1, 1), ("RF", 1, -1), ("LH", -1, 1), ("RH", -1, -1)):
+        foot = _box_collision((0.04, 0.04, 0.04), xyz=(0, 0, -0.3)) if points_per_foot_box else ""
+        out.append(f'<link name="{leg}_HIP">' + _inertial(1.5, com=(0, 0.02 * sy, 0), I=_box_inertia(1.5, 0.1, 0.1, 0.1)) + "</link>")
+        out.append(f'<link name="{leg}_THIGH">' + _inertial(2.0, com=(0, 0, -0.14), I=_box_inertia(2.0, 0.06, 0.06, 0.3)) + "</link>")
+        out.append(f'<link name="{leg}_SHANK">' + _inertial(1.5, com=(0, 0, -0.14), I=_box_inertia(1.5, 0.05, 0.05, 0.3)) + foot + "</link>")
+        out.append(_joint(f"{leg}_HAA", "revolute", "base", f"{leg}_HIP", (0.3 * sx, 0.12 * sy, 0), (1, 0, 0), lower=-jl, upper=jl))
+        out.append(_joint(f"{leg}_HFE", "revolute", f"{leg}_HIP", f"{leg}_THIGH", (0, 0.06 * sy, 0), (0, 1, 0), lower=-jl, upper=jl))
+        out.append(_joint(f"{leg}_KFE", "revolute", f"{leg}_THIGH", f"{leg}_SHANK", (0, 0, -0.3), (0, 1, 0), lower=-jl, upper=jl))
+    out.append("</robot>")
+    return "".join(out)
+
+
+def chain_urdf(n_links: int = 5, fixed_base: bool = True, seed: int = 0) -> str:
+    """Random serial/branching chain with mixed revolute/prismatic joints, skewed axes and
+    rotated joint frames: a stress model for parity tests (cf. the reference's scalable
+    "garpez" fixture, ``tests/conftest.py:479-707``)."""
+    rng = np.random.default_rng(seed)
+    out = ['<robot name="chain">']
+    if fixed_base:
+        out.append('<link name="world"/>')
+    for i in range(n_links):
+        m = float(rng.uniform(0.5, 2.0))
+        com = tuple(float(v) for v in rng.uniform(-0.1, 0.1, 3))
+        dims = tuple(float(v) for v in rng.uniform(0.05, 0.3, 3))
+        rpy = tuple(float(v) for v in rng.uniform(-0.5, 0.5, 3))
+        coll = _box_collision(dims, xyz=com) if (not fixed_base and i in (0, n_links - 1)) else ""
+        out.append(f'<link name="link{i:02d}">' + _inertial(m, com=com, I=_box_inertia(m, *dims), rpy=rpy) + coll + "</link>")
+    if fixed_base:
+        out.append(_joint("world_to_base", "fixed", "world", "link00", (0.1, -0.2, 0.5), (0, 0, 0), rpy=(0.1, 0.2, 0.3)))
+    for i in range(1, n_links):
+        parent = int(rng.integers(max(0, i - 3), i))
+        jt = "prismatic" if rng.uniform() < 0.25 else "revolute"
+        axis = rng.normal(size=3)
+        axis = tuple(float(v) for v in axis / np.linalg.norm(axis))
+        xyz = tuple(float(v) for v in rng.uniform(-0.3, 0.3, 3))
+        rpy = tuple(float(v) for v in rng.uniform(-1.0, 1.0, 3))
+        out.append(_joint(f"joint{i:02d}", jt, f"link{parent:02d}", f"link{i:02d}", xyz, axis, rpy=rpy,
+                          lower=-1.5, upper=1.5, damping=float(rng.uniform(0, 0.2)), friction=float(rng.uniform(0, 0.1))))
+    out.append("</robot>")
+    return "".join(out)
