@@ -1,0 +1,167 @@
+/* jaxsim_amd -- C ABI of the MI355X-native batched rigid-body step.
+ *
+ * Drop-in boundary for the hot path of ami-iit/jaxsim.  The reference has no FFI seam: the
+ * path sits behind plain Python functions taking (model, data) pytrees.  Each entry point
+ * below names the reference function it replaces (paths relative to the reference root).
+ * A Python maintainer binds these with ctypes (INTEGRATION.md shows the stub); the in-tree
+ * binding is jaxsim_amd/_lib.py.
+ *
+ * Conventions
+ *  - plain C types only; no torch / HIP types in signatures (streams are `void*`
+ *    = hipStream_t, NULL = default stream);
+ *  - every batched array is a *device* pointer laid out [row][N] with the batch index N
+ *    fastest (struct-of-arrays), dtype = the model's dtype (float or double);
+ *  - state block rows (reference `JaxSimModelData`, src/jaxsim/api/data.py:46-63; the base
+ *    velocity is stored inertial-fixed like the reference, :151-156,187-188):
+ *        base_position[3] base_quaternion[4] (wxyz) joint_positions[n]
+ *        base_linear_velocity[3] base_angular_velocity[3] joint_velocities[n]
+ *        tangential_deformation[n_cp][3]
+ *    row offsets are reported by jxs_model_layout();
+ *  - all kernels are asynchronous on the given stream; the caller synchronises;
+ *  - functions return 0 on success, a negative JXS_E* code otherwise, and
+ *    jxs_last_error() returns a thread-local message.  No exceptions cross the ABI.
+ */
+#ifndef JAXSIM_AMD_H
+#define JAXSIM_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JXS_OK 0
+#define JXS_EINVAL (-1)      /* bad argument / unsupported model                     */
+#define JXS_ENODEVICE (-2)   /* no HIP device / HIP runtime error                    */
+#define JXS_ENOMEM (-3)
+#define JXS_ECOMM (-4)       /* RCCL error                                           */
+
+#define JXS_F32 0
+#define JXS_F64 1
+
+/* Velocity / force representations: src/jaxsim/api/common.py:39-47 */
+#define JXS_REPR_INERTIAL 0
+#define JXS_REPR_BODY 1
+#define JXS_REPR_MIXED 2
+
+/* Host description of one model: the static tables of `KinDynParameters`
+ * (src/jaxsim/api/kin_dyn_parameters.py:86-284) plus the model-level constants of
+ * `JaxSimModel` (src/jaxsim/api/model.py:52-82).  All arrays are host pointers, indexed by
+ * the reference link index (entry 0 of the per-joint arrays is unused: joint i moves link i).
+ */
+typedef struct jxs_model_desc {
+  int32_t n_links;
+  int32_t floating_base;
+  int32_t dtype; /* JXS_F32 | JXS_F64 */
+  const int32_t* parent;        /* [nL]   parent_array, parent[0] = -1                      */
+  const int32_t* joint_type;    /* [nL]   1 revolute, 2 prismatic (math/joint_model.py)     */
+  const double* joint_axis;     /* [nL][3]                                                  */
+  const double* lambda_H_pre;   /* [nL][16] row-major 4x4                                   */
+  const double* suc_H_i;        /* [nL][16]                                                 */
+  const double* link_mass;      /* [nL]                                                     */
+  const double* link_com;       /* [nL][3]                                                  */
+  const double* link_inertia;   /* [nL][9] I_CoM row-major                                  */
+  const double* friction_static;       /* [nL] */
+  const double* friction_viscous;      /* [nL] */
+  const double* position_limit_min;    /* [nL] */
+  const double* position_limit_max;    /* [nL] */
+  const double* position_limit_spring; /* [nL] */
+  const double* position_limit_damper; /* [nL] */
+  int32_t n_points;               /* collidable points (ContactParameters, :765-840)        */
+  const int32_t* point_body;      /* [n_points]                                             */
+  const double* point_position;   /* [n_points][3]                                          */
+  const uint8_t* point_enabled;   /* [n_points]                                             */
+  double time_step;               /* api/model.py:54-56                                     */
+  double gravity;                 /* signed z acceleration (-9.81)                          */
+  double K, D, mu, p, q;          /* SoftContactsParams, rbda/contacts/soft.py:24-46        */
+  double terrain_height;          /* FlatTerrain, terrain/terrain.py:65-124                 */
+  double torque_max, omega_th, omega_max; /* ActuationParams, rbda/actuation/common.py:16-19 */
+  int32_t enable_friction;
+} jxs_model_desc;
+
+typedef struct jxs_model jxs_model; /* opaque, immutable after creation, shareable */
+
+typedef struct jxs_layout {
+  int32_t n_links, n_joints, n_points, n_rows;
+  int32_t row_pos, row_quat, row_s, row_vlin, row_vang, row_sd, row_m;
+  int32_t group; /* lanes per environment chosen for this model */
+  int32_t dtype;
+} jxs_layout;
+
+/* ---- library / device ---------------------------------------------------------------- */
+const char* jxs_last_error(void);
+int jxs_device_count(int* count);
+int jxs_set_device(int device);
+int jxs_malloc(void** dptr, uint64_t bytes);
+int jxs_free(void* dptr);
+int jxs_memcpy_h2d(void* dst, const void* src, uint64_t bytes, void* stream);
+int jxs_memcpy_d2h(void* dst, const void* src, uint64_t bytes, void* stream);
+int jxs_memcpy_d2d(void* dst, const void* src, uint64_t bytes, void* stream);
+int jxs_memset(void* dst, int value, uint64_t bytes, void* stream);
+int jxs_stream_create(void** stream);
+int jxs_stream_destroy(void* stream);
+int jxs_stream_synchronize(void* stream);
+int jxs_device_synchronize(void);
+/* HIP events on a stream (bench.py times the step kernel with these). */
+int jxs_event_create(void** event);
+int jxs_event_destroy(void* event);
+int jxs_event_record(void* event, void* stream);
+int jxs_event_elapsed_ms(void* start, void* stop, float* ms);
+
+/* ---- model ----------------------------------------------------------------------------
+ * Replaces JaxSimModel.build / KinDynParameters.build as far as the device is concerned:
+ * uploads the constant tables (src/jaxsim/api/model.py:225-330).                        */
+int jxs_model_create(const jxs_model_desc* desc, jxs_model** out);
+int jxs_model_destroy(jxs_model* model);
+int jxs_model_layout(const jxs_model* model, jxs_layout* out);
+
+/* ---- hot path ------------------------------------------------------------------------- */
+
+/* js.model.step (src/jaxsim/api/model.py:2601-2681): actuation model -> soft contacts ->
+ * ABA -> semi-implicit Euler.  state_out may alias state_in (in-place).  `tau` =
+ * joint_force_references [n][N] or NULL (zeros); `link_forces` = [nL*6][N] or NULL,
+ * expressed in `force_repr` (the data's velocity representation, api/model.py:2641-2646). */
+int jxs_step(jxs_model* model, const void* state_in, void* state_out, const void* tau,
+             const void* link_forces, int force_repr, int N, void* stream);
+
+/* `n_steps` consecutive steps with constant inputs in ONE launch sequence (what a
+ * `jax.lax.fori_loop` over `step` does in the reference's notebooks); in place.           */
+int jxs_rollout(jxs_model* model, void* state, const void* tau, const void* link_forces,
+                int force_repr, int N, int n_steps, void* stream);
+
+/* forward_dynamics_aba (src/jaxsim/api/model.py:1269-1406) in inertial representation:
+ * out_acc = [6+n][N] = inertial-fixed base acceleration then joint accelerations.
+ * `joint_forces` are applied as given (no actuation model), no contact forces.          */
+int jxs_forward_dynamics_aba(jxs_model* model, const void* state, const void* joint_forces,
+                             const void* link_forces, int force_repr, void* out_acc, int N,
+                             void* stream);
+
+/* inverse_dynamics / RNEA (src/jaxsim/api/model.py:1746-1894, rbda/rnea.py:12-238) in
+ * inertial representation: in_acc = [6+n][N] (base acceleration, joint accelerations) or
+ * NULL (zeros => free_floating_bias_forces, :1934-1978); out = [6+n][N] = base wrench then
+ * joint torques.                                                                        */
+int jxs_inverse_dynamics(jxs_model* model, const void* state, const void* in_acc,
+                         const void* link_forces, int force_repr, void* out_forces, int N,
+                         void* stream);
+
+/* The cached kinematics of JaxSimModelData.replace (src/jaxsim/api/data.py:405-523,
+ * rbda/forward_kinematics.py:12-113): link transforms [nL*12][N] (rows of [R|p]) and
+ * inertial-fixed link velocities [nL*6][N]; either output may be NULL.                  */
+int jxs_refresh_kinematics(jxs_model* model, const void* state, void* out_link_transforms,
+                           void* out_link_velocities, int N, void* stream);
+
+/* ---- multi-GPU: one process per GPU, batch sharded, no per-step communication ---------
+ * One RCCL all-gather over xGMI concatenates the final state shards (SURVEY.md section
+ * 8(e)); the reference has no counterpart (single-device JAX).  The 128-byte unique id is
+ * created on rank 0 and distributed by the host launcher (torch.distributed / MPI / file). */
+int jxs_comm_unique_id(char id[128]);
+int jxs_comm_init(void** comm, const char id[128], int rank, int world_size);
+int jxs_comm_destroy(void* comm);
+/* recv[world][rows][n_local]  <-  send[rows][n_local] of every rank */
+int jxs_allgather(void* comm, const void* send, void* recv, uint64_t count, int dtype,
+                  void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JAXSIM_AMD_H */

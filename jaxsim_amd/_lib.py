@@ -1,0 +1,223 @@
+"""ctypes binding of the C-ABI library (``include/jaxsim_amd.h``).
+
+The product path has no CPU fallback: if ``libjaxsim_amd.so`` cannot be loaded, or no HIP
+device answers, every entry point raises ``JaxsimAmdError`` loudly.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+import pathlib
+
+import numpy as np
+
+_HERE = pathlib.Path(__file__).resolve().parent
+LIB_PATH = _HERE / "csrc" / "libjaxsim_amd.so"
+
+JXS_F32, JXS_F64 = 0, 1
+
+
+class JaxsimAmdError(RuntimeError):
+    pass
+
+
+class ModelDesc(C.Structure):
+    """``jxs_model_desc`` (include/jaxsim_amd.h)."""
+
+    _fields_ = [
+        ("n_links", C.c_int32),
+        ("floating_base", C.c_int32),
+        ("dtype", C.c_int32),
+        ("parent", C.POINTER(C.c_int32)),
+        ("joint_type", C.POINTER(C.c_int32)),
+        ("joint_axis", C.POINTER(C.c_double)),
+        ("lambda_H_pre", C.POINTER(C.c_double)),
+        ("suc_H_i", C.POINTER(C.c_double)),
+        ("link_mass", C.POINTER(C.c_double)),
+        ("link_com", C.POINTER(C.c_double)),
+        ("link_inertia", C.POINTER(C.c_double)),
+        ("friction_static", C.POINTER(C.c_double)),
+        ("friction_viscous", C.POINTER(C.c_double)),
+        ("position_limit_min", C.POINTER(C.c_double)),
+        ("position_limit_max", C.POINTER(C.c_double)),
+        ("position_limit_spring", C.POINTER(C.c_double)),
+        ("position_limit_damper", C.POINTER(C.c_double)),
+        ("n_points", C.c_int32),
+        ("point_body", C.POINTER(C.c_int32)),
+        ("point_position", C.POINTER(C.c_double)),
+        ("point_enabled", C.POINTER(C.c_uint8)),
+        ("time_step", C.c_double),
+        ("gravity", C.c_double),
+        ("K", C.c_double),
+        ("D", C.c_double),
+        ("mu", C.c_double),
+        ("p", C.c_double),
+        ("q", C.c_double),
+        ("terrain_height", C.c_double),
+        ("torque_max", C.c_double),
+        ("omega_th", C.c_double),
+        ("omega_max", C.c_double),
+        ("enable_friction", C.c_int32),
+    ]
+
+
+class Layout(C.Structure):
+    """``jxs_layout`` (include/jaxsim_amd.h)."""
+
+    _fields_ = [(n, C.c_int32) for n in (
+        "n_links", "n_joints", "n_points", "n_rows", "row_pos", "row_quat", "row_s", "row_vlin",
+        "row_vang", "row_sd", "row_m", "group", "dtype")]  # fmt: skip
+
+
+def dtype_code(dtype) -> int:
+    dt = np.dtype(dtype)
+    if dt == np.float32:
+        return JXS_F32
+    if dt == np.float64:
+        return JXS_F64
+    raise ValueError(f"unsupported dtype {dt}; use float32 or float64")
+
+
+def make_desc(model, dtype) -> tuple[ModelDesc, list]:
+    """Flatten a host ``JaxSimModel`` into a ``jxs_model_desc``.
+
+    Returns the struct and the list of NumPy arrays that back its pointers (keep it alive).
+    """
+    kdp = model.kin_dyn_parameters
+    nL = kdp.number_of_links()
+    keep = []
+
+    def dptr(a, shape):
+        arr = np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(shape))
+        keep.append(arr)
+        return arr.ctypes.data_as(C.POINTER(C.c_double))
+
+    def iptr(a, n):
+        arr = np.ascontiguousarray(np.asarray(a, dtype=np.int32).reshape(n))
+        keep.append(arr)
+        return arr.ctypes.data_as(C.POINTER(C.c_int32))
+
+    def per_joint(a, fill=0.0):
+        return np.concatenate([[fill], np.asarray(a, dtype=np.float64).reshape(nL - 1)])
+
+    fmax = np.finfo(np.float64).max
+    d = ModelDesc()
+    d.n_links = nL
+    d.floating_base = int(model.floating_base())
+    d.dtype = dtype_code(dtype)
+    d.parent = iptr(kdp.parent_array, nL)
+    d.joint_type = iptr(np.concatenate([[0], kdp.joint_types]), nL)
+    d.joint_axis = dptr(np.vstack([np.zeros((1, 3)), kdp.joint_axis.reshape(nL - 1, 3)]), (nL, 3))
+    d.lambda_H_pre = dptr(kdp.lambda_H_pre, (nL, 16))
+    d.suc_H_i = dptr(kdp.suc_H_i, (nL, 16))
+    d.link_mass = dptr(kdp.link_mass, (nL,))
+    d.link_com = dptr(kdp.link_com, (nL, 3))
+    d.link_inertia = dptr(kdp.link_inertia_com, (nL, 9))
+    d.friction_static = dptr(per_joint(kdp.friction_static), (nL,))
+    d.friction_viscous = dptr(per_joint(kdp.friction_viscous), (nL,))
+    d.position_limit_min = dptr(per_joint(kdp.position_limits_min, -fmax), (nL,))
+    d.position_limit_max = dptr(per_joint(kdp.position_limits_max, fmax), (nL,))
+    d.position_limit_spring = dptr(per_joint(kdp.position_limit_spring), (nL,))
+    d.position_limit_damper = dptr(per_joint(kdp.position_limit_damper), (nL,))
+    n_cp = kdp.number_of_collidable_points()
+    d.n_points = n_cp
+    d.point_body = iptr(kdp.contact_body if n_cp else np.zeros(1), max(n_cp, 1))
+    d.point_position = dptr(kdp.contact_point if n_cp else np.zeros((1, 3)), (max(n_cp, 1), 3))
+    en = np.ascontiguousarray(np.asarray(kdp.contact_enabled if n_cp else np.zeros(1), dtype=np.uint8))
+    keep.append(en)
+    d.point_enabled = en.ctypes.data_as(C.POINTER(C.c_uint8))
+    d.time_step = float(model.time_step)
+    d.gravity = float(model.gravity)
+    cp = model.contact_params
+    d.K, d.D, d.mu, d.p, d.q = float(cp.K), float(cp.D), float(cp.mu), float(cp.p), float(cp.q)
+    d.terrain_height = float(model.terrain._height)
+    ap = model.actuation_params
+    d.torque_max, d.omega_th, d.omega_max = float(ap.torque_max), float(ap.omega_th), float(ap.omega_max)
+    d.enable_friction = int(bool(ap.enable_friction))
+    return d, keep
+
+
+def model_signature(model, dtype) -> tuple:
+    """Everything the device copy depends on; a change rebuilds the device tables."""
+    kdp = model.kin_dyn_parameters
+    cp, ap = model.contact_params, model.actuation_params
+    return (
+        id(kdp), np.dtype(dtype).str, model.time_step, model.gravity, model.floating_base(),
+        cp.K, cp.D, cp.mu, cp.p, cp.q, model.terrain._height,
+        ap.torque_max, ap.omega_th, ap.omega_max, ap.enable_friction,
+    )  # fmt: skip
+
+
+_lib = None
+
+
+def _declare(lib):
+    vp, cp_ = C.c_void_p, C.c_char_p
+    lib.jxs_last_error.restype = cp_
+    lib.jxs_last_error.argtypes = []
+    sig = {
+        "jxs_device_count": [C.POINTER(C.c_int)],
+        "jxs_set_device": [C.c_int],
+        "jxs_malloc": [C.POINTER(vp), C.c_uint64],
+        "jxs_free": [vp],
+        "jxs_memcpy_h2d": [vp, vp, C.c_uint64, vp],
+        "jxs_memcpy_d2h": [vp, vp, C.c_uint64, vp],
+        "jxs_memcpy_d2d": [vp, vp, C.c_uint64, vp],
+        "jxs_memset": [vp, C.c_int, C.c_uint64, vp],
+        "jxs_stream_create": [C.POINTER(vp)],
+        "jxs_stream_destroy": [vp],
+        "jxs_stream_synchronize": [vp],
+        "jxs_device_synchronize": [],
+        "jxs_event_create": [C.POINTER(vp)],
+        "jxs_event_destroy": [vp],
+        "jxs_event_record": [vp, vp],
+        "jxs_event_elapsed_ms": [vp, vp, C.POINTER(C.c_float)],
+        "jxs_model_create": [C.POINTER(ModelDesc), C.POINTER(vp)],
+        "jxs_model_destroy": [vp],
+        "jxs_model_layout": [vp, C.POINTER(Layout)],
+        "jxs_step": [vp, vp, vp, vp, vp, C.c_int, C.c_int, vp],
+        "jxs_rollout": [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp],
+        "jxs_forward_dynamics_aba": [vp, vp, vp, vp, C.c_int, vp, C.c_int, vp],
+        "jxs_inverse_dynamics": [vp, vp, vp, vp, C.c_int, vp, C.c_int, vp],
+        "jxs_refresh_kinematics": [vp, vp, vp, vp, C.c_int, vp],
+        "jxs_comm_unique_id": [C.c_char * 128],
+        "jxs_comm_init": [C.POINTER(vp), C.c_char * 128, C.c_int, C.c_int],
+        "jxs_comm_destroy": [vp],
+        "jxs_allgather": [vp, vp, vp, C.c_uint64, C.c_int, vp],
+    }
+    for name, args in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = C.c_int
+        fn.argtypes = args
+    return sig
+
+
+EXPORTED_SYMBOLS = None
+
+
+def load(path: os.PathLike | None = None):
+    """Load ``libjaxsim_amd.so`` (built by ``__graft_entry__.build()`` / ``csrc/build.sh``)."""
+    global _lib, EXPORTED_SYMBOLS
+    if _lib is not None and path is None:
+        return _lib
+    p = pathlib.Path(path) if path is not None else LIB_PATH
+    if not p.exists():
+        raise JaxsimAmdError(
+            f"HIP extension not built: {p} is missing. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or jaxsim_amd/csrc/build.sh). There is no CPU fallback."
+        )
+    try:
+        lib = C.CDLL(str(p))
+    except OSError as e:  # missing ROCm runtime, wrong arch, ...
+        raise JaxsimAmdError(f"cannot load {p}: {e}") from e
+    EXPORTED_SYMBOLS = tuple(_declare(lib).keys()) + ("jxs_last_error",)
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().jxs_last_error()
+        raise JaxsimAmdError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,866 @@
+// Kernel core of the batched rigid-body step: one link per lane, one environment per lane
+// group, wavefront shuffles along the kinematic tree.  Templated on the lane backend so the
+// identical source runs as the gfx950 kernel (jxs_lanes_device.h) and as a host lockstep
+// emulation in the CPU tests (tests/emul/jxs_lanes_host.h).  The code is branch-free over
+// lane values: every branch below is wave-uniform (depends only on KParams / the mode).
+//
+// Formulation: the reference runs Featherstone's ABA in link
+// coordinates with 6x6 Pluecker transforms between neighbours (`src/jaxsim/rbda/aba.py`).
+// Here every spatial quantity is expressed in ONE frame C = (origin at the base-link
+// position, world-aligned axes, at rest).  All neighbour transforms become the identity, so
+// the serial sweeps shrink to "add the child's articulated inertia to the parent", and
+// forward kinematics / velocities / RNEA accelerations become tree prefix sums done by
+// pointer jumping in ceil(log2(depth+1)) shuffle rounds.  Spatial vectors are
+// [linear; angular] like the reference (`src/jaxsim/math/adjoint.py:92-107`); in exact
+// arithmetic the results equal the reference's.
+//
+// Reference rows implemented here:
+//   B actuation   api/actuation_model.py:7-126      H joint transforms  api/kin_dyn_parameters.py:396-451
+//   M kinematics  rbda/forward_kinematics.py:12-113 J,K,L soft contacts rbda/contacts/soft.py:195-444
+//   I point->link api/contact.py:557-603            G ABA               rbda/aba.py:12-292
+//   C integrator  api/integrators.py:14-88          R RNEA              rbda/rnea.py:12-238
+//   A step glue   api/model.py:2601-2681            N cache refresh     api/data.py:405-523
+#pragma once
+#include "jxs_params.h"
+
+namespace jxs {
+
+template <class L>
+struct Core {
+  using T = typename L::T;
+  using V = typename L::V;
+  using VI = typename L::VI;
+  using VM = typename L::VM;
+  static constexpr int G = L::G;
+
+  const KParams<T>& P;
+  const KArgs<T>& A;
+  const L& ln;
+
+  JXS_HD Core(const KParams<T>& p, const KArgs<T>& a, const L& l) : P(p), A(a), ln(l) {}
+
+  // ---- small dense helpers on lane values ------------------------------------------------
+  static JXS_HD void cross(const V* a, const V* b, V* o) {
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+  }
+  static JXS_HD void mat3vec(const V* R, const V* x, V* o) {  // o = R x, R row-major
+    o[0] = R[0] * x[0] + R[1] * x[1] + R[2] * x[2];
+    o[1] = R[3] * x[0] + R[4] * x[1] + R[5] * x[2];
+    o[2] = R[6] * x[0] + R[7] * x[1] + R[8] * x[2];
+  }
+  static JXS_HD void mat3mul(const V* a, const V* b, V* o) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) o[3 * i + j] = a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j] + a[3 * i + 2] * b[6 + j];
+  }
+  // symmetric 6x6 stored as upper triangle, row-major: idx(i,j), i <= j
+  static JXS_HD constexpr int sidx(int i, int j) {
+    return (i <= j) ? (i * 6 - (i * (i - 1)) / 2 + (j - i)) : (j * 6 - (j * (j - 1)) / 2 + (i - j));
+  }
+
+  // ==========================================================================================
+  template <int MODE>
+  JXS_HD void run() {
+    const VI lane = ln.lane();
+    const VI jtype = ln.lconsti(A.lti, LI_JTYPE);
+    const VI parent = ln.lconsti(A.lti, LI_PARENT);
+    const VI level = ln.lconsti(A.lti, LI_LEVEL);
+    const VM is_joint = jtype != 0;
+    const VM is_rev = jtype == 1;
+    const VM is_pri = jtype == 2;
+    const VM is_root = level == 0;
+    const VI jrow = lane - 1;  // joint arrays are 0-based: ii = i - 1   (rbda/aba.py:133)
+
+    // ---- state (row D) -----------------------------------------------------------------
+    const V s = ln.gload(A.state_in, jrow + P.row_s, is_joint);
+    const V sd = ln.gload(A.state_in, jrow + P.row_sd, is_joint);
+    V pB[3], q[4], vW[3], om[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      pB[k] = ln.gload_u(A.state_in, P.row_pos + k);
+      vW[k] = ln.gload_u(A.state_in, P.row_vlin + k);
+      om[k] = ln.gload_u(A.state_in, P.row_vang + k);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) q[k] = ln.gload_u(A.state_in, P.row_quat + k);
+
+    // ---- B: joint torques (api/actuation_model.py:7-126) --------------------------------
+    V tau = (A.tau != nullptr) ? ln.gload(A.tau, jrow, is_joint) : V(T(0));
+    if (MODE == MODE_STEP) {
+      const V smin = ln.lconstf(A.ltf, LF_SMIN), smax = ln.lconstf(A.ltf, LF_SMAX);
+      const V klim = ln.lconstf(A.ltf, LF_KLIM), dlim = ln.lconstf(A.ltf, LF_DLIM);
+      const V lower = vmin(s - smin, V(T(0)));  // clip(max=0)
+      const V upper = vmax(s - smax, V(T(0)));  // clip(min=0)
+      V tau_pl = -(klim * (lower + upper));
+      // `jnp.positive` is unary plus: tau_pl -= tau_pl * d * sd   (actuation_model.py:64-66)
+      tau_pl = tau_pl - tau_pl * (dlim * sd);
+      V tau_fr = V(T(0));
+      if (P.enable_friction) {
+        const V kc = ln.lconstf(A.ltf, LF_KC), kv = ln.lconstf(A.ltf, LF_KV);
+        const V sgn = vsel(sd > V(T(0)), V(T(1)), vsel(sd < V(T(0)), V(T(-1)), V(T(0))));
+        tau_fr = -(kc * sgn + kv * sd);
+      }
+      const V tot = tau + tau_fr + tau_pl;
+      const V av = vabs(sd);
+      const V lim = vsel(av <= V(P.w_th), V(P.tau_max),
+                         vsel(av <= V(P.w_max), P.tau_max * (V(T(1)) - (av - P.w_th) / (P.w_max - P.w_th)), V(T(0))));
+      tau = vmax(vmin(tot, lim), -lim);  // clip(tot, -lim, lim)
+    }
+
+    // ---- base rotation: DCM of q/|q| (data.base_orientation, api/data.py:267-286) --------
+    V R[9], r[3];
+    {
+      const V nsq = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+      const V nrm = vsqrt(nsq);
+      const V inv = V(T(1)) / (nrm + vsel(nrm == V(T(0)), V(P.eps), V(T(0))));
+#pragma unroll
+      for (int k = 0; k < 4; ++k) q[k] = q[k] * inv;
+    }
+    V R0[9];
+    {
+      const V w = q[0], x = q[1], y = q[2], z = q[3];
+      const V two = V(T(2));
+      R0[0] = V(T(1)) - two * (y * y + z * z);
+      R0[1] = two * (x * y - w * z);
+      R0[2] = two * (x * z + w * y);
+      R0[3] = two * (x * y + w * z);
+      R0[4] = V(T(1)) - two * (x * x + z * z);
+      R0[5] = two * (y * z - w * x);
+      R0[6] = two * (x * z - w * y);
+      R0[7] = two * (y * z + w * x);
+      R0[8] = V(T(1)) - two * (x * x + y * y);
+    }
+
+    // ---- H: local parent->child transform lambda_H_pre * pre_H_suc(s) * suc_H_i ----------
+    //      (api/kin_dyn_parameters.py:396-451, math/joint_model.py:146-200, math/rotation.py:58-84)
+    V ax[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) ax[k] = ln.lconstf(A.ltf, LF_AXIS + k);
+    {
+      V sn, cs;
+      vsincos(vsel(is_rev, s, V(T(0))), sn, cs);
+      const V hs = vsin(vsel(is_rev, s, V(T(0))) * T(0.5));
+      const V c1 = T(2) * hs * hs;  // 1 - cos, computed as 2 sin^2(theta/2) like the reference
+      V Rj[9];
+      Rj[0] = cs + c1 * ax[0] * ax[0];
+      Rj[1] = -sn * ax[2] + c1 * ax[0] * ax[1];
+      Rj[2] = sn * ax[1] + c1 * ax[0] * ax[2];
+      Rj[3] = sn * ax[2] + c1 * ax[1] * ax[0];
+      Rj[4] = cs + c1 * ax[1] * ax[1];
+      Rj[5] = -sn * ax[0] + c1 * ax[1] * ax[2];
+      Rj[6] = -sn * ax[1] + c1 * ax[2] * ax[0];
+      Rj[7] = sn * ax[0] + c1 * ax[2] * ax[1];
+      Rj[8] = cs + c1 * ax[2] * ax[2];
+      V pj[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) pj[k] = vsel(is_pri, s * ax[k], V(T(0)));
+      V Rpre[9], ppre[3];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) Rpre[k] = ln.lconstf(A.ltf, LF_RPRE + k);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) ppre[k] = ln.lconstf(A.ltf, LF_PPRE + k);
+      V Rl[9], pl[3];
+      if (P.any_suc) {
+        V Rsuc[9], psuc[3], tmp[9], t3[3];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Rsuc[k] = ln.lconstf(A.ltf, LF_RSUC + k);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) psuc[k] = ln.lconstf(A.ltf, LF_PSUC + k);
+        mat3mul(Rj, Rsuc, tmp);
+        mat3mul(Rpre, tmp, Rl);
+        mat3vec(Rj, psuc, t3);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) t3[k] = t3[k] + pj[k];
+        mat3vec(Rpre, t3, pl);
+      } else {
+        mat3mul(Rpre, Rj, Rl);
+        mat3vec(Rpre, pj, pl);
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) pl[k] = pl[k] + ppre[k];
+      // The base lane starts from (R0, 0): frame C has its origin at the base position.
+#pragma unroll
+      for (int k = 0; k < 9; ++k) R[k] = vsel(is_root, R0[k], Rl[k]);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) r[k] = vsel(is_root, V(T(0)), pl[k]);
+    }
+
+    // ---- M: forward kinematics as a tree prefix product (pointer jumping) ----------------
+    //      equals the scan of rbda/forward_kinematics.py:80-103 in exact arithmetic
+    for (int k = 0; k < P.n_rounds; ++k) {
+      const VI src = ln.lconsti(A.lti, LI_JUMP + k);
+      const VM ok = src >= 0;
+      V Ra[9], ra[3];
+#pragma unroll
+      for (int e = 0; e < 9; ++e) Ra[e] = ln.shfl(R[e], src);
+#pragma unroll
+      for (int e = 0; e < 3; ++e) ra[e] = ln.shfl(r[e], src);
+      V Rn[9], rn[3];
+      mat3mul(Ra, R, Rn);
+      mat3vec(Ra, r, rn);
+#pragma unroll
+      for (int e = 0; e < 9; ++e) R[e] = vsel(ok, Rn[e], R[e]);
+#pragma unroll
+      for (int e = 0; e < 3; ++e) r[e] = vsel(ok, rn[e] + ra[e], r[e]);
+    }
+
+    // Base velocity in C: [v_W + w x p_B ; w] (= mixed velocity).  ABA keeps v_0 = 0 for a
+    // fixed base (rbda/aba.py:109-121) while the cached link velocities still start from the
+    // stored base velocity (rbda/forward_kinematics.py:69-70): `vBx` carries that difference.
+    V vBc[3];
+    cross(om, pB, vBc);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) vBc[k] = vBc[k] + vW[k];
+
+    // ---- motion subspace in C: S = W_X_i [0;a] or W_X_i [a;0]  (kin_dyn_parameters.py:239-261)
+    V Sl[3], Sa[3], Ra_[3];
+    mat3vec(R, ax, Ra_);
+    {
+      V rxa[3];
+      cross(r, Ra_, rxa);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        Sa[k] = vsel(is_rev, Ra_[k], V(T(0)));
+        Sl[k] = vsel(is_rev, rxa[k], vsel(is_pri, Ra_[k], V(T(0))));
+      }
+    }
+
+    // ---- link velocities: v_i = v_lambda + S_i sd_i  -> prefix sum over ancestors --------
+    V vJl[3], vJa[3], vl[3], va[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      vJl[k] = Sl[k] * sd;
+      vJa[k] = Sa[k] * sd;
+      vl[k] = vsel(is_root, P.floating ? vBc[k] : V(T(0)), vJl[k]);
+      va[k] = vsel(is_root, P.floating ? om[k] : V(T(0)), vJa[k]);
+    }
+    prefix6(vl, va);
+
+    // c_i = v_i x vJ_i   (Cross.vx, math/cross.py:14-43; rbda/aba.py:141)
+    V cl[3], ca[3];
+    {
+      V t0[3], t1[3];
+      cross(va, vJl, t0);
+      cross(vl, vJa, t1);
+      cross(va, vJa, ca);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) cl[k] = t0[k] + t1[k];
+    }
+
+    // offset of the cached kinematics w.r.t. the ABA base frame (quirk 12): R0 * p(suc_H_i[0])
+    V doff[3];
+    {
+      V bo[3] = {V(P.base_off[0]), V(P.base_off[1]), V(P.base_off[2])};
+      mat3vec(R0, bo, doff);
+    }
+
+    if (MODE == MODE_KIN) {
+      store_kinematics(lane, level, R, r, vl, va, pB, doff, vBc, om);
+      return;
+    }
+
+    // ---- external link wrenches in C -----------------------------------------------------
+    V fl[3] = {V(T(0)), V(T(0)), V(T(0))}, fa[3] = {V(T(0)), V(T(0)), V(T(0))};
+    if (A.link_f != nullptr) {
+      const VM is_link = level >= 0;
+      V f6[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) f6[k] = ln.gload(A.link_f, lane * 6 + k, is_link);
+      V arm[3], t[3];
+      if (A.force_repr == REPR_INERTIAL) {
+        // [f; mu_W - p_B x f]
+        cross(pB, f6, t);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          fl[k] = f6[k];
+          fa[k] = f6[3 + k] - t[k];
+        }
+      } else {
+        // Mixed: [f; mu + p_L x f]; Body: [R f; R mu + p_L x R f]  (api/common.py:191-219),
+        // p_L from the cached link transforms (api/model.py:2641-2646).
+        V fw[3], mw[3];
+        if (A.force_repr == REPR_BODY) {
+          mat3vec(R, f6, fw);
+          mat3vec(R, f6 + 3, mw);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            fw[k] = f6[k];
+            mw[k] = f6[3 + k];
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) arm[k] = r[k] + doff[k];
+        cross(arm, fw, t);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          fl[k] = fw[k];
+          fa[k] = mw[k] + t[k];
+        }
+      }
+    }
+
+    // ---- J,K,L,I: soft contacts ----------------------------------------------------------
+    if (MODE == MODE_STEP && P.n_chunks > 0) contacts(lane, R, r, vl, va, pB, doff, vBc, om, fl, fa);
+
+    // ---- link inertia in C and bias force --------------------------------------------------
+    // M = [[m I, m S(c)^T],[m S(c), I_c + m S(c) S(c)^T]]  (math/inertia.py:14-41) with the CoM
+    // c = r + R c_L and I_c = R I_L R^T expressed in C.
+    const V mass = ln.lconstf(A.ltf, LF_MASS);
+    V cw[3], Ic[6];
+    {
+      V cL[3], IL[6];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) cL[k] = ln.lconstf(A.ltf, LF_COM + k);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) IL[k] = ln.lconstf(A.ltf, LF_ICOM + k);
+      mat3vec(R, cL, cw);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) cw[k] = cw[k] + r[k];
+      // T = R * I_L (3x3), then Ic = T * R^T (symmetric)
+      const V I9[9] = {IL[0], IL[1], IL[2], IL[1], IL[3], IL[4], IL[2], IL[4], IL[5]};
+      V Tm[9];
+      mat3mul(R, I9, Tm);
+      Ic[0] = Tm[0] * R[0] + Tm[1] * R[1] + Tm[2] * R[2];
+      Ic[1] = Tm[0] * R[3] + Tm[1] * R[4] + Tm[2] * R[5];
+      Ic[2] = Tm[0] * R[6] + Tm[1] * R[7] + Tm[2] * R[8];
+      Ic[3] = Tm[3] * R[3] + Tm[4] * R[4] + Tm[5] * R[5];
+      Ic[4] = Tm[3] * R[6] + Tm[4] * R[7] + Tm[5] * R[8];
+      Ic[5] = Tm[6] * R[6] + Tm[7] * R[7] + Tm[8] * R[8];
+    }
+    // h = M v:  h_lin = m (v + w x c),  h_ang = I_c w + c x h_lin
+    V hl[3], ha[3];
+    {
+      V t[3];
+      cross(va, cw, t);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) hl[k] = mass * (vl[k] + t[k]);
+      V Iw[3];
+      Iw[0] = Ic[0] * va[0] + Ic[1] * va[1] + Ic[2] * va[2];
+      Iw[1] = Ic[1] * va[0] + Ic[3] * va[1] + Ic[4] * va[2];
+      Iw[2] = Ic[2] * va[0] + Ic[4] * va[1] + Ic[5] * va[2];
+      cross(cw, hl, t);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) ha[k] = Iw[k] + t[k];
+    }
+    // v x* h = [w x h_lin ; v x h_lin + w x h_ang]   (Cross.vx_star, math/cross.py:45-58)
+    V bl[3], ba[3];
+    {
+      V t0[3], t1[3];
+      cross(va, hl, bl);
+      cross(vl, hl, t0);
+      cross(va, ha, t1);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) ba[k] = t0[k] + t1[k];
+    }
+
+    if (MODE == MODE_ID) {
+      rnea(lane, jrow, level, parent, is_joint, is_root, Sl, Sa, cl, ca, mass, cw, Ic, bl, ba, fl, fa, pB);
+      return;
+    }
+
+    // ---- G: articulated-body algorithm ------------------------------------------------------
+    // pA_i = v x* M v - f_i          (rbda/aba.py:109-121,157-160)
+    V pA[6];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      pA[k] = bl[k] - fl[k];
+      pA[3 + k] = ba[k] - fa[k];
+    }
+    // MA_i = M_i (upper triangle of the symmetric 6x6)
+    V MA[21];
+    {
+      const V zero = V(T(0));
+      const V mcx = mass * cw[0], mcy = mass * cw[1], mcz = mass * cw[2];
+      // top-left: m I
+      MA[sidx(0, 0)] = mass; MA[sidx(0, 1)] = zero; MA[sidx(0, 2)] = zero;
+      MA[sidx(1, 1)] = mass; MA[sidx(1, 2)] = zero;
+      MA[sidx(2, 2)] = mass;
+      // top-right: m S(c)^T = -m S(c) = [[0, mcz, -mcy],[-mcz, 0, mcx],[mcy, -mcx, 0]]
+      MA[sidx(0, 3)] = zero; MA[sidx(0, 4)] = mcz; MA[sidx(0, 5)] = -mcy;
+      MA[sidx(1, 3)] = -mcz; MA[sidx(1, 4)] = zero; MA[sidx(1, 5)] = mcx;
+      MA[sidx(2, 3)] = mcy; MA[sidx(2, 4)] = -mcx; MA[sidx(2, 5)] = zero;
+      // bottom-right: I_c + m (|c|^2 I - c c^T)
+      const V cc = cw[0] * cw[0] + cw[1] * cw[1] + cw[2] * cw[2];
+      MA[sidx(3, 3)] = Ic[0] + mass * (cc - cw[0] * cw[0]);
+      MA[sidx(3, 4)] = Ic[1] - mcx * cw[1];
+      MA[sidx(3, 5)] = Ic[2] - mcx * cw[2];
+      MA[sidx(4, 4)] = Ic[3] + mass * (cc - cw[1] * cw[1]);
+      MA[sidx(4, 5)] = Ic[4] - mcy * cw[2];
+      MA[sidx(5, 5)] = Ic[5] + mass * (cc - cw[2] * cw[2]);
+    }
+    const V S6[6] = {Sl[0], Sl[1], Sl[2], Sa[0], Sa[1], Sa[2]};
+    const V c6[6] = {cl[0], cl[1], cl[2], ca[0], ca[1], ca[2]};
+
+    // Pass 2 (rbda/aba.py:184-224), leaves to base, one tree level per iteration.  In frame C
+    // the propagation X^T Ma X is the identity congruence: parents simply add.
+    V U[6], inv_d = V(T(0)), u = V(T(0));
+#pragma unroll
+    for (int k = 0; k < 6; ++k) U[k] = V(T(0));
+    VI child[kMaxChildren];
+#pragma unroll
+    for (int k = 0; k < kMaxChildren; ++k) child[k] = ln.lconsti(A.lti, LI_CHILD + k);
+    const int first_level = P.floating ? 1 : 2;  // fixed base: nothing propagates into link 0
+    for (int Lv = P.max_depth; Lv >= 1; --Lv) {
+      // U = MA S, d = S^T U, u = tau - S^T pA
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        V acc = MA[sidx(i, 0)] * S6[0];
+#pragma unroll
+        for (int j = 1; j < 6; ++j) acc = acc + MA[sidx(i, j)] * S6[j];
+        U[i] = acc;
+      }
+      V d = U[0] * S6[0], sp = pA[0] * S6[0];
+#pragma unroll
+      for (int i = 1; i < 6; ++i) {
+        d = d + U[i] * S6[i];
+        sp = sp + pA[i] * S6[i];
+      }
+      u = tau - sp;
+      inv_d = V(T(1)) / d;
+      if (Lv < first_level) break;
+      // Ma = MA - U U^T / d ;  pa = pA + Ma c + U u / d
+      V Ma[21], pa[6], Ud[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) Ud[i] = U[i] * inv_d;
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = i; j < 6; ++j) Ma[sidx(i, j)] = MA[sidx(i, j)] - Ud[i] * U[j];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        V acc = pA[i] + Ud[i] * u;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) acc = acc + Ma[sidx(i, j)] * c6[j];
+        pa[i] = acc;
+      }
+      // parents at level Lv-1 gather from their children (all at level Lv)
+      const VM is_par = level == (Lv - 1);
+#pragma unroll
+      for (int k = 0; k < kMaxChildren; ++k) {
+        if (k < P.maxch[Lv]) {
+          const VM ok = is_par && (child[k] >= 0);
+#pragma unroll
+          for (int e = 0; e < 21; ++e) MA[e] = MA[e] + vsel(ok, ln.shfl(Ma[e], child[k]), V(T(0)));
+#pragma unroll
+          for (int e = 0; e < 6; ++e) pA[e] = pA[e] + vsel(ok, ln.shfl(pa[e], child[k]), V(T(0)));
+        }
+      }
+    }
+    // U, 1/d, u of every lane are final here: a link's MA stops changing once its children
+    // (one level deeper) have been gathered, and the last iteration recomputed them for all lanes.
+
+    // Pass 3 (rbda/aba.py:240-267): base acceleration, then top-down.
+    V a6[6];
+    if (P.floating) {
+      solve6(MA, pA, a6);  // a0 = solve(-MA_0, pA_0), meaningful in the base lane only
+    } else {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) a6[k] = V(T(0));
+      a6[2] = V(-P.g);  // a0 = -B_X_W W_g expressed in C
+    }
+    V sdd = V(T(0));
+    for (int Lv = 1; Lv <= P.max_depth; ++Lv) {
+      V ap[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) ap[k] = ln.shfl(a6[k], parent);
+      const VM act = level == Lv;
+      V ai[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) ai[k] = ap[k] + c6[k];
+      V ua = U[0] * ai[0];
+#pragma unroll
+      for (int k = 1; k < 6; ++k) ua = ua + U[k] * ai[k];
+      const V sdd_i = (u - ua) * inv_d;
+      sdd = vsel(act, sdd_i, sdd);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) a6[k] = vsel(act, ai[k] + S6[k] * sdd_i, a6[k]);
+    }
+
+    // Base acceleration: W_a = a_0 + W_g (rbda/aba.py:284-292); the angular part is frame
+    // independent, the linear part is shifted back to the world origin at the end.
+    V acl[3], aca[3];  // base spatial acceleration in C (broadcast from the base lane)
+    {
+      const VI zero_lane = lane * 0;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        acl[k] = P.floating ? ln.shfl(a6[k], zero_lane) : V(T(0));
+        aca[k] = P.floating ? ln.shfl(a6[3 + k], zero_lane) : V(T(0));
+      }
+      if (P.floating) acl[2] = acl[2] + P.g;
+    }
+
+    if (MODE == MODE_FD) {
+      // inertial-fixed base acceleration: a_lin^W = a_lin^C - wdot x p_B
+      V t[3];
+      cross(aca, pB, t);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        ln.gstore(A.out_a, lane * 0 + k, acl[k] - t[k], is_root);
+        ln.gstore(A.out_a, lane * 0 + (3 + k), aca[k], is_root);
+      }
+      ln.gstore(A.out_a, jrow + 6, sdd, is_joint);
+      return;
+    }
+
+    // ---- C: semi-implicit Euler (api/integrators.py:14-88) ---------------------------------
+    {
+      const V dt = V(P.dt);
+      const V sd_new = sd + dt * sdd;
+      const V s_new = s + dt * sd_new;
+      ln.gstore(A.state_out, jrow + P.row_s, s_new, is_joint);
+      ln.gstore(A.state_out, jrow + P.row_sd, sd_new, is_joint);
+      // base: w+ = w + dt wdot ; pdot = (v_W + dt a_W) + w+ x p_B = vBc + dt a_lin^C
+      V omn[3], pd[3], t[3], vWn[3];
+      cross(aca, pB, t);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        omn[k] = om[k] + dt * aca[k];
+        pd[k] = vBc[k] + dt * acl[k];
+        vWn[k] = vW[k] + dt * (acl[k] - t[k]);
+      }
+      // Qdot = 1/2 Q_inertial(q) [K |w| (1 - |q|); w]   (math/quaternion.py:68-132)
+      const V nw = vsqrt(omn[0] * omn[0] + omn[1] * omn[1] + omn[2] * omn[2]);
+      const V nq = vsqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+      const V h0 = P.quat_K * nw * (V(T(1)) - nq);
+      const V half = V(T(0.5));
+      V qn[4];
+      qn[0] = q[0] + dt * half * (q[0] * h0 - q[1] * omn[0] - q[2] * omn[1] - q[3] * omn[2]);
+      qn[1] = q[1] + dt * half * (q[1] * h0 + q[0] * omn[0] + q[3] * omn[1] - q[2] * omn[2]);
+      qn[2] = q[2] + dt * half * (q[2] * h0 - q[3] * omn[0] + q[0] * omn[1] + q[1] * omn[2]);
+      qn[3] = q[3] + dt * half * (q[3] * h0 + q[2] * omn[0] - q[1] * omn[1] + q[0] * omn[2]);
+      const V nn = vsqrt(qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3]);
+      const V invn = V(T(1)) / vsel(nn == V(T(0)), V(T(1)), nn);
+      const VI zl = lane * 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) ln.gstore(A.state_out, zl + (P.row_quat + k), qn[k] * invn, is_root);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        ln.gstore(A.state_out, zl + (P.row_pos + k), pB[k] + dt * pd[k], is_root);
+        ln.gstore(A.state_out, zl + (P.row_vlin + k), vWn[k], is_root);
+        ln.gstore(A.state_out, zl + (P.row_vang + k), omn[k], is_root);
+      }
+    }
+  }
+
+  // ==========================================================================================
+  // inclusive prefix sum of a 6-vector over the ancestors of every lane (pointer jumping)
+  JXS_HD void prefix6(V* xl, V* xa) const {
+    for (int k = 0; k < P.n_rounds; ++k) {
+      const VI src = ln.lconsti(A.lti, LI_JUMP + k);
+      const VM ok = src >= 0;
+      V tl[3], ta[3];
+#pragma unroll
+      for (int e = 0; e < 3; ++e) {
+        tl[e] = ln.shfl(xl[e], src);
+        ta[e] = ln.shfl(xa[e], src);
+      }
+#pragma unroll
+      for (int e = 0; e < 3; ++e) {
+        xl[e] = xl[e] + vsel(ok, tl[e], V(T(0)));
+        xa[e] = xa[e] + vsel(ok, ta[e], V(T(0)));
+      }
+    }
+  }
+
+  // a = -MA^-1 pA for the symmetric positive-definite 6x6 MA (LDL^T, no pivoting)
+  JXS_HD void solve6(const V* MA, const V* pA, V* a) const {
+    V Lm[6][6], Dd[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      V dj = MA[sidx(j, j)];
+#pragma unroll
+      for (int k = 0; k < j; ++k) dj = dj - Lm[j][k] * Lm[j][k] * Dd[k];
+      Dd[j] = dj;
+      const V inv = V(T(1)) / dj;
+#pragma unroll
+      for (int i = j + 1; i < 6; ++i) {
+        V lij = MA[sidx(i, j)];
+#pragma unroll
+        for (int k = 0; k < j; ++k) lij = lij - Lm[i][k] * Lm[j][k] * Dd[k];
+        Lm[i][j] = lij * inv;
+      }
+    }
+    V y[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      V acc = -pA[i];
+#pragma unroll
+      for (int k = 0; k < i; ++k) acc = acc - Lm[i][k] * y[k];
+      y[i] = acc;
+    }
+#pragma unroll
+    for (int i = 5; i >= 0; --i) {
+      V acc = y[i] / Dd[i];
+#pragma unroll
+      for (int k = i + 1; k < 6; ++k) acc = acc - Lm[k][i] * a[k];
+      a[i] = acc;
+    }
+  }
+
+  // ==========================================================================================
+  // Soft contacts: point kinematics (rbda/collidable_points.py:9-65), penetration
+  // (rbda/contacts/common.py:25-63), Hunt-Crossley + stick/slip state
+  // (rbda/contacts/soft.py:195-388), per-link wrench sum (api/contact.py:557-603) and the
+  // Euler update of the tangential deformation (api/integrators.py:67-71).
+  JXS_HD void contacts(const VI& lane, const V* R, const V* r, const V* vl, const V* va, const V* pB,
+                       const V* doff, const V* vBc, const V* om, V* fl, V* fa) const {
+    const V zero = V(T(0));
+    for (int ch = 0; ch < P.n_chunks; ++ch) {
+      const VI slot = lane + ch * G;
+      const VI body = ln.ploadi(A.pti, PI_BODY, P.n_slots, slot);
+      const VI prow = ln.ploadi(A.pti, PI_ROW, P.n_slots, slot);
+      const VI tail = ln.ploadi(A.pti, PI_TAIL, P.n_slots, slot);
+      const VM valid = body >= 0;
+      V Lp[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) Lp[k] = ln.ploadf(A.ptf, PF_POS + k, P.n_slots, slot);
+      V m[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) m[k] = ln.gload(A.state_in, prow * 3 + (P.row_m + k), valid);
+      // kinematics of the parent link
+      V Rb[9], rb[3], vbl[3], vba[3];
+#pragma unroll
+      for (int e = 0; e < 9; ++e) Rb[e] = ln.shfl(R[e], body);
+#pragma unroll
+      for (int e = 0; e < 3; ++e) {
+        rb[e] = ln.shfl(r[e], body);
+        vbl[e] = ln.shfl(vl[e], body);
+        vba[e] = ln.shfl(va[e], body);
+      }
+      V rc0[3], rc[3], pw[3], pd[3], t[3];
+      mat3vec(Rb, Lp, rc0);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        rc0[k] = rc0[k] + rb[k];     // relative to the ABA base origin
+        rc[k] = rc0[k] + doff[k];    // relative to the base position, cached (FK) placement
+        pw[k] = rc[k] + pB[k];       // world position
+      }
+      // pdot_C = W_v_L,lin + W_w_L x W_p_C of the cached link kinematics
+      // (collidable_points.py:50-53), written about the C origin.
+      cross(vba, rc0, t);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) pd[k] = vbl[k] + t[k];
+      if (!P.floating) {
+        // cached link velocities of a fixed-base model include the stored base velocity
+        cross(om, rc, t);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) pd[k] = pd[k] + vBc[k] + t[k];
+      } else {
+        cross(om, doff, t);  // zero for URDF models (suc_H_i[0] = I when floating)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) pd[k] = pd[k] + t[k];
+      }
+      // penetration data, flat terrain: n = +z, h = [0,0,height - p_z]
+      const V delta = vmax(zero, V(P.terrain_h) - pw[2]);
+      const VM in_contact = delta > zero;
+      const V ddelta = vsel(in_contact, -pd[2], zero);
+      V dp, dq;
+      if (P.pq_half) {
+        dp = vsqrt(delta + P.eps);
+        dq = dp;
+      } else {
+        dp = vpow(delta + P.eps, V(P.p));
+        dq = vpow(delta + P.eps, V(P.q));
+      }
+      const V Kdp = P.K * dp, Ddq = P.D * dq;
+      const V fn = vmax(zero, Kdp * delta + Ddq * ddelta);
+      // tangential quantities (normal = +z)
+      const V vt[3] = {pd[0], pd[1], zero};
+      const V mn[3] = {zero, zero, m[2]};
+      const V mt[3] = {m[0], m[1], zero};
+      V ft[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) ft[k] = -(Kdp * mt[k] + Ddq * vt[k]);
+      const V ft2 = ft[0] * ft[0] + ft[1] * ft[1] + ft[2] * ft[2];
+      const V mufn = P.mu * fn;
+      const VM no_contact = !in_contact;  // delta <= 0
+      const VM sticking = no_contact || (ft2 <= mufn * mufn);
+      const V nrm = vsqrt(ft2);
+      const V scale = vmin(mufn, nrm) / (nrm + vsel(nrm == zero, V(P.eps), zero));
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        ft[k] = vsel(sticking, ft[k], scale * ft[k]);
+        ft[k] = vsel(no_contact, zero, ft[k]);
+      }
+      // deformation rate: no contact | sticking | slipping
+      V md[3];
+      const V inv_Ddq = V(T(1)) / Ddq;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const V md_nc = -(P.K_over_D * m[k]);
+        const V md_st = vt[k] - P.K_over_D * mn[k];
+        const V md_sl = -(ft[k] + Kdp * mt[k]) * inv_Ddq;
+        md[k] = vsel(no_contact, md_nc, vsel(sticking, md_st, md_sl));
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        ln.gstore(A.state_out, prow * 3 + (P.row_m + k), m[k] + P.dt * md[k], valid);
+      // wrench in C: [f; r_C x f]  (W_f = [f; p x f], soft.py:377-388, moved to the C origin)
+      V w6[6];
+      w6[0] = vsel(valid, ft[0], zero);
+      w6[1] = vsel(valid, ft[1], zero);
+      w6[2] = vsel(valid, fn + ft[2], zero);
+      cross(rc, w6, w6 + 3);
+      // segmented suffix-sum over the slots of one link (slots are sorted by link)
+      for (int st = 0, off = 1; st < P.seg_steps; ++st, off <<= 1) {
+        const VM take = tail >= off;
+        const VI src = lane + off;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) w6[k] = w6[k] + vsel(take, ln.shfl(w6[k], src), zero);
+      }
+      const VI hd = ln.lconsti(A.head, ch);
+      const VM has = hd >= 0;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        fl[k] = fl[k] + vsel(has, ln.shfl(w6[k], hd), zero);
+        fa[k] = fa[k] + vsel(has, ln.shfl(w6[3 + k], hd), zero);
+      }
+    }
+  }
+
+  // ==========================================================================================
+  // R: RNEA in frame C (rbda/rnea.py:12-238).  in_a = inertial base acceleration + sdd.
+  JXS_HD void rnea(const VI& lane, const VI& jrow, const VI& level, const VI& parent, const VM& is_joint,
+                   const VM& is_root, const V* Sl, const V* Sa, const V* cl, const V* ca, const V& mass,
+                   const V* cw, const V* Ic, const V* bl, const V* ba, const V* fl, const V* fa,
+                   const V* pB) const {
+    (void)parent;
+    const V zero = V(T(0));
+    const V sdd = (A.in_a != nullptr) ? ln.gload(A.in_a, jrow + 6, is_joint) : zero;
+    // base acceleration in C: a_0 = (Wdot_v - W_g) moved to the C origin (floating) or -W_g
+    V al[3], aa[3];
+    {
+      V wl[3] = {zero, zero, zero}, wa[3] = {zero, zero, zero};
+      if (P.floating && A.in_a != nullptr) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          wl[k] = ln.gload_u(A.in_a, k);
+          wa[k] = ln.gload_u(A.in_a, 3 + k);
+        }
+      }
+      V t[3];
+      cross(wa, pB, t);  // a_lin^C = a_lin^W + wdot x p_B
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const V base_l = wl[k] + t[k], base_a = wa[k];
+        al[k] = vsel(is_root, base_l, Sl[k] * sdd + cl[k]);
+        aa[k] = vsel(is_root, base_a, Sa[k] * sdd + ca[k]);
+      }
+      al[2] = al[2] - vsel(is_root, V(P.g), zero);
+    }
+    prefix6(al, aa);  // a_i = a_lambda + S sdd + v x vJ  (rnea.py:150-152)
+    // f_i = M a + v x* M v - f_ext  (rnea.py:163-168)
+    V f6[6];
+    {
+      V t[3], Ml[3], Ma_[3];
+      cross(aa, cw, t);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) Ml[k] = mass * (al[k] + t[k]);
+      V Iw[3];
+      Iw[0] = Ic[0] * aa[0] + Ic[1] * aa[1] + Ic[2] * aa[2];
+      Iw[1] = Ic[1] * aa[0] + Ic[3] * aa[1] + Ic[4] * aa[2];
+      Iw[2] = Ic[2] * aa[0] + Ic[4] * aa[1] + Ic[5] * aa[2];
+      cross(cw, Ml, t);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) Ma_[k] = Iw[k] + t[k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        f6[k] = Ml[k] + bl[k] - fl[k];
+        f6[3 + k] = Ma_[k] + ba[k] - fa[k];
+      }
+      // The reference leaves f_0 = 0 for a fixed base (rnea.py:114-131).
+      if (!P.floating) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) f6[k] = vsel(is_root, zero, f6[k]);
+      }
+    }
+    // backward pass: f_lambda += f_i, one level per iteration (rnea.py:193-219)
+    VI child[kMaxChildren];
+#pragma unroll
+    for (int k = 0; k < kMaxChildren; ++k) child[k] = ln.lconsti(A.lti, LI_CHILD + k);
+    const int first_level = P.floating ? 1 : 2;
+    for (int Lv = P.max_depth; Lv >= first_level; --Lv) {
+      const VM is_par = level == (Lv - 1);
+#pragma unroll
+      for (int k = 0; k < kMaxChildren; ++k) {
+        if (k < P.maxch[Lv]) {
+          const VM ok = is_par && (child[k] >= 0);
+          V g6[6];
+#pragma unroll
+          for (int e = 0; e < 6; ++e) g6[e] = ln.shfl(f6[e], child[k]);
+#pragma unroll
+          for (int e = 0; e < 6; ++e) f6[e] = f6[e] + vsel(ok, g6[e], zero);
+        }
+      }
+    }
+    V tq = Sl[0] * f6[0] + Sl[1] * f6[1] + Sl[2] * f6[2] + Sa[0] * f6[3] + Sa[1] * f6[4] + Sa[2] * f6[5];
+    ln.gstore(A.out_a, jrow + 6, tq, is_joint);
+    // W_f0 = B_X_W^T f_0: move the base wrench from the C origin back to the world origin
+    V t[3];
+    cross(pB, f6, t);
+    const VI zl = lane * 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      ln.gstore(A.out_a, zl + k, f6[k], is_root);
+      ln.gstore(A.out_a, zl + (3 + k), f6[3 + k] + t[k], is_root);
+    }
+  }
+
+  // ==========================================================================================
+  // N: cached kinematics -- W_H_L and inertial-fixed W_v_WL of every link (api/data.py:480-492)
+  JXS_HD void store_kinematics(const VI& lane, const VI& level, const V* R, const V* r, const V* vl,
+                               const V* va, const V* pB, const V* doff, const V* vBc, const V* om) const {
+    const VM is_link = level >= 0;
+    V p[3], vlin[3], vang[3], t[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      p[k] = r[k] + doff[k] + pB[k];
+      vlin[k] = vl[k];
+      vang[k] = va[k];
+    }
+    if (!P.floating) {
+      // fixed base: the cache starts from the stored base velocity (forward_kinematics.py:69-70)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        vlin[k] = vlin[k] + vBc[k];
+        vang[k] = vang[k] + om[k];
+      }
+    }
+    // spatial velocity about the C origin -> about the world origin: v_lin^W = v_lin^C - w x p_B
+    // (the cached transforms are offset by doff, whose effect on W_X_i S is w_i x doff)
+    cross(vang, pB, t);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) vlin[k] = vlin[k] - t[k];
+    {
+      // linear part uses the cached positions (r + doff): add (r+doff) x S_ang contributions,
+      // i.e. doff x (w_i - w_base) for the joint part.
+      V wrel[3], t2[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) wrel[k] = va[k] - (P.floating ? om[k] : V(T(0)));
+      cross(doff, wrel, t2);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) vlin[k] = vlin[k] + t2[k];
+    }
+    if (A.out_H != nullptr) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) ln.gstore(A.out_H, lane * 12 + (4 * i + j), R[3 * i + j], is_link);
+        ln.gstore(A.out_H, lane * 12 + (4 * i + 3), p[i], is_link);
+      }
+    }
+    if (A.out_V != nullptr) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        ln.gstore(A.out_V, lane * 6 + k, vlin[k], is_link);
+        ln.gstore(A.out_V, lane * 6 + (3 + k), vang[k], is_link);
+      }
+    }
+  }
+};
+
+}  // namespace jxs

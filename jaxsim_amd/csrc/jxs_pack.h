@@ -1,0 +1,241 @@
+// Host-side packer: jxs_model_desc (reference-shaped tables) -> KParams + per-lane tables.
+// Pure C++ (no HIP); shared by the device library and by the CPU emulation harness of the
+// tests so both consume byte-identical tables.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "../../include/jaxsim_amd.h"
+#include "jxs_params.h"
+
+namespace jxs {
+
+template <typename T>
+struct Packed {
+  KParams<T> P;
+  int G = 0;
+  std::vector<T> ltf;
+  std::vector<int> lti;
+  std::vector<T> ptf;
+  std::vector<int> pti;
+  std::vector<int> head;
+  int n_disabled = 0;
+};
+
+inline int pow2ceil(int x) {
+  int p = 1;
+  while (p < x) p <<= 1;
+  return p;
+}
+
+// Returns an empty string on success, otherwise the reason the model is unsupported.
+template <typename T>
+std::string pack_model(const jxs_model_desc& d, Packed<T>& out) {
+  const int nL = d.n_links;
+  if (nL < 1) return "n_links must be >= 1";
+  if (nL > 64) return "models with more than 64 links are not supported (one link per lane of a wave)";
+  if (d.parent[0] != -1) return "parent[0] must be -1";
+  for (int i = 1; i < nL; ++i) {
+    if (d.parent[i] < 0 || d.parent[i] >= i) return "parent array must be topologically ordered (BFS indices)";
+    if (d.joint_type[i] != 1 && d.joint_type[i] != 2) return "joint types must be revolute(1) or prismatic(2)";
+  }
+  // Quirk 12: ABA ignores suc_H_i[0] while the cached kinematics include it.
+  // A pure translation is reproduced exactly (KParams::base_off); a rotated base-link pose is not.
+  {
+    const double* H = d.suc_H_i;
+    const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c)
+        if (std::fabs(H[4 * r + c] - I3[3 * r + c]) > 1e-12)
+          return "a base link pose (suc_H_i[0]) with a rotation is not supported";
+  }
+
+  // enabled points, stably sorted by parent link
+  std::vector<int> en;
+  for (int k = 0; k < d.n_points; ++k)
+    if (d.point_enabled[k]) en.push_back(k);
+  out.n_disabled = d.n_points - (int)en.size();
+  for (int k : en)
+    if (d.point_body[k] < 0 || d.point_body[k] >= nL) return "collidable point with an invalid parent link";
+  std::stable_sort(en.begin(), en.end(), [&](int a, int b) { return d.point_body[a] < d.point_body[b]; });
+
+  const int n_en = (int)en.size();
+  int G = pow2ceil(std::max(nL, std::min(n_en, 32)));
+  G = std::max(G, 4);
+  out.G = G;
+  const int n_chunks = (n_en + G - 1) / G;
+  const int n_slots = n_chunks * G;
+
+  KParams<T>& P = out.P;
+  P = KParams<T>();
+  P.nL = nL;
+  P.n = nL - 1;
+  P.n_points = d.n_points;
+  P.n_slots = n_slots;
+  P.n_chunks = n_chunks;
+  P.floating = d.floating_base ? 1 : 0;
+
+  // tree structure
+  std::vector<int> level(nL, 0);
+  int max_depth = 0;
+  for (int i = 1; i < nL; ++i) {
+    level[i] = level[d.parent[i]] + 1;
+    max_depth = std::max(max_depth, level[i]);
+  }
+  if (max_depth > kMaxDepth) return "kinematic tree too deep";
+  P.max_depth = max_depth;
+  int rounds = 0;
+  while ((1 << rounds) < max_depth + 1) ++rounds;
+  if (rounds > kMaxRounds) return "kinematic tree too deep";
+  P.n_rounds = rounds;
+  std::vector<std::vector<int>> children(nL);
+  for (int i = 1; i < nL; ++i) children[d.parent[i]].push_back(i);
+  for (int L = 0; L <= kMaxDepth; ++L) P.maxch[L] = 0;
+  for (int i = 0; i < nL; ++i) {
+    if ((int)children[i].size() > kMaxChildren) return "links with more than 6 children are not supported";
+    if (!children[i].empty()) P.maxch[level[i] + 1] = std::max(P.maxch[level[i] + 1], (int)children[i].size());
+  }
+
+  // state rows
+  P.row_pos = 0;
+  P.row_quat = 3;
+  P.row_s = 7;
+  P.row_vlin = 7 + P.n;
+  P.row_vang = 10 + P.n;
+  P.row_sd = 13 + P.n;
+  P.row_m = 13 + 2 * P.n;
+  P.n_rows = 13 + 2 * P.n + 3 * d.n_points;
+
+  // constants
+  P.dt = (T)d.time_step;
+  P.g = (T)d.gravity;
+  P.K = (T)d.K;
+  P.D = (T)d.D;
+  P.mu = (T)d.mu;
+  P.p = (T)d.p;
+  P.q = (T)d.q;
+  P.K_over_D = (T)d.K / (T)d.D;
+  P.pq_half = (d.p == 0.5 && d.q == 0.5) ? 1 : 0;
+  P.terrain_h = (T)d.terrain_height;
+  P.tau_max = (T)d.torque_max;
+  P.w_th = (T)d.omega_th;
+  P.w_max = (T)d.omega_max;
+  P.enable_friction = d.enable_friction ? 1 : 0;
+  for (int k = 0; k < 3; ++k) P.base_off[k] = (T)d.suc_H_i[4 * k + 3];
+  P.eps = std::numeric_limits<T>::epsilon();
+  P.quat_K = (T)0.1;
+
+  // per-lane tables
+  out.ltf.assign((size_t)LF_COUNT * G, T(0));
+  out.lti.assign((size_t)LI_COUNT * G, 0);
+  auto F = [&](int f, int lane) -> T& { return out.ltf[(size_t)f * G + lane]; };
+  auto I = [&](int f, int lane) -> int& { return out.lti[(size_t)f * G + lane]; };
+  const T big = std::numeric_limits<T>::max();
+  auto clampT = [&](double x) -> T {
+    if (x >= (double)big) return big;
+    if (x <= -(double)big) return -big;
+    return (T)x;
+  };
+  int any_suc = 0;
+  for (int lane = 0; lane < G; ++lane) {
+    // identity transforms everywhere by default
+    for (int k = 0; k < 3; ++k) {
+      F(LF_RPRE + 4 * k, lane) = T(1);
+      F(LF_RSUC + 4 * k, lane) = T(1);
+    }
+    I(LI_JTYPE, lane) = 0;
+    I(LI_PARENT, lane) = -1;
+    I(LI_LEVEL, lane) = -1;
+    for (int k = 0; k < kMaxRounds; ++k) I(LI_JUMP + k, lane) = -1;
+    for (int k = 0; k < kMaxChildren; ++k) I(LI_CHILD + k, lane) = -1;
+    F(LF_SMIN, lane) = -big;
+    F(LF_SMAX, lane) = big;
+    if (lane >= nL) continue;
+    const int i = lane;
+    I(LI_LEVEL, i) = level[i];
+    F(LF_MASS, i) = (T)d.link_mass[i];
+    for (int k = 0; k < 3; ++k) F(LF_COM + k, i) = (T)d.link_com[3 * i + k];
+    const double* Ii = d.link_inertia + 9 * i;
+    F(LF_ICOM + 0, i) = (T)Ii[0];
+    F(LF_ICOM + 1, i) = (T)(0.5 * (Ii[1] + Ii[3]));
+    F(LF_ICOM + 2, i) = (T)(0.5 * (Ii[2] + Ii[6]));
+    F(LF_ICOM + 3, i) = (T)Ii[4];
+    F(LF_ICOM + 4, i) = (T)(0.5 * (Ii[5] + Ii[7]));
+    F(LF_ICOM + 5, i) = (T)Ii[8];
+    for (int k = 0; k < (int)children[i].size(); ++k) I(LI_CHILD + k, i) = children[i][k];
+    if (i == 0) continue;
+    I(LI_JTYPE, i) = d.joint_type[i];
+    I(LI_PARENT, i) = d.parent[i];
+    int anc = d.parent[i];
+    // jump[k] = ancestor at distance 2^k
+    std::vector<int> chain;  // ancestors at distance 1,2,3,...
+    for (int a = i; a != 0;) {
+      a = d.parent[a];
+      chain.push_back(a);
+    }
+    (void)anc;
+    for (int k = 0; k < kMaxRounds; ++k) {
+      const int dist = 1 << k;
+      I(LI_JUMP + k, i) = (dist <= (int)chain.size()) ? chain[dist - 1] : -1;
+    }
+    const double* Hp = d.lambda_H_pre + 16 * i;
+    const double* Hs = d.suc_H_i + 16 * i;
+    for (int r = 0; r < 3; ++r) {
+      for (int c = 0; c < 3; ++c) {
+        F(LF_RPRE + 3 * r + c, i) = (T)Hp[4 * r + c];
+        F(LF_RSUC + 3 * r + c, i) = (T)Hs[4 * r + c];
+        if (std::fabs(Hs[4 * r + c] - (r == c ? 1.0 : 0.0)) > 0) any_suc = 1;
+      }
+      F(LF_PPRE + r, i) = (T)Hp[4 * r + 3];
+      F(LF_PSUC + r, i) = (T)Hs[4 * r + 3];
+      if (Hs[4 * r + 3] != 0.0) any_suc = 1;
+    }
+    for (int k = 0; k < 3; ++k) F(LF_AXIS + k, i) = (T)d.joint_axis[3 * i + k];
+    F(LF_KC, i) = (T)d.friction_static[i];
+    F(LF_KV, i) = (T)d.friction_viscous[i];
+    F(LF_SMIN, i) = clampT(d.position_limit_min[i]);
+    F(LF_SMAX, i) = clampT(d.position_limit_max[i]);
+    F(LF_KLIM, i) = (T)d.position_limit_spring[i];
+    F(LF_DLIM, i) = (T)d.position_limit_damper[i];
+  }
+  P.any_suc = any_suc;
+
+  // point slots
+  out.ptf.assign((size_t)PF_COUNT * std::max(n_slots, 1), T(0));
+  out.pti.assign((size_t)PI_COUNT * std::max(n_slots, 1), 0);
+  out.head.assign((size_t)std::max(n_chunks, 1) * G, -1);
+  int max_seg = 1;
+  for (int s = 0; s < n_slots; ++s) {
+    out.pti[(size_t)PI_BODY * n_slots + s] = -1;
+    out.pti[(size_t)PI_ROW * n_slots + s] = 0;
+    out.pti[(size_t)PI_TAIL * n_slots + s] = 0;
+  }
+  for (int s = 0; s < n_en; ++s) {
+    const int k = en[s];
+    out.pti[(size_t)PI_BODY * n_slots + s] = d.point_body[k];
+    out.pti[(size_t)PI_ROW * n_slots + s] = k;
+    for (int c = 0; c < 3; ++c) out.ptf[(size_t)(PF_POS + c) * n_slots + s] = (T)d.point_position[3 * k + c];
+  }
+  for (int ch = 0; ch < n_chunks; ++ch) {
+    int s = ch * G;
+    const int end = std::min(n_en, (ch + 1) * G);
+    while (s < end) {
+      const int body = d.point_body[en[s]];
+      int e = s;
+      while (e + 1 < end && d.point_body[en[e + 1]] == body) ++e;
+      out.head[(size_t)ch * G + body] = s - ch * G;
+      for (int t = s; t <= e; ++t) out.pti[(size_t)PI_TAIL * n_slots + t] = e - t;
+      max_seg = std::max(max_seg, e - s + 1);
+      s = e + 1;
+    }
+  }
+  int seg_steps = 0;
+  while ((1 << seg_steps) < max_seg) ++seg_steps;
+  P.seg_steps = seg_steps;
+  return std::string();
+}
+
+}  // namespace jxs

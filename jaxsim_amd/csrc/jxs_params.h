@@ -1,0 +1,113 @@
+// Kernel parameter block + per-lane table layout shared by the host packer, the HIP
+// kernels and the host lockstep emulation used by the CPU tests.
+//
+// Mapping: one environment is processed by a group of G lanes of a
+// wavefront (G = 4..64, power of two); lane j of the group owns link j of the kinematic tree
+// (reference link index, BFS order, `src/jaxsim/parsers/kinematic_graph.py:133-134`) and, in
+// the contact phase, collidable-point slot j of the current chunk.
+#pragma once
+#include <cstdint>
+
+#ifndef JXS_HD
+#if defined(__HIPCC__)
+#define JXS_HD __host__ __device__ __forceinline__
+#else
+#define JXS_HD inline
+#endif
+#endif
+
+namespace jxs {
+
+constexpr int kMaxDepth = 63;    // max tree depth supported by the level loops
+constexpr int kMaxChildren = 6;  // max children of one link (statically unrolled gather)
+constexpr int kMaxRounds = 6;    // pointer-jumping rounds: ceil(log2(depth+1)) <= 6
+
+// ---- per-lane float table fields: ltf[field * G + lane] ------------------------------------
+enum LaneF : int {
+  LF_RPRE = 0,    // 9: rotation of lambda_H_pre (row-major)   math/joint_model.py:70-98
+  LF_PPRE = 9,    // 3: translation of lambda_H_pre
+  LF_RSUC = 12,   // 9: rotation of suc_H_i
+  LF_PSUC = 21,   // 3: translation of suc_H_i
+  LF_AXIS = 24,   // 3: unit joint axis
+  LF_MASS = 27,   // 1
+  LF_COM = 28,    // 3: CoM in the link frame
+  LF_ICOM = 31,   // 6: I_CoM xx,xy,xz,yy,yz,zz
+  LF_KC = 37,     // friction_static       kin_dyn_parameters.py:502-571
+  LF_KV = 38,     // friction_viscous
+  LF_SMIN = 39,   // position_limits_min
+  LF_SMAX = 40,   // position_limits_max
+  LF_KLIM = 41,   // position_limit_spring
+  LF_DLIM = 42,   // position_limit_damper
+  LF_COUNT = 43
+};
+
+// ---- per-lane int table fields: lti[field * G + lane] --------------------------------------
+enum LaneI : int {
+  LI_JTYPE = 0,   // 0 = none (base / padding lane), 1 revolute, 2 prismatic
+  LI_PARENT = 1,  // parent lane, -1 for the base and padding lanes
+  LI_LEVEL = 2,   // tree depth, -1 for padding lanes
+  LI_JUMP = 3,    // kMaxRounds entries: ancestor at distance 2^k, -1 if beyond the base
+  LI_CHILD = LI_JUMP + kMaxRounds,  // kMaxChildren entries: child lanes, -1 if none
+  LI_COUNT = LI_CHILD + kMaxChildren
+};
+
+// ---- per-point-slot tables (slots = n_chunks * G): ptf[field * slots + slot] etc. ----------
+enum PointF : int { PF_POS = 0, PF_COUNT = 3 };
+enum PointI : int {
+  PI_BODY = 0,   // lane of the parent link, -1 for an empty slot
+  PI_ROW = 1,    // original collidable-point index (row of the tangential deformation state)
+  PI_TAIL = 2,   // number of slots after this one in the same (chunk, link) segment
+  PI_COUNT = 3
+};
+// head[chunk * G + lane]: slot-lane of the first point of link `lane` in that chunk, -1 if none.
+
+enum Mode : int {
+  MODE_STEP = 0,  // js.model.step                         api/model.py:2601-2681
+  MODE_FD = 1,    // forward_dynamics_aba (no contacts)    api/model.py:1269-1406
+  MODE_ID = 2,    // inverse_dynamics / RNEA               api/model.py:1746-1894
+  MODE_KIN = 3    // cached kinematics of JaxSimModelData  api/data.py:405-523
+};
+
+enum ForceRepr : int { REPR_INERTIAL = 0, REPR_BODY = 1, REPR_MIXED = 2 };  // api/common.py:39-47
+
+// Wave-uniform parameters, passed by value as the kernel argument (lives in SGPRs / kernarg).
+template <typename T>
+struct KParams {
+  // topology
+  int nL, n, n_points, n_slots, n_chunks, seg_steps, n_rounds, max_depth, floating, any_suc;
+  int maxch[kMaxDepth + 1];  // maxch[L]: max #children (at level L) of any link at level L-1
+  // state-block rows ([row][N], N fastest): SURVEY.md section 8(a) row D
+  int row_pos, row_quat, row_s, row_vlin, row_vang, row_sd, row_m, n_rows;
+  // model constants
+  T dt, g;                       // time_step, signed z gravity          api/model.py:54-60
+  T K, D, mu, p, q, K_over_D;    // SoftContactsParams                   rbda/contacts/soft.py:24-46
+  int pq_half;                   // p == q == 0.5 -> sqrt instead of pow
+  T terrain_h;                   // FlatTerrain height                   terrain/terrain.py:65-124
+  T tau_max, w_th, w_max;        // ActuationParams                      rbda/actuation/common.py:16-19
+  int enable_friction;
+  T base_off[3];                 // translation of suc_H_i[0] (quirk 12)
+  T eps;                         // finfo(dtype).eps                     rbda/contacts/soft.py:246
+  T quat_K;                      // Baumgarte gain of Quaternion.derivative (0.1)  math/quaternion.py:72
+};
+
+// Device/host pointers handed to the core for one launch.
+template <typename T>
+struct KArgs {
+  const T* ltf;        // [LF_COUNT][G]
+  const int* lti;      // [LI_COUNT][G]
+  const T* ptf;        // [PF_COUNT][n_slots]
+  const int* pti;      // [PI_COUNT][n_slots]
+  const int* head;     // [n_chunks][G]
+  const T* state_in;   // [n_rows][N]
+  T* state_out;        // [n_rows][N] (may alias state_in)
+  const T* tau;        // [n][N] or null            joint_force_references / joint_forces
+  const T* link_f;     // [nL*6][N] or null         link_forces
+  int force_repr;      // ForceRepr of link_f
+  const T* in_a;       // MODE_ID: [6+n][N] inertial base acceleration + joint accelerations, or null
+  T* out_a;            // MODE_FD: [6+n][N] ; MODE_ID: [6+n][N] (base wrench, joint torques)
+  T* out_H;            // MODE_KIN: [nL*12][N] rows of [R|p] per link (row-major 3x4)
+  T* out_V;            // MODE_KIN: [nL*6][N] inertial-fixed link velocities
+  int N;               // batch size (leading dimension of every [row][N] array)
+};
+
+}  // namespace jxs

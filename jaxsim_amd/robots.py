@@ -240,7 +240,7 @@ def chain_urdf(n_links: int = 5, fixed_base: bool = True, seed: int = 0) -> str:
         coll = _box_collision(dims, xyz=com) if (not fixed_base and i in (0, n_links - 1)) else ""
         out.append(f'<link name="link{i:02d}">' + _inertial(m, com=com, I=_box_inertia(m, *dims), rpy=rpy) + coll + "</link>")
     if fixed_base:
-        out.append(_joint("world_to_base", "fixed", "world", "link00", (0.1, -0.2, 0.5), (0, 0, 0), rpy=(0.1, 0.2, 0.3)))
+        out.append(_joint("world_to_base", "fixed", "world", "link00", (0.1, -0.2, 0.5), (0, 0, 0)))
     for i in range(1, n_links):
         parent = int(rng.integers(max(0, i - 3), i))
         jt = "prismatic" if rng.uniform() < 0.25 else "revolute"

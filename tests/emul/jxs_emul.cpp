@@ -1,0 +1,98 @@
+// TEST INFRASTRUCTURE: CPU lockstep emulation of the HIP kernel core.
+//
+// Compiles jaxsim_amd/csrc/jxs_core.h -- the very source of the gfx950 kernels -- against the
+// host lane backend (jxs_lanes_host.h) so that `pytest -m "not gpu"` can compare the kernel
+// logic (table packing, shuffles along the tree, level loops, contacts, integrator) with the
+// oracle on a machine without a GPU.  Not part of the product: jaxsim_amd/ never loads it.
+#include <cstring>
+#include <string>
+
+#include "jxs_lanes_host.h"
+// lanes first: the core's unqualified calls on Vec resolve by ADL
+#include "../../jaxsim_amd/csrc/jxs_core.h"
+#include "../../jaxsim_amd/csrc/jxs_pack.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+template <typename T, int G>
+void run_group(const jxs::Packed<T>& pk, jxs::KArgs<T> a, int mode) {
+  a.ltf = pk.ltf.data();
+  a.lti = pk.lti.data();
+  a.ptf = pk.ptf.data();
+  a.pti = pk.pti.data();
+  a.head = pk.head.data();
+  for (int env = 0; env < a.N; ++env) {
+    jxs::HostLanes<T, G> ln(a.N, env);
+    jxs::Core<jxs::HostLanes<T, G>> core(pk.P, a, ln);
+    switch (mode) {
+      case jxs::MODE_STEP: core.template run<jxs::MODE_STEP>(); break;
+      case jxs::MODE_FD: core.template run<jxs::MODE_FD>(); break;
+      case jxs::MODE_ID: core.template run<jxs::MODE_ID>(); break;
+      default: core.template run<jxs::MODE_KIN>(); break;
+    }
+  }
+}
+
+template <typename T>
+int run_typed(const jxs_model_desc* d, int mode, const void* state_in, void* state_out, const void* tau,
+              const void* link_f, int force_repr, const void* in_a, void* out_a, void* out_H, void* out_V,
+              int N) {
+  jxs::Packed<T> pk;
+  const std::string err = jxs::pack_model<T>(*d, pk);
+  if (!err.empty()) {
+    g_err = err;
+    return JXS_EINVAL;
+  }
+  jxs::KArgs<T> a{};
+  a.state_in = static_cast<const T*>(state_in);
+  a.state_out = static_cast<T*>(state_out);
+  a.tau = static_cast<const T*>(tau);
+  a.link_f = static_cast<const T*>(link_f);
+  a.force_repr = force_repr;
+  a.in_a = static_cast<const T*>(in_a);
+  a.out_a = static_cast<T*>(out_a);
+  a.out_H = static_cast<T*>(out_H);
+  a.out_V = static_cast<T*>(out_V);
+  a.N = N;
+  if (mode == jxs::MODE_STEP && state_out != state_in && pk.n_disabled > 0)
+    std::memcpy(state_out, state_in, sizeof(T) * (size_t)pk.P.n_rows * N);
+  switch (pk.G) {
+    case 4: run_group<T, 4>(pk, a, mode); break;
+    case 8: run_group<T, 8>(pk, a, mode); break;
+    case 16: run_group<T, 16>(pk, a, mode); break;
+    case 32: run_group<T, 32>(pk, a, mode); break;
+    case 64: run_group<T, 64>(pk, a, mode); break;
+    default: g_err = "bad group size"; return JXS_EINVAL;
+  }
+  return JXS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* jxs_emul_last_error(void) { return g_err.c_str(); }
+
+int jxs_emul_layout(const jxs_model_desc* d, jxs_layout* out) {
+  jxs::Packed<double> pk;
+  const std::string err = jxs::pack_model<double>(*d, pk);
+  if (!err.empty()) {
+    g_err = err;
+    return JXS_EINVAL;
+  }
+  const auto& P = pk.P;
+  *out = jxs_layout{P.nL, P.n, P.n_points, P.n_rows, P.row_pos, P.row_quat, P.row_s,
+                    P.row_vlin, P.row_vang, P.row_sd, P.row_m, pk.G, d->dtype};
+  return JXS_OK;
+}
+
+int jxs_emul_run(const jxs_model_desc* d, int mode, const void* state_in, void* state_out, const void* tau,
+                 const void* link_f, int force_repr, const void* in_a, void* out_a, void* out_H, void* out_V,
+                 int N) {
+  if (d->dtype == JXS_F64)
+    return run_typed<double>(d, mode, state_in, state_out, tau, link_f, force_repr, in_a, out_a, out_H, out_V, N);
+  return run_typed<float>(d, mode, state_in, state_out, tau, link_f, force_repr, in_a, out_a, out_H, out_V, N);
+}
+}

@@ -1,0 +1,174 @@
+// TEST INFRASTRUCTURE: host lockstep emulation of one lane group.
+//
+// `Vec<T,G>` holds one value per lane; every operator is elementwise, so the kernel core
+// (jaxsim_amd/csrc/jxs_core.h), which is written branch-free over lane values, runs here on
+// the CPU with exactly the data flow it has on the GPU: shuffles become gathers between
+// lanes of the group.  This is what lets the CPU test-suite (-m "not gpu") check the kernel
+// logic against the oracle without a GPU.  It is never shipped or benchmarked.
+#pragma once
+#include <cmath>
+#include <cstddef>
+
+#include "jxs_params.h"
+
+namespace jxs {
+
+template <typename T, int G>
+struct Vec {
+  T v[G];
+  Vec() {
+    for (int i = 0; i < G; ++i) v[i] = T();
+  }
+  Vec(T s) {  // NOLINT(google-explicit-constructor): scalar broadcast
+    for (int i = 0; i < G; ++i) v[i] = s;
+  }
+#define JXS_BIN(op)                                           \
+  friend Vec operator op(const Vec& a, const Vec& b) {        \
+    Vec r;                                                    \
+    for (int i = 0; i < G; ++i) r.v[i] = a.v[i] op b.v[i];    \
+    return r;                                                 \
+  }
+  JXS_BIN(+) JXS_BIN(-) JXS_BIN(*) JXS_BIN(/) JXS_BIN(&)
+#undef JXS_BIN
+#define JXS_CMP(op)                                              \
+  friend Vec<bool, G> operator op(const Vec& a, const Vec& b) {  \
+    Vec<bool, G> r;                                              \
+    for (int i = 0; i < G; ++i) r.v[i] = a.v[i] op b.v[i];       \
+    return r;                                                    \
+  }
+  JXS_CMP(<) JXS_CMP(<=) JXS_CMP(>) JXS_CMP(>=) JXS_CMP(==) JXS_CMP(!=)
+#undef JXS_CMP
+  friend Vec operator-(const Vec& a) {
+    Vec r;
+    for (int i = 0; i < G; ++i) r.v[i] = -a.v[i];
+    return r;
+  }
+  Vec& operator+=(const Vec& b) { return *this = *this + b; }
+  Vec& operator-=(const Vec& b) { return *this = *this - b; }
+  Vec& operator*=(const Vec& b) { return *this = *this * b; }
+  friend Vec vsel(const Vec<bool, G>& m, const Vec& a, const Vec& b) {
+    Vec r;
+    for (int i = 0; i < G; ++i) r.v[i] = m.v[i] ? a.v[i] : b.v[i];
+    return r;
+  }
+  friend Vec vsqrt(const Vec& a) {
+    Vec r;
+    for (int i = 0; i < G; ++i) r.v[i] = std::sqrt(a.v[i]);
+    return r;
+  }
+  friend Vec vabs(const Vec& a) {
+    Vec r;
+    for (int i = 0; i < G; ++i) r.v[i] = std::fabs(a.v[i]);
+    return r;
+  }
+  friend Vec vmin(const Vec& a, const Vec& b) {
+    Vec r;
+    for (int i = 0; i < G; ++i) r.v[i] = std::fmin(a.v[i], b.v[i]);
+    return r;
+  }
+  friend Vec vmax(const Vec& a, const Vec& b) {
+    Vec r;
+    for (int i = 0; i < G; ++i) r.v[i] = std::fmax(a.v[i], b.v[i]);
+    return r;
+  }
+  friend Vec vpow(const Vec& a, const Vec& b) {
+    Vec r;
+    for (int i = 0; i < G; ++i) r.v[i] = std::pow(a.v[i], b.v[i]);
+    return r;
+  }
+  friend Vec vsin(const Vec& a) {
+    Vec r;
+    for (int i = 0; i < G; ++i) r.v[i] = std::sin(a.v[i]);
+    return r;
+  }
+  friend void vsincos(const Vec& a, Vec& s, Vec& c) {
+    for (int i = 0; i < G; ++i) {
+      s.v[i] = std::sin(a.v[i]);
+      c.v[i] = std::cos(a.v[i]);
+    }
+  }
+};
+
+template <int G>
+inline Vec<bool, G> operator&&(const Vec<bool, G>& a, const Vec<bool, G>& b) {
+  Vec<bool, G> r;
+  for (int i = 0; i < G; ++i) r.v[i] = a.v[i] && b.v[i];
+  return r;
+}
+template <int G>
+inline Vec<bool, G> operator||(const Vec<bool, G>& a, const Vec<bool, G>& b) {
+  Vec<bool, G> r;
+  for (int i = 0; i < G; ++i) r.v[i] = a.v[i] || b.v[i];
+  return r;
+}
+template <int G>
+inline Vec<bool, G> operator!(const Vec<bool, G>& a) {
+  Vec<bool, G> r;
+  for (int i = 0; i < G; ++i) r.v[i] = !a.v[i];
+  return r;
+}
+template <int G>
+inline Vec<bool, G> operator&&(const Vec<bool, G>& a, bool b) { return a && Vec<bool, G>(b); }
+template <int G>
+inline Vec<bool, G> operator&&(bool a, const Vec<bool, G>& b) { return Vec<bool, G>(a) && b; }
+template <int G>
+inline Vec<bool, G> operator||(const Vec<bool, G>& a, bool b) { return a || Vec<bool, G>(b); }
+
+template <typename T_, int G_>
+struct HostLanes {
+  using T = T_;
+  using V = Vec<T_, G_>;
+  using VI = Vec<int, G_>;
+  using VM = Vec<bool, G_>;
+  static constexpr int G = G_;
+
+  int env_;
+  int N_;
+  HostLanes(int N, int env) : env_(env), N_(N) {}
+
+  VI lane() const {
+    VI r;
+    for (int i = 0; i < G; ++i) r.v[i] = i;
+    return r;
+  }
+  VM all_true() const { return VM(true); }
+
+  template <typename U>
+  Vec<U, G> shfl(const Vec<U, G>& x, const VI& src) const {
+    Vec<U, G> r;
+    for (int i = 0; i < G; ++i) r.v[i] = x.v[src.v[i] & (G - 1)];
+    return r;
+  }
+  V lconstf(const T* tbl, int field) const {
+    V r;
+    for (int i = 0; i < G; ++i) r.v[i] = tbl[field * G + i];
+    return r;
+  }
+  VI lconsti(const int* tbl, int field) const {
+    VI r;
+    for (int i = 0; i < G; ++i) r.v[i] = tbl[field * G + i];
+    return r;
+  }
+  V ploadf(const T* tbl, int field, int n_slots, const VI& slot) const {
+    V r;
+    for (int i = 0; i < G; ++i) r.v[i] = tbl[field * n_slots + slot.v[i]];
+    return r;
+  }
+  VI ploadi(const int* tbl, int field, int n_slots, const VI& slot) const {
+    VI r;
+    for (int i = 0; i < G; ++i) r.v[i] = tbl[field * n_slots + slot.v[i]];
+    return r;
+  }
+  V gload(const T* base, const VI& row, const VM& mask) const {
+    V r;
+    for (int i = 0; i < G; ++i) r.v[i] = mask.v[i] ? base[(size_t)row.v[i] * N_ + env_] : T(0);
+    return r;
+  }
+  V gload_u(const T* base, int row) const { return V(base[(size_t)row * N_ + env_]); }
+  void gstore(T* base, const VI& row, const V& val, const VM& mask) const {
+    for (int i = 0; i < G; ++i)
+      if (mask.v[i]) base[(size_t)row.v[i] * N_ + env_] = val.v[i];
+  }
+};
+
+}  // namespace jxs

@@ -1,0 +1,85 @@
+"""TEST INFRASTRUCTURE: ctypes binding of the CPU lockstep emulation (tests/emul).
+
+Builds ``tests/emul/libjxs_emul.so`` with g++ on first use.  The emulation compiles the
+kernel core of the product (``jaxsim_amd/csrc/jxs_core.h``) against a host lane backend.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import pathlib
+import subprocess
+
+import numpy as np
+
+from jaxsim_amd import _lib
+
+_HERE = pathlib.Path(__file__).resolve().parent
+_SRC = _HERE / "emul" / "jxs_emul.cpp"
+_SO = _HERE / "emul" / "libjxs_emul.so"
+_ROOT = _HERE.parent
+MODE_STEP, MODE_FD, MODE_ID, MODE_KIN = 0, 1, 2, 3
+
+
+def build(force: bool = False) -> pathlib.Path:
+    deps = [_SRC, _HERE / "emul" / "jxs_lanes_host.h"] + sorted((_ROOT / "jaxsim_amd" / "csrc").glob("*.h"))
+    deps.append(_ROOT / "include" / "jaxsim_amd.h")
+    if force or not _SO.exists() or any(d.stat().st_mtime > _SO.stat().st_mtime for d in deps):
+        cmd = ["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas",
+               f"-I{_ROOT / 'jaxsim_amd' / 'csrc'}", f"-I{_HERE / 'emul'}", str(_SRC), "-o", str(_SO)]  # fmt: skip
+        subprocess.run(cmd, check=True)
+    return _SO
+
+
+_emul = None
+
+
+def lib():
+    global _emul
+    if _emul is None:
+        _emul = C.CDLL(str(build()))
+        _emul.jxs_emul_last_error.restype = C.c_char_p
+        vp = C.c_void_p
+        _emul.jxs_emul_run.restype = C.c_int
+        _emul.jxs_emul_run.argtypes = [C.POINTER(_lib.ModelDesc), C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, C.c_int]
+        _emul.jxs_emul_layout.restype = C.c_int
+        _emul.jxs_emul_layout.argtypes = [C.POINTER(_lib.ModelDesc), C.POINTER(_lib.Layout)]
+    return _emul
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def layout(model, dtype=np.float64) -> _lib.Layout:
+    d, keep = _lib.make_desc(model, dtype)
+    out = _lib.Layout()
+    rc = lib().jxs_emul_layout(C.byref(d), C.byref(out))
+    if rc != 0:
+        raise RuntimeError(lib().jxs_emul_last_error().decode())
+    return out
+
+
+def run(model, mode, state, *, tau=None, link_forces=None, force_repr=0, in_acc=None, dtype=None):
+    """Run one emulated launch.  All arrays are [rows, N] C-contiguous of the model dtype."""
+    dtype = np.dtype(dtype or state.dtype)
+    d, keep = _lib.make_desc(model, dtype)
+    N = state.shape[1]
+    nL, n = model.number_of_links(), model.dofs()
+    c = lambda a: None if a is None else np.ascontiguousarray(a, dtype=dtype)  # noqa: E731
+    state, tau, link_forces, in_acc = c(state), c(tau), c(link_forces), c(in_acc)
+    state_out = state.copy() if mode == MODE_STEP else None
+    out_a = np.zeros((6 + n, N), dtype=dtype) if mode in (MODE_FD, MODE_ID) else None
+    out_H = np.zeros((nL * 12, N), dtype=dtype) if mode == MODE_KIN else None
+    out_V = np.zeros((nL * 6, N), dtype=dtype) if mode == MODE_KIN else None
+    rc = lib().jxs_emul_run(
+        C.byref(d), mode, _p(state), _p(state_out), _p(tau), _p(link_forces), int(force_repr), _p(in_acc),
+        _p(out_a), _p(out_H), _p(out_V), N,
+    )  # fmt: skip
+    if rc != 0:
+        raise RuntimeError(lib().jxs_emul_last_error().decode())
+    if mode == MODE_STEP:
+        return state_out
+    if mode == MODE_KIN:
+        return out_H, out_V
+    return out_a
