@@ -1,0 +1,258 @@
+#!/usr/bin/env python3
+"""Headline benchmark: simulated env-steps/s of ``js.model.step`` for the synthetic iCub
+23-DoF floating-base humanoid with soft ground contacts (BASELINE.json configs[2] on one GPU,
+configs[3] = the same workload sharded over the GPUs of a node).
+
+    python bench.py --gpus 1 --steps 2000 --warmup 50
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+        --master-port 29500 bench.py --gpus 8 --steps 2000 --warmup 50
+
+A "step" is one ``jxs_step`` launch over the rank's batch (1024 environments per GPU, weak
+scaling: 8192 environments on 8 GPUs).  The state is resident in HBM, there is no host
+round-trip inside the timed region and no per-step communication; after the timed region the
+final state shards are concatenated with ONE RCCL all-gather (timed separately).  Rank 0
+prints one JSON line.  ``torch.distributed`` is used only as the launcher's process group
+(barrier, max-over-ranks, unique-id broadcast); the data path is the C-ABI library.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+FP32_PEAK_TFLOPS = 157.3  # vector FP32 peak (same guide)
+FLOPS_PER_ENV_STEP = 30e3  # structure-exploiting flop model, SURVEY.md section 8(d) / A.5
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--envs-per-gpu", type=int, default=1024)
+    ap.add_argument("--dtype", default="float32", choices=["float32", "float64"])
+    ap.add_argument("--model", default="icub23", choices=["icub23", "icub23_16", "anymal12", "cartpole"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def build_model(name):
+    import jaxsim_amd as ja
+    from jaxsim_amd import robots
+
+    urdf = {
+        "icub23": lambda: robots.icub23_urdf(sole_boxes_per_foot=2),
+        "icub23_16": lambda: robots.icub23_urdf(sole_boxes_per_foot=1),
+        "anymal12": robots.anymal12_urdf,
+        "cartpole": robots.cartpole_urdf,
+    }[name]()
+    return ja.JaxSimModel.build_from_model_description(urdf)
+
+
+def synthetic_state(model, n_envs, seed, dtype):
+    """Synthetic inputs of SURVEY.md section 8(d): 'standing set' -- base z in [0.55, 0.75],
+    |roll|,|pitch| <= 0.3, yaw U(-pi, pi), joints U(limits), all velocities U(-1, 1), zero
+    tangential deformation, tau_ref = 0, link_forces = None."""
+    import jaxsim_amd.api as js
+
+    floating = model.floating_base()
+    return js.data.random_model_data(
+        model,
+        batch_size=n_envs,
+        seed=seed,
+        dtype=dtype,
+        base_pos_bounds=((-1, -1, 0.55), (1, 1, 0.75)) if floating else ((0, 0, 0), (0, 0, 0)),
+        base_rpy_bounds=((-0.3, -0.3, -np.pi), (0.3, 0.3, np.pi)) if floating else ((0, 0, 0), (0, 0, 0)),
+    )
+
+
+def cpu_baseline(model, n_envs, dtype, budget_s):
+    """Oracle C port (reference-structured dense 6x6 ABA, OpenMP over envs) on the host cores,
+    same workload, bounded sample."""
+    from oracle import cport
+    from jaxsim_amd import state as st
+
+    import oracle
+
+    cores = os.cpu_count() or 1
+    d = oracle.random_model_data(
+        model, batch_size=n_envs, seed=0, dtype=dtype,
+        base_pos_bounds=((-1, -1, 0.55), (1, 1, 0.75)), base_rpy_bounds=((-0.3, -0.3, -np.pi), (0.3, 0.3, np.pi)),
+    )  # fmt: skip
+    blk = st.pack_state(
+        st.StateLayout.of(model), dtype=dtype, base_position=d.base_position, base_quaternion=d.base_quaternion,
+        joint_positions=d.joint_positions, base_linear_velocity=d.base_linear_velocity,
+        base_angular_velocity=d.base_angular_velocity, joint_velocities=d.joint_velocities,
+        tangential_deformation=d.tangential_deformation,
+    )  # fmt: skip
+    cport.step(model, blk, n_steps=5, n_threads=cores)  # warm up the thread pool
+    t0 = time.perf_counter()
+    cport.step(model, blk, n_steps=20, n_threads=cores)
+    rate = 20 * n_envs / (time.perf_counter() - t0)
+    n_steps = int(max(20, min(20000, budget_s * rate / n_envs)))
+    t0 = time.perf_counter()
+    cport.step(model, blk, n_steps=n_steps, n_threads=cores)
+    dt = time.perf_counter() - t0
+    return {
+        "value": n_steps * n_envs / dt,
+        "unit": "env-steps/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"{n_steps} steps x {n_envs} envs of the same workload, oracle C port (dense 6x6 reference "
+        f"formulation, gcc -O3 -march=native, OpenMP {cores} threads), {np.dtype(dtype).name}, {dt:.1f} s",
+    }
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("multi-GPU runs are launched with torch.distributed.run (one rank per GPU)")
+
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import jaxsim_amd.api as js
+    from jaxsim_amd import _lib, distributed, runtime
+
+    runtime.require_device()
+    runtime.set_device(local_rank)
+    dtype = np.dtype(args.dtype)
+    model = build_model(args.model)
+    n_local = args.envs_per_gpu
+    data = synthetic_state(model, n_local, seed=rank, dtype=dtype)
+    stream = runtime.Stream()
+    runtime.set_stream(stream)
+    dm = runtime.device_model(model, dtype)
+    lib = _lib.load()
+    import ctypes as C
+
+    state_ptr = C.c_void_p(data._state.ptr)
+
+    def run_steps(k):
+        for _ in range(k):
+            rc = lib.jxs_step(dm.handle, state_ptr, state_ptr, None, None, 2, n_local, stream.handle)
+            if rc != 0:
+                _lib.check(rc, "jxs_step")
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    run_steps(args.warmup)
+    stream.synchronize()
+    ev0, ev1 = runtime.Event(), runtime.Event()
+
+    barrier()
+    runtime.synchronize(stream)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    run_steps(args.steps)
+    ev1.record(stream)
+    runtime.synchronize(stream)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_ms(ev1) / max(args.steps, 1)  # HIP events on the launch stream
+
+    if dist is not None:
+        import torch
+
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # final state concat: ONE RCCL all-gather over xGMI, outside the timed region
+    allgather_ms = None
+    final = data.state_block()
+    if dist is not None:
+        comm = distributed.communicator_from_torch()
+        runtime.synchronize(stream)
+        barrier()
+        t1 = time.perf_counter()
+        full = distributed.all_gather_state(comm, data)
+        allgather_ms = (time.perf_counter() - t1) * 1e3
+        assert full.shape == (final.shape[0], n_local * world)
+        lo = rank * n_local
+        assert np.array_equal(full[:, lo : lo + n_local], final)
+    finite = bool(np.isfinite(final).all())
+
+    if rank == 0:
+        lay = dm.layout
+        n_total = n_local * world
+        value = n_total * args.steps / elapsed
+        n, n_cp = lay.n_joints, lay.n_points
+        alg_bytes_per_env = (2 * (13 + 2 * n + 3 * n_cp) + n) * dtype.itemsize
+        achieved_gbs = alg_bytes_per_env * n_local / (kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "env-steps/sec (whole node), iCub 23-DoF soft-contact, batch 1024/8192",
+            "value": value,
+            "unit": "env-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32" if dtype == np.float32 else "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.model} synthetic floating-base humanoid, soft contacts (K=1e6, D=2000, mu=0.5), "
+                f"semi-implicit Euler dt=1e-3, nL={lay.n_links} n={n} n_cp={n_cp}, "
+                f"{n_local} envs per GPU x {world} GPU(s) = {n_total} envs, one jxs_step launch per step",
+                "envs_per_gpu": n_local,
+                "global_batch": n_total,
+                "lanes_per_env": int(lay.group),
+                "parallelism": f"batch-sharded x{world}, no per-step communication",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved_gbs,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved_gbs / HBM_PEAK_GBS,
+                "traffic": None,
+                "algorithmic_bytes_per_env_step": alg_bytes_per_env,
+                "kernel": "jxs_kernel<float,32,MODE_STEP>" if dtype == np.float32 else "jxs_kernel<double,32,MODE_STEP>",
+                "kernel_avg_launch_us": kernel_ms * 1e3,
+                "fp32_flop_model_per_env_step": FLOPS_PER_ENV_STEP,
+                "fp32_frac_of_vector_peak": FLOPS_PER_ENV_STEP * n_local / (kernel_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
+            },
+            "final_state_finite": finite,
+            "allgather_ms": allgather_ms,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(model, n_local, dtype, args.cpu_baseline_seconds)
+            except Exception as e:  # the baseline must never take the GPU number down with it
+                out["cpu_baseline"] = {"value": None, "unit": "env-steps/s", "cores": os.cpu_count(), "kind": "port",
+                                       "sample": f"failed: {e!r}"}  # fmt: skip
+        print(json.dumps(out), flush=True)
+
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,191 @@
+"""``jaxsim.api.model`` mirror for the hot path: the Python functions a jaxsim user calls.
+
+Every function launches the HIP kernels through the C-ABI; there is no CPU fallback.
+Representation handling at the boundary (Inertial / Body / Mixed, default Mixed on the data
+object) follows the reference wrappers and is done in NumPy on the few [N,6] base
+quantities; the batched state itself never leaves the GPU inside ``step``.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from .. import _lib, runtime
+from ..data import JaxSimModelData, _inertial_to_other, _other_to_inertial
+from ..model import JaxSimModel, VelRepr  # noqa: F401
+from ..runtime import DeviceArray
+
+
+def _as_device(x, rows: int, N: int, dtype, trailing_shape) -> DeviceArray | None:
+    """Accept None | DeviceArray ([rows][N]) | host array ([N, *trailing] or [*trailing])."""
+    if x is None:
+        return None
+    if isinstance(x, DeviceArray):
+        if x.shape != (rows, N) or x.dtype != np.dtype(dtype):
+            raise ValueError((x.shape, (rows, N)))
+        return x
+    a = np.asarray(x, dtype=np.float64)
+    a = a.squeeze() if a.ndim > len(trailing_shape) + 1 else a
+    if a.shape == tuple(trailing_shape):
+        a = np.broadcast_to(a, (N,) + tuple(trailing_shape))
+    if a.shape != (N,) + tuple(trailing_shape):
+        raise ValueError((a.shape, (N,) + tuple(trailing_shape)))  # cf. rbda/utils.py:102-133
+    return DeviceArray.from_host(np.ascontiguousarray(a.reshape(N, rows).T), dtype=dtype)
+
+
+def _ptr(d: DeviceArray | None):
+    return None if d is None else C.c_void_p(d.ptr)
+
+
+def step(
+    model: JaxSimModel,
+    data: JaxSimModelData,
+    *,
+    link_forces=None,
+    joint_force_references=None,
+    inplace: bool = False,
+) -> JaxSimModelData:
+    """``js.model.step`` (``src/jaxsim/api/model.py:2601-2681``).
+
+    ``link_forces`` ([N, nL, 6] or [nL, 6]) are expressed in ``data.velocity_representation``
+    exactly like the reference (``:2641-2646``); ``joint_force_references`` is [N, n] or [n].
+    Returns a new data object (functional); ``inplace=True`` (extension) updates ``data``'s
+    buffer instead and returns a data object sharing it.
+    """
+    dm = runtime.device_model(model, data.dtype)
+    N, nL, n = data.batch_size, model.number_of_links(), model.dofs()
+    f = _as_device(link_forces, nL * 6, N, data.dtype, (nL, 6))
+    tau = _as_device(joint_force_references, n, N, data.dtype, (n,))
+    out = data._state if inplace else DeviceArray(data._state.rows, N, data.dtype)
+    _lib.check(
+        _lib.load().jxs_step(
+            dm.handle, C.c_void_p(data._state.ptr), C.c_void_p(out.ptr), _ptr(tau), _ptr(f),
+            int(data.velocity_representation), N, runtime._sp(),
+        ),
+        "jxs_step",
+    )  # fmt: skip
+    return JaxSimModelData(model, out, data.velocity_representation, data._batched)
+
+
+def rollout(model: JaxSimModel, data: JaxSimModelData, n_steps: int, *, link_forces=None,
+            joint_force_references=None) -> JaxSimModelData:  # fmt: skip
+    """``n_steps`` back-to-back steps with constant inputs (what ``jax.lax.fori_loop`` over
+    ``step`` does in the reference's notebooks); the input data is not modified."""
+    dm = runtime.device_model(model, data.dtype)
+    N, nL, n = data.batch_size, model.number_of_links(), model.dofs()
+    f = _as_device(link_forces, nL * 6, N, data.dtype, (nL, 6))
+    tau = _as_device(joint_force_references, n, N, data.dtype, (n,))
+    out = data._state.copy()
+    _lib.check(
+        _lib.load().jxs_rollout(
+            dm.handle, C.c_void_p(out.ptr), _ptr(tau), _ptr(f), int(data.velocity_representation), N,
+            int(n_steps), runtime._sp(),
+        ),
+        "jxs_rollout",
+    )  # fmt: skip
+    return JaxSimModelData(model, out, data.velocity_representation, data._batched)
+
+
+def _mixed_frame(data: JaxSimModelData):
+    """(W_H_C, W_v_WC) of the active representation (``api/model.py:1356-1398``)."""
+    N = data.batch_size
+    H = data._base_transform_batched()
+    rep = data.velocity_representation
+    if rep == VelRepr.Inertial:
+        return np.broadcast_to(np.eye(4), (N, 4, 4)), np.zeros((N, 6))
+    if rep == VelRepr.Body:
+        return H, data._base_velocity_batched(VelRepr.Inertial)
+    Hm = H.copy()
+    Hm[:, :3, :3] = np.eye(3)
+    v = np.zeros((N, 6))
+    v[:, :3] = data._base_velocity_batched(VelRepr.Mixed)[:, :3]
+    return Hm, v
+
+
+def _vx(v6: np.ndarray, x6: np.ndarray) -> np.ndarray:
+    """``Cross.vx(v) @ x`` (``src/jaxsim/math/cross.py:14-43``), batched."""
+    v, w = v6[:, :3], v6[:, 3:]
+    return np.concatenate([np.cross(w, x6[:, :3]) + np.cross(v, x6[:, 3:]), np.cross(w, x6[:, 3:])], -1)
+
+
+def forward_dynamics_aba(model: JaxSimModel, data: JaxSimModelData, *, joint_forces=None, link_forces=None):
+    """``forward_dynamics_aba`` (``src/jaxsim/api/model.py:1269-1406``): base acceleration in
+    the active representation of ``data`` and joint accelerations."""
+    dm = runtime.device_model(model, data.dtype)
+    N, nL, n = data.batch_size, model.number_of_links(), model.dofs()
+    f = _as_device(link_forces, nL * 6, N, data.dtype, (nL, 6))
+    tau = _as_device(joint_forces, n, N, data.dtype, (n,))
+    out = DeviceArray(6 + n, N, data.dtype)
+    _lib.check(
+        _lib.load().jxs_forward_dynamics_aba(
+            dm.handle, C.c_void_p(data._state.ptr), _ptr(tau), _ptr(f), int(data.velocity_representation),
+            C.c_void_p(out.ptr), N, runtime._sp(),
+        ),
+        "jxs_forward_dynamics_aba",
+    )  # fmt: skip
+    res = out.to_host().T.astype(np.float64)
+    W_vd, sdd = res[:, :6], res[:, 6:]
+    if model.floating_base():
+        W_H_C, W_v_WC = _mixed_frame(data)
+        W_v_WB = data._base_velocity_batched(VelRepr.Inertial)
+        C_vd = _inertial_to_other(W_vd - _vx(W_v_WC, W_v_WB), VelRepr.Body, W_H_C, False)
+    else:
+        C_vd = np.zeros((N, 6))
+    return data._out(C_vd.astype(data.dtype)), data._out(sdd.astype(data.dtype))
+
+
+def inverse_dynamics(model: JaxSimModel, data: JaxSimModelData, *, joint_accelerations=None,
+                     base_acceleration=None, link_forces=None):  # fmt: skip
+    """``inverse_dynamics`` (``src/jaxsim/api/model.py:1746-1894``): base wrench in the active
+    representation and joint torques."""
+    dm = runtime.device_model(model, data.dtype)
+    N, nL, n = data.batch_size, model.number_of_links(), model.dofs()
+    sdd = np.zeros((N, n)) if joint_accelerations is None else np.broadcast_to(
+        np.asarray(joint_accelerations, dtype=np.float64).reshape(-1, n), (N, n))  # fmt: skip
+    vd = np.zeros((N, 6)) if base_acceleration is None else np.broadcast_to(
+        np.asarray(base_acceleration, dtype=np.float64).reshape(-1, 6), (N, 6))  # fmt: skip
+    # active representation -> inertial (api/model.py:1801-1842)
+    W_H_C, W_v_WC = _mixed_frame(data)
+    C_v_WC = _inertial_to_other(W_v_WC, VelRepr.Body, W_H_C, False)
+    W_vd = _other_to_inertial(vd + _vx(C_v_WC, data._base_velocity_batched()), VelRepr.Body, W_H_C, False)
+    in_acc = DeviceArray.from_host(np.ascontiguousarray(np.concatenate([W_vd, sdd], -1).T), dtype=data.dtype)
+    f = _as_device(link_forces, nL * 6, N, data.dtype, (nL, 6))
+    out = DeviceArray(6 + n, N, data.dtype)
+    _lib.check(
+        _lib.load().jxs_inverse_dynamics(
+            dm.handle, C.c_void_p(data._state.ptr), C.c_void_p(in_acc.ptr), _ptr(f),
+            int(data.velocity_representation), C.c_void_p(out.ptr), N, runtime._sp(),
+        ),
+        "jxs_inverse_dynamics",
+    )  # fmt: skip
+    res = out.to_host().T.astype(np.float64)
+    f_B = _inertial_to_other(res[:, :6], data.velocity_representation, data._base_transform_batched(), True)
+    return data._out(f_B.astype(data.dtype)), data._out(res[:, 6:].astype(data.dtype))
+
+
+def free_floating_gravity_forces(model: JaxSimModel, data: JaxSimModelData):
+    """``g(q)`` (``src/jaxsim/api/model.py:1897-1931``)."""
+    z = data.replace(
+        model,
+        joint_velocities=np.zeros_like(data._fields()["joint_velocities"]),
+        base_linear_velocity=np.zeros((data.batch_size, 3)),
+        base_angular_velocity=np.zeros((data.batch_size, 3)),
+    )
+    fB, tau = inverse_dynamics(model, z)
+    return np.concatenate([fB, tau], axis=-1)
+
+
+def free_floating_bias_forces(model: JaxSimModel, data: JaxSimModelData):
+    """``h(q, nu)`` (``src/jaxsim/api/model.py:1934-1978``); fixed-base models drop the base
+    velocity like the reference does."""
+    d = data
+    if not model.floating_base():
+        d = data.replace(
+            model,
+            base_linear_velocity=np.zeros((data.batch_size, 3)),
+            base_angular_velocity=np.zeros((data.batch_size, 3)),
+        )
+    fB, tau = inverse_dynamics(model, d)
+    return np.concatenate([fB, tau], axis=-1)

@@ -1,0 +1,410 @@
+// C-ABI implementation (include/jaxsim_amd.h): gfx950 kernels + launchers + device plumbing.
+//
+// Launch geometry: one wavefront per workgroup, G lanes per environment, 64/G environments
+// per wave.  At the benchmark size (N = 1024 environments per GPU, G = 32) that is 512
+// single-wave workgroups, i.e. two waves on each of the 256 CUs, placed by the dispatcher on
+// different SIMDs; all cross-lane traffic is wavefront shuffles, no LDS allocation, no
+// barriers.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstring>
+#include <memory>
+#include <string>
+
+#include "../../include/jaxsim_amd.h"
+#include "jxs_lanes_device.h"
+// lanes before the core: the core's unqualified calls on scalar lane values bind here
+#include "jxs_core.h"
+#include "jxs_pack.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+int hip_fail(hipError_t e, const char* what) {
+  return fail(JXS_ENODEVICE, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define JXS_HIP(call)                                  \
+  do {                                                 \
+    hipError_t e_ = (call);                            \
+    if (e_ != hipSuccess) return hip_fail(e_, #call);  \
+  } while (0)
+
+template <typename T, int G, int MODE>
+__global__ __launch_bounds__(64) void jxs_kernel(const jxs::KParams<T> P, const jxs::KArgs<T> A) {
+  const jxs::DeviceLanes<T, G> ln(A.N);
+  jxs::Core<jxs::DeviceLanes<T, G>> core(P, A, ln);
+  core.template run<MODE>();
+}
+
+template <typename T>
+struct DeviceTables {
+  T* ltf = nullptr;
+  int* lti = nullptr;
+  T* ptf = nullptr;
+  int* pti = nullptr;
+  int* head = nullptr;
+};
+
+template <typename T, int G, int MODE>
+hipError_t launch_one(const jxs::KParams<T>& P, const jxs::KArgs<T>& A, hipStream_t s) {
+  const int envs_per_wave = 64 / G;
+  const int blocks = (A.N + envs_per_wave - 1) / envs_per_wave;
+  hipLaunchKernelGGL((jxs_kernel<T, G, MODE>), dim3(blocks), dim3(64), 0, s, P, A);
+  return hipGetLastError();
+}
+
+template <typename T, int MODE>
+hipError_t launch_g(int G, const jxs::KParams<T>& P, const jxs::KArgs<T>& A, hipStream_t s) {
+  switch (G) {
+    case 4: return launch_one<T, 4, MODE>(P, A, s);
+    case 8: return launch_one<T, 8, MODE>(P, A, s);
+    case 16: return launch_one<T, 16, MODE>(P, A, s);
+    case 32: return launch_one<T, 32, MODE>(P, A, s);
+    default: return launch_one<T, 64, MODE>(P, A, s);
+  }
+}
+
+template <typename T>
+hipError_t launch_mode(int mode, int G, const jxs::KParams<T>& P, const jxs::KArgs<T>& A, hipStream_t s) {
+  switch (mode) {
+    case jxs::MODE_STEP: return launch_g<T, jxs::MODE_STEP>(G, P, A, s);
+    case jxs::MODE_FD: return launch_g<T, jxs::MODE_FD>(G, P, A, s);
+    case jxs::MODE_ID: return launch_g<T, jxs::MODE_ID>(G, P, A, s);
+    default: return launch_g<T, jxs::MODE_KIN>(G, P, A, s);
+  }
+}
+
+template <typename T>
+struct ModelT {
+  jxs::Packed<T> pk;
+  DeviceTables<T> dev;
+
+  ~ModelT() {
+    (void)hipFree(dev.ltf);
+    (void)hipFree(dev.lti);
+    (void)hipFree(dev.ptf);
+    (void)hipFree(dev.pti);
+    (void)hipFree(dev.head);
+  }
+
+  template <typename U>
+  static hipError_t upload(U** dptr, const std::vector<U>& v) {
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(dptr), std::max<size_t>(v.size(), 1) * sizeof(U));
+    if (e != hipSuccess) return e;
+    if (!v.empty()) e = hipMemcpy(*dptr, v.data(), v.size() * sizeof(U), hipMemcpyHostToDevice);
+    return e;
+  }
+  hipError_t upload_all() {
+    hipError_t e;
+    if ((e = upload(&dev.ltf, pk.ltf)) != hipSuccess) return e;
+    if ((e = upload(&dev.lti, pk.lti)) != hipSuccess) return e;
+    if ((e = upload(&dev.ptf, pk.ptf)) != hipSuccess) return e;
+    if ((e = upload(&dev.pti, pk.pti)) != hipSuccess) return e;
+    return upload(&dev.head, pk.head);
+  }
+  jxs::KArgs<T> args(int N) const {
+    jxs::KArgs<T> a{};
+    a.ltf = dev.ltf;
+    a.lti = dev.lti;
+    a.ptf = dev.ptf;
+    a.pti = dev.pti;
+    a.head = dev.head;
+    a.N = N;
+    return a;
+  }
+};
+
+}  // namespace
+
+struct jxs_model {
+  int dtype = JXS_F32;
+  std::unique_ptr<ModelT<float>> f32;
+  std::unique_ptr<ModelT<double>> f64;
+};
+
+namespace {
+
+template <typename T>
+ModelT<T>* typed(jxs_model* m);
+template <>
+ModelT<float>* typed<float>(jxs_model* m) { return m->f32.get(); }
+template <>
+ModelT<double>* typed<double>(jxs_model* m) { return m->f64.get(); }
+
+template <typename T>
+int create_typed(const jxs_model_desc* d, std::unique_ptr<ModelT<T>>& slot) {
+  auto mt = std::make_unique<ModelT<T>>();
+  const std::string err = jxs::pack_model<T>(*d, mt->pk);
+  if (!err.empty()) return fail(JXS_EINVAL, err);
+  hipError_t e = mt->upload_all();
+  if (e != hipSuccess) return hip_fail(e, "uploading model tables");
+  slot = std::move(mt);
+  return JXS_OK;
+}
+
+template <typename T>
+int run_typed(jxs_model* model, int mode, const void* state_in, void* state_out, const void* tau,
+              const void* link_f, int force_repr, const void* in_a, void* out_a, void* out_H, void* out_V, int N,
+              int repeat, void* stream) {
+  ModelT<T>* mt = typed<T>(model);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  jxs::KArgs<T> a = mt->args(N);
+  a.state_in = static_cast<const T*>(state_in);
+  a.state_out = static_cast<T*>(state_out);
+  a.tau = static_cast<const T*>(tau);
+  a.link_f = static_cast<const T*>(link_f);
+  a.force_repr = force_repr;
+  a.in_a = static_cast<const T*>(in_a);
+  a.out_a = static_cast<T*>(out_a);
+  a.out_H = static_cast<T*>(out_H);
+  a.out_V = static_cast<T*>(out_V);
+  if (mode == jxs::MODE_STEP && state_out != state_in && mt->pk.n_disabled > 0) {
+    // rows of disabled collidable points are not touched by the kernel: carry them over
+    JXS_HIP(hipMemcpyAsync(state_out, state_in, sizeof(T) * (size_t)mt->pk.P.n_rows * N, hipMemcpyDeviceToDevice, s));
+  }
+  for (int it = 0; it < repeat; ++it) {
+    hipError_t e = launch_mode<T>(mode, mt->pk.G, mt->pk.P, a, s);
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+  }
+  return JXS_OK;
+}
+
+int run_any(jxs_model* model, int mode, const void* state_in, void* state_out, const void* tau, const void* link_f,
+            int force_repr, const void* in_a, void* out_a, void* out_H, void* out_V, int N, int repeat,
+            void* stream) {
+  if (model == nullptr) return fail(JXS_EINVAL, "null model");
+  if (state_in == nullptr) return fail(JXS_EINVAL, "null state");
+  if (N <= 0) return fail(JXS_EINVAL, "N must be positive");
+  if (force_repr < 0 || force_repr > 2) return fail(JXS_EINVAL, "invalid force representation");
+  if (model->dtype == JXS_F64)
+    return run_typed<double>(model, mode, state_in, state_out, tau, link_f, force_repr, in_a, out_a, out_H, out_V, N,
+                             repeat, stream);
+  return run_typed<float>(model, mode, state_in, state_out, tau, link_f, force_repr, in_a, out_a, out_H, out_V, N,
+                          repeat, stream);
+}
+
+// ---- RCCL, resolved lazily so that the library loads (and the CPU symbol test passes)
+// ---- without pulling a second RCCL next to the one a host launcher may already hold.
+struct Rccl {
+  void* h = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+Rccl g_rccl;
+
+int rccl_load() {
+  if (g_rccl.h != nullptr) return JXS_OK;
+  void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+  if (h == nullptr) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+  if (h == nullptr) return fail(JXS_ECOMM, std::string("cannot load RCCL: ") + dlerror());
+  Rccl r;
+  r.h = h;
+  r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+  r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
+  r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+  r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(h, "ncclAllGather"));
+  r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+  if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.GetErrorString)
+    return fail(JXS_ECOMM, "RCCL library lacks an expected symbol");
+  g_rccl = r;
+  return JXS_OK;
+}
+int rccl_fail(ncclResult_t r, const char* what) {
+  return fail(JXS_ECOMM, std::string(what) + ": " + g_rccl.GetErrorString(r));
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* jxs_last_error(void) { return g_err.c_str(); }
+
+int jxs_device_count(int* count) {
+  if (count == nullptr) return fail(JXS_EINVAL, "null count");
+  hipError_t e = hipGetDeviceCount(count);
+  if (e != hipSuccess) {
+    *count = 0;
+    return hip_fail(e, "hipGetDeviceCount");
+  }
+  return JXS_OK;
+}
+int jxs_set_device(int device) {
+  JXS_HIP(hipSetDevice(device));
+  return JXS_OK;
+}
+int jxs_malloc(void** dptr, uint64_t bytes) {
+  if (dptr == nullptr) return fail(JXS_EINVAL, "null dptr");
+  hipError_t e = hipMalloc(dptr, bytes > 0 ? bytes : 1);
+  if (e == hipErrorOutOfMemory) return fail(JXS_ENOMEM, "hipMalloc: out of memory");
+  if (e != hipSuccess) return hip_fail(e, "hipMalloc");
+  return JXS_OK;
+}
+int jxs_free(void* dptr) {
+  JXS_HIP(hipFree(dptr));
+  return JXS_OK;
+}
+int jxs_memcpy_h2d(void* dst, const void* src, uint64_t bytes, void* stream) {
+  JXS_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, static_cast<hipStream_t>(stream)));
+  JXS_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+  return JXS_OK;
+}
+int jxs_memcpy_d2h(void* dst, const void* src, uint64_t bytes, void* stream) {
+  JXS_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)));
+  JXS_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+  return JXS_OK;
+}
+int jxs_memcpy_d2d(void* dst, const void* src, uint64_t bytes, void* stream) {
+  JXS_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
+  return JXS_OK;
+}
+int jxs_memset(void* dst, int value, uint64_t bytes, void* stream) {
+  JXS_HIP(hipMemsetAsync(dst, value, bytes, static_cast<hipStream_t>(stream)));
+  return JXS_OK;
+}
+int jxs_stream_create(void** stream) {
+  if (stream == nullptr) return fail(JXS_EINVAL, "null stream");
+  hipStream_t s;
+  JXS_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  *stream = s;
+  return JXS_OK;
+}
+int jxs_stream_destroy(void* stream) {
+  JXS_HIP(hipStreamDestroy(static_cast<hipStream_t>(stream)));
+  return JXS_OK;
+}
+int jxs_stream_synchronize(void* stream) {
+  JXS_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+  return JXS_OK;
+}
+int jxs_device_synchronize(void) {
+  JXS_HIP(hipDeviceSynchronize());
+  return JXS_OK;
+}
+int jxs_event_create(void** event) {
+  if (event == nullptr) return fail(JXS_EINVAL, "null event");
+  hipEvent_t e;
+  JXS_HIP(hipEventCreate(&e));
+  *event = e;
+  return JXS_OK;
+}
+int jxs_event_destroy(void* event) {
+  JXS_HIP(hipEventDestroy(static_cast<hipEvent_t>(event)));
+  return JXS_OK;
+}
+int jxs_event_record(void* event, void* stream) {
+  JXS_HIP(hipEventRecord(static_cast<hipEvent_t>(event), static_cast<hipStream_t>(stream)));
+  return JXS_OK;
+}
+int jxs_event_elapsed_ms(void* start, void* stop, float* ms) {
+  JXS_HIP(hipEventSynchronize(static_cast<hipEvent_t>(stop)));
+  JXS_HIP(hipEventElapsedTime(ms, static_cast<hipEvent_t>(start), static_cast<hipEvent_t>(stop)));
+  return JXS_OK;
+}
+
+int jxs_model_create(const jxs_model_desc* desc, jxs_model** out) {
+  if (desc == nullptr || out == nullptr) return fail(JXS_EINVAL, "null argument");
+  if (desc->dtype != JXS_F32 && desc->dtype != JXS_F64) return fail(JXS_EINVAL, "dtype must be JXS_F32 or JXS_F64");
+  if (desc->D <= 0 && desc->n_points > 0) return fail(JXS_EINVAL, "soft-contact damping D must be positive");
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count == 0)
+    return fail(JXS_ENODEVICE, "no HIP device available (this library has no CPU fallback)");
+  auto m = std::make_unique<jxs_model>();
+  m->dtype = desc->dtype;
+  int rc = (desc->dtype == JXS_F64) ? create_typed<double>(desc, m->f64) : create_typed<float>(desc, m->f32);
+  if (rc != JXS_OK) return rc;
+  *out = m.release();
+  return JXS_OK;
+}
+int jxs_model_destroy(jxs_model* model) {
+  delete model;
+  return JXS_OK;
+}
+int jxs_model_layout(const jxs_model* model, jxs_layout* out) {
+  if (model == nullptr || out == nullptr) return fail(JXS_EINVAL, "null argument");
+  auto fill = [&](const auto& pk) {
+    const auto& P = pk.P;
+    *out = jxs_layout{P.nL, P.n, P.n_points, P.n_rows, P.row_pos, P.row_quat, P.row_s,
+                      P.row_vlin, P.row_vang, P.row_sd, P.row_m, pk.G, model->dtype};
+  };
+  if (model->dtype == JXS_F64) fill(model->f64->pk); else fill(model->f32->pk);
+  return JXS_OK;
+}
+
+int jxs_step(jxs_model* model, const void* state_in, void* state_out, const void* tau, const void* link_forces,
+             int force_repr, int N, void* stream) {
+  if (state_out == nullptr) return fail(JXS_EINVAL, "null state_out");
+  return run_any(model, jxs::MODE_STEP, state_in, state_out, tau, link_forces, force_repr, nullptr, nullptr, nullptr,
+                 nullptr, N, 1, stream);
+}
+int jxs_rollout(jxs_model* model, void* state, const void* tau, const void* link_forces, int force_repr, int N,
+                int n_steps, void* stream) {
+  if (n_steps < 0) return fail(JXS_EINVAL, "n_steps must be >= 0");
+  return run_any(model, jxs::MODE_STEP, state, state, tau, link_forces, force_repr, nullptr, nullptr, nullptr, nullptr,
+                 N, n_steps, stream);
+}
+int jxs_forward_dynamics_aba(jxs_model* model, const void* state, const void* joint_forces, const void* link_forces,
+                             int force_repr, void* out_acc, int N, void* stream) {
+  if (out_acc == nullptr) return fail(JXS_EINVAL, "null out_acc");
+  return run_any(model, jxs::MODE_FD, state, nullptr, joint_forces, link_forces, force_repr, nullptr, out_acc, nullptr,
+                 nullptr, N, 1, stream);
+}
+int jxs_inverse_dynamics(jxs_model* model, const void* state, const void* in_acc, const void* link_forces,
+                         int force_repr, void* out_forces, int N, void* stream) {
+  if (out_forces == nullptr) return fail(JXS_EINVAL, "null out_forces");
+  return run_any(model, jxs::MODE_ID, state, nullptr, nullptr, link_forces, force_repr, in_acc, out_forces, nullptr,
+                 nullptr, N, 1, stream);
+}
+int jxs_refresh_kinematics(jxs_model* model, const void* state, void* out_link_transforms, void* out_link_velocities,
+                           int N, void* stream) {
+  return run_any(model, jxs::MODE_KIN, state, nullptr, nullptr, nullptr, 0, nullptr, nullptr, out_link_transforms,
+                 out_link_velocities, N, 1, stream);
+}
+
+int jxs_comm_unique_id(char id[128]) {
+  if (id == nullptr) return fail(JXS_EINVAL, "null id");
+  int rc = rccl_load();
+  if (rc != JXS_OK) return rc;
+  ncclUniqueId u;
+  ncclResult_t r = g_rccl.GetUniqueId(&u);
+  if (r != ncclSuccess) return rccl_fail(r, "ncclGetUniqueId");
+  static_assert(sizeof(u.internal) == 128, "unexpected ncclUniqueId size");
+  std::memcpy(id, u.internal, 128);
+  return JXS_OK;
+}
+int jxs_comm_init(void** comm, const char id[128], int rank, int world_size) {
+  if (comm == nullptr || id == nullptr) return fail(JXS_EINVAL, "null argument");
+  int rc = rccl_load();
+  if (rc != JXS_OK) return rc;
+  ncclUniqueId u;
+  std::memcpy(u.internal, id, 128);
+  ncclComm_t c;
+  ncclResult_t r = g_rccl.CommInitRank(&c, world_size, u, rank);
+  if (r != ncclSuccess) return rccl_fail(r, "ncclCommInitRank");
+  *comm = c;
+  return JXS_OK;
+}
+int jxs_comm_destroy(void* comm) {
+  if (comm == nullptr) return JXS_OK;
+  ncclResult_t r = g_rccl.CommDestroy(static_cast<ncclComm_t>(comm));
+  if (r != ncclSuccess) return rccl_fail(r, "ncclCommDestroy");
+  return JXS_OK;
+}
+int jxs_allgather(void* comm, const void* send, void* recv, uint64_t count, int dtype, void* stream) {
+  if (comm == nullptr || send == nullptr || recv == nullptr) return fail(JXS_EINVAL, "null argument");
+  ncclResult_t r = g_rccl.AllGather(send, recv, count, dtype == JXS_F64 ? ncclFloat64 : ncclFloat32,
+                                    static_cast<ncclComm_t>(comm), static_cast<hipStream_t>(stream));
+  if (r != ncclSuccess) return rccl_fail(r, "ncclAllGather");
+  return JXS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,111 @@
+"""Multi-GPU: one process per GPU, the batch sharded in contiguous slices, no per-step
+communication; ONE RCCL all-gather over xGMI concatenates the final state shards.
+
+The reference has no multi-device code (single-process JAX, ``jax.vmap`` only; SURVEY.md
+headline fact 1): environments never interact, so the batch shards trivially.  The process
+group of the *launcher* (``torch.distributed``, started by ``torch.distributed.run``) is used
+only for bootstrap -- broadcasting the 128-byte RCCL unique id, barriers, and the timing
+reduction of ``bench.py`` -- while the data path goes through ``jxs_allgather`` (RCCL called
+from the C-ABI library on raw device pointers).  On a machine without GPUs (the CPU tests,
+``gloo`` backend) the same host logic gathers through ``torch.distributed`` instead.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib, runtime
+
+
+def shard_bounds(n_total: int, rank: int, world_size: int) -> tuple[int, int]:
+    """Contiguous slice ``[lo, hi)`` of the batch owned by ``rank`` (remainder spread over the
+    first ranks)."""
+    if not (0 <= rank < world_size):
+        raise ValueError((rank, world_size))
+    base, rem = divmod(int(n_total), int(world_size))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_block(block: np.ndarray, rank: int, world_size: int) -> np.ndarray:
+    """Slice a host ``[rows, N]`` state block for ``rank``."""
+    lo, hi = shard_bounds(block.shape[1], rank, world_size)
+    return np.ascontiguousarray(block[:, lo:hi])
+
+
+def concat_shards(gathered: np.ndarray) -> np.ndarray:
+    """``[world, rows, n_local]`` (the all-gather result) -> ``[rows, world * n_local]``."""
+    w, rows, n = gathered.shape
+    return np.ascontiguousarray(np.transpose(gathered, (1, 0, 2)).reshape(rows, w * n))
+
+
+class Communicator:
+    """RCCL communicator owned by the C-ABI library (``jxs_comm_*``)."""
+
+    def __init__(self, unique_id: bytes, rank: int, world_size: int):
+        if len(unique_id) != 128:
+            raise ValueError("RCCL unique id must be 128 bytes")
+        self.rank, self.world_size = int(rank), int(world_size)
+        buf = (C.c_char * 128).from_buffer_copy(unique_id)
+        h = C.c_void_p()
+        _lib.check(_lib.load().jxs_comm_init(C.byref(h), buf, self.rank, self.world_size), "jxs_comm_init")
+        self.handle = h
+
+    @staticmethod
+    def create_unique_id() -> bytes:
+        buf = (C.c_char * 128)()
+        _lib.check(_lib.load().jxs_comm_unique_id(buf), "jxs_comm_unique_id")
+        return bytes(buf.raw)
+
+    def all_gather(self, shard: runtime.DeviceArray) -> runtime.DeviceArray:
+        """Gather equal-sized ``[rows][n_local]`` shards into ``[world*rows][n_local]``."""
+        out = runtime.DeviceArray(shard.rows * self.world_size, shard.cols, shard.dtype)
+        _lib.check(
+            _lib.load().jxs_allgather(
+                self.handle, C.c_void_p(shard.ptr), C.c_void_p(out.ptr), shard.rows * shard.cols,
+                _lib.dtype_code(shard.dtype), runtime._sp(),
+            ),
+            "jxs_allgather",
+        )  # fmt: skip
+        return out
+
+    def __del__(self):
+        try:
+            _lib.load().jxs_comm_destroy(self.handle)
+        except Exception:
+            pass
+
+
+def communicator_from_torch() -> Communicator:
+    """Bootstrap a ``Communicator`` from an initialised ``torch.distributed`` process group:
+    rank 0 creates the RCCL unique id, the launcher's group broadcasts it."""
+    import torch.distributed as dist
+
+    rank, world = dist.get_rank(), dist.get_world_size()
+    box = [Communicator.create_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    return Communicator(box[0], rank, world)
+
+
+def all_gather_state_blocks_host(local_block: np.ndarray) -> np.ndarray:
+    """CPU path of the final concat (``gloo``): gather host ``[rows, n_local]`` blocks of equal
+    size through the launcher's process group and return ``[rows, N_total]``."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size()
+    t = torch.from_numpy(np.ascontiguousarray(local_block))
+    outs = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(outs, t)
+    return concat_shards(np.stack([o.numpy() for o in outs], axis=0))
+
+
+def all_gather_state(comm: Communicator, data) -> np.ndarray:
+    """GPU path of the final concat: RCCL all-gather of the device state, returned on the
+    host as one ``[rows, N_total]`` block (every rank gets the full batch)."""
+    gathered = comm.all_gather(data._state)
+    rows = data._state.rows
+    host = gathered.to_host().reshape(comm.world_size, rows, data._state.cols)
+    return concat_shards(host)

@@ -1,0 +1,202 @@
+"""Thin device runtime over the C-ABI: buffers, a size-bucketed free list, streams, events.
+
+No PyTorch / no HIP Python bindings: memory comes from ``jxs_malloc`` and is handed to the
+kernels as raw device pointers.  Freed buffers go back to a per-size free list so that the
+functional ``step`` (a fresh state block per call, like the reference's immutable pytrees)
+does not pay a ``hipMalloc`` per step.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import threading
+
+import numpy as np
+
+from . import _lib
+
+_pool_lock = threading.Lock()
+_pool: dict[int, list[int]] = {}
+_current_stream = None  # None = default (null) stream
+
+
+def current_stream():
+    return _current_stream
+
+
+def set_stream(stream) -> None:
+    """Select the HIP stream (``Stream`` or ``None``) used by subsequent calls."""
+    global _current_stream
+    _current_stream = stream
+
+
+def _sp(stream=None):
+    s = stream if stream is not None else _current_stream
+    return None if s is None else s.handle
+
+
+def device_count() -> int:
+    lib = _lib.load()
+    n = C.c_int(0)
+    rc = lib.jxs_device_count(C.byref(n))
+    return n.value if rc == 0 else 0
+
+
+def require_device() -> None:
+    if device_count() == 0:
+        raise _lib.JaxsimAmdError("no HIP device available; jaxsim_amd has no CPU fallback")
+
+
+def set_device(index: int) -> None:
+    _lib.check(_lib.load().jxs_set_device(int(index)), "jxs_set_device")
+
+
+def synchronize(stream=None) -> None:
+    lib = _lib.load()
+    if stream is None and _current_stream is None:
+        _lib.check(lib.jxs_device_synchronize(), "jxs_device_synchronize")
+    else:
+        _lib.check(lib.jxs_stream_synchronize(_sp(stream)), "jxs_stream_synchronize")
+
+
+class Stream:
+    def __init__(self):
+        h = C.c_void_p()
+        _lib.check(_lib.load().jxs_stream_create(C.byref(h)), "jxs_stream_create")
+        self.handle = h
+
+    def synchronize(self):
+        _lib.check(_lib.load().jxs_stream_synchronize(self.handle), "jxs_stream_synchronize")
+
+    def __del__(self):
+        try:
+            _lib.load().jxs_stream_destroy(self.handle)
+        except Exception:
+            pass
+
+
+class Event:
+    def __init__(self):
+        h = C.c_void_p()
+        _lib.check(_lib.load().jxs_event_create(C.byref(h)), "jxs_event_create")
+        self.handle = h
+
+    def record(self, stream=None):
+        _lib.check(_lib.load().jxs_event_record(self.handle, _sp(stream)), "jxs_event_record")
+
+    def elapsed_ms(self, stop: "Event") -> float:
+        ms = C.c_float(0)
+        _lib.check(_lib.load().jxs_event_elapsed_ms(self.handle, stop.handle, C.byref(ms)), "jxs_event_elapsed_ms")
+        return float(ms.value)
+
+    def __del__(self):
+        try:
+            _lib.load().jxs_event_destroy(self.handle)
+        except Exception:
+            pass
+
+
+class DeviceArray:
+    """A 2-D ``[rows][N]`` device array (N fastest) of float32/float64."""
+
+    def __init__(self, rows: int, cols: int, dtype, *, zero: bool = False):
+        self.rows, self.cols = int(rows), int(cols)
+        self.dtype = np.dtype(dtype)
+        self.nbytes = self.rows * self.cols * self.dtype.itemsize
+        self._bucket = max(self.nbytes, 1)
+        lib = _lib.load()
+        ptr = None
+        with _pool_lock:
+            free = _pool.get(self._bucket)
+            if free:
+                ptr = free.pop()
+        if ptr is None:
+            p = C.c_void_p()
+            _lib.check(lib.jxs_malloc(C.byref(p), self._bucket), "jxs_malloc")
+            ptr = p.value
+        self.ptr = ptr
+        if zero:
+            _lib.check(lib.jxs_memset(C.c_void_p(self.ptr), 0, self.nbytes, _sp()), "jxs_memset")
+
+    @property
+    def shape(self):
+        return (self.rows, self.cols)
+
+    def __del__(self):
+        ptr = getattr(self, "ptr", None)
+        if ptr is not None:
+            with _pool_lock:
+                _pool.setdefault(self._bucket, []).append(ptr)
+            self.ptr = None
+
+    @staticmethod
+    def from_host(a: np.ndarray, dtype=None) -> "DeviceArray":
+        a = np.ascontiguousarray(a, dtype=dtype or a.dtype)
+        if a.ndim != 2:
+            raise ValueError("expected a [rows, N] array")
+        out = DeviceArray(a.shape[0], a.shape[1], a.dtype)
+        _lib.check(
+            _lib.load().jxs_memcpy_h2d(C.c_void_p(out.ptr), a.ctypes.data_as(C.c_void_p), out.nbytes, _sp()),
+            "jxs_memcpy_h2d",
+        )
+        return out
+
+    def to_host(self) -> np.ndarray:
+        out = np.empty((self.rows, self.cols), dtype=self.dtype)
+        _lib.check(
+            _lib.load().jxs_memcpy_d2h(out.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr), self.nbytes, _sp()),
+            "jxs_memcpy_d2h",
+        )
+        return out
+
+    def copy(self) -> "DeviceArray":
+        out = DeviceArray(self.rows, self.cols, self.dtype)
+        _lib.check(
+            _lib.load().jxs_memcpy_d2d(C.c_void_p(out.ptr), C.c_void_p(self.ptr), self.nbytes, _sp()),
+            "jxs_memcpy_d2d",
+        )
+        return out
+
+
+def trim_pool() -> None:
+    """Return every pooled buffer to the driver."""
+    lib = _lib.load()
+    with _pool_lock:
+        for ptrs in _pool.values():
+            for p in ptrs:
+                lib.jxs_free(C.c_void_p(p))
+        _pool.clear()
+
+
+class DeviceModel:
+    """Owner of one ``jxs_model`` handle (device copy of the constant tables)."""
+
+    def __init__(self, model, dtype):
+        require_device()
+        lib = _lib.load()
+        desc, keep = _lib.make_desc(model, dtype)
+        h = C.c_void_p()
+        _lib.check(lib.jxs_model_create(C.byref(desc), C.byref(h)), "jxs_model_create")
+        self.handle = h
+        self.dtype = np.dtype(dtype)
+        lay = _lib.Layout()
+        _lib.check(lib.jxs_model_layout(h, C.byref(lay)), "jxs_model_layout")
+        self.layout = lay
+
+    def __del__(self):
+        try:
+            _lib.load().jxs_model_destroy(self.handle)
+        except Exception:
+            pass
+
+
+def device_model(model, dtype) -> DeviceModel:
+    """Device tables of ``model`` for ``dtype``; rebuilt when a model constant changed."""
+    sig = _lib.model_signature(model, dtype)
+    cache = model.__dict__.setdefault("_device", {})
+    hit = cache.get(np.dtype(dtype).str)
+    if hit is not None and hit[0] == sig:
+        return hit[1]
+    dm = DeviceModel(model, dtype)
+    cache[np.dtype(dtype).str] = (sig, dm)
+    return dm

@@ -1,0 +1,127 @@
+"""Shared helpers of the test-suite (TEST INFRASTRUCTURE)."""
+
+from __future__ import annotations
+
+import dataclasses
+
+import numpy as np
+
+import jaxsim_amd as ja
+import oracle
+from jaxsim_amd import robots
+from jaxsim_amd import state as st
+
+# Stated tolerances (north_star: "within a stated fp32/fp64 tolerance"), metric = rel_err below.
+# The truth is ALWAYS the fp64 oracle evaluated on the same (already rounded) inputs:
+#   fp64 kernels: 1e-10;
+#   fp32 kernels: 5e-4 for one step / one evaluation.  The reference formulation itself, run
+#   in fp32, is 1e-4..5e-4 away from its fp64 result on the contact-rich humanoid states
+#   (test_fp32_not_worse_than_reference_formulation), so a tighter bound would test rounding
+#   luck, not correctness.
+FP64_TOL = 1e-10
+FP32_TOL = 5e-4
+
+
+class ModelZoo:
+    """Lazily built host models used across the tests."""
+
+    _urdf = {
+        "box": lambda: robots.box_urdf(),
+        "sphere": lambda: robots.sphere_urdf(),
+        "pendulum": lambda: robots.single_pendulum_urdf(),
+        "double_pendulum": lambda: robots.double_pendulum_urdf(),
+        "cartpole": lambda: robots.cartpole_urdf(),
+        "chain5": lambda: robots.chain_urdf(5, fixed_base=True, seed=1),
+        "chain9f": lambda: robots.chain_urdf(9, fixed_base=False, seed=2),
+        "anymal": lambda: robots.anymal12_urdf(),
+        "icub": lambda: robots.icub23_urdf(),
+        "icub16": lambda: robots.icub23_urdf(sole_boxes_per_foot=1),
+    }
+    # base height range putting some collidable points in contact
+    contact_z = {"box": (0.0, 0.1), "sphere": (0.05, 0.12), "chain9f": (0.0, 0.3), "anymal": (0.58, 0.70),
+                 "icub": (0.56, 0.68), "icub16": (0.56, 0.68)}  # fmt: skip
+
+    def __init__(self):
+        self._cache = {}
+
+    def __call__(self, name: str) -> ja.JaxSimModel:
+        if name not in self._cache:
+            self._cache[name] = ja.JaxSimModel.build_from_model_description(self._urdf[name]())
+        return self._cache[name]
+
+    def random_data(self, name, N, seed=0, dtype=np.float64, rep=oracle.VelRepr.Mixed, in_contact=True):
+        m = self(name)
+        kw = {}
+        if in_contact and name in self.contact_z:
+            z0, z1 = self.contact_z[name]
+            kw = dict(base_pos_bounds=((-1, -1, z0), (1, 1, z1)), base_rpy_bounds=((-0.3, -0.3, -3), (0.3, 0.3, 3)))
+        d = oracle.random_model_data(m, batch_size=N, seed=seed, dtype=dtype, velocity_representation=rep, **kw)
+        rng = np.random.default_rng(seed + 1000)
+        d.tangential_deformation[:] = (1e-3 * rng.normal(size=d.tangential_deformation.shape)).astype(dtype)
+        return d
+
+
+def odata_to_block(model, d: oracle.OracleData, dtype=None) -> np.ndarray:
+    L = st.StateLayout.of(model)
+    return st.pack_state(
+        L,
+        base_position=d.base_position,
+        base_quaternion=d.base_quaternion,
+        joint_positions=d.joint_positions,
+        base_linear_velocity=d.base_linear_velocity,
+        base_angular_velocity=d.base_angular_velocity,
+        joint_velocities=d.joint_velocities,
+        tangential_deformation=d.tangential_deformation,
+        dtype=dtype or d.dtype,
+    )
+
+
+def block_to_odata(model, block: np.ndarray, rep=oracle.VelRepr.Mixed) -> oracle.OracleData:
+    f = st.unpack_state(st.StateLayout.of(model), block)
+    d = oracle.OracleData(
+        f["base_position"], f["base_quaternion"], f["joint_positions"], f["base_linear_velocity"],
+        f["base_angular_velocity"], f["joint_velocities"], f["tangential_deformation"], velocity_representation=rep,
+    )  # fmt: skip
+    return d.update_caches(model)
+
+
+def rel_err(a: np.ndarray, ref: np.ndarray) -> float:
+    """max |a-ref| / max(1, |ref|) -- the tolerance metric used by every parity test."""
+    a, ref = np.asarray(a, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    return float(np.max(np.abs(a - ref) / np.maximum(1.0, np.abs(ref)))) if a.size else 0.0
+
+
+def tol_of(dtype) -> float:
+    return FP64_TOL if np.dtype(dtype) == np.float64 else FP32_TOL
+
+
+def random_inputs(model, N, seed, dtype):
+    rng = np.random.default_rng(seed)
+    n, nL = model.dofs(), model.number_of_links()
+    tau = rng.uniform(-5, 5, size=(N, n)).astype(dtype)
+    f = rng.uniform(-1, 1, size=(N, nL, 6)).astype(dtype)
+    return tau, f
+
+
+def with_params(model, **changes):
+    """Shallow copy of a host model with some model-level fields replaced."""
+    with model.editable(validate=False) as m:
+        for k, v in changes.items():
+            setattr(m, k, v)
+    return m
+
+
+def enable_points(model, idx):
+    kdp = model.kin_dyn_parameters
+    en = np.zeros(kdp.number_of_collidable_points(), dtype=bool)
+    en[list(idx)] = True
+    return with_params(model, kin_dyn_parameters=dataclasses.replace(kdp, contact_enabled=en))
+
+
+def upcast(d: oracle.OracleData) -> oracle.OracleData:
+    """fp64 copy of an oracle state (same values): the truth for fp32 parity checks."""
+    kw = {}
+    for fld in dataclasses.fields(d):
+        v = getattr(d, fld.name)
+        kw[fld.name] = v.astype(np.float64) if isinstance(v, np.ndarray) else v
+    return oracle.OracleData(**kw)

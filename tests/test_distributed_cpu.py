@@ -1,0 +1,52 @@
+"""N>1 path on CPU: world_size-2 ``gloo`` job (127.0.0.1 rendezvous) + host sharding logic."""
+
+import os
+import pathlib
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from jaxsim_amd import distributed
+
+HERE = pathlib.Path(__file__).resolve().parent
+
+
+def test_shard_bounds_cover_the_batch():
+    for n, w in ((8192, 8), (1024, 1), (10, 3), (7, 8)):
+        cuts = [distributed.shard_bounds(n, r, w) for r in range(w)]
+        assert cuts[0][0] == 0 and cuts[-1][1] == n
+        assert all(cuts[i][1] == cuts[i + 1][0] for i in range(w - 1))
+        sizes = [hi - lo for lo, hi in cuts]
+        assert max(sizes) - min(sizes) <= 1
+    assert distributed.shard_bounds(8192, 3, 8) == (3072, 4096)
+    with pytest.raises(ValueError):
+        distributed.shard_bounds(8, 8, 8)
+
+
+def test_concat_shards_inverts_sharding():
+    blk = np.arange(5 * 12, dtype=np.float32).reshape(5, 12)
+    shards = np.stack([distributed.shard_block(blk, r, 3) for r in range(3)], axis=0)
+    np.testing.assert_array_equal(distributed.concat_shards(shards), blk)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_world_size_2_gloo_shard_step_gather():
+    import emul_binding
+
+    emul_binding.build()  # build once, before the two ranks race for it
+    cmd = [
+        sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(HERE / "dist_worker.py"),
+    ]  # fmt: skip
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    assert "DIST_OK" in res.stdout

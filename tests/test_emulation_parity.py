@@ -1,0 +1,187 @@
+"""CPU parity: the kernel core (jaxsim_amd/csrc/jxs_core.h), compiled against the host
+lockstep lane backend, versus the oracle.  Same tables, same shuffles, same level loops as
+the gfx950 kernels -- only the lane backend differs -- so this is the -m "not gpu" check of
+the kernel *logic*.  Tolerances (helpers.py): fp64 1e-10, fp32 5e-4 relative to the fp64 oracle on the same inputs.
+"""
+
+import numpy as np
+import pytest
+
+import emul_binding as eb
+import helpers
+import oracle
+from oracle import VelRepr
+
+REPR_CODE = {VelRepr.Inertial: 0, VelRepr.Body: 1, VelRepr.Mixed: 2}
+ALL = ["box", "sphere", "pendulum", "double_pendulum", "cartpole", "chain5", "chain9f", "anymal", "icub", "icub16"]
+
+
+@pytest.mark.parametrize("name", ALL)
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_step_matches_oracle(models, name, dtype):
+    model = models(name)
+    N = 6
+    d = models.random_data(name, N, seed=4, dtype=dtype)
+    tau, f = helpers.random_inputs(model, N, 5, dtype)
+    ref = oracle.step(model, helpers.upcast(d), link_forces=f.astype(np.float64), joint_force_references=tau.astype(np.float64))
+    out = eb.run(model, eb.MODE_STEP, helpers.odata_to_block(model, d), tau=tau.T,
+                 link_forces=f.reshape(N, -1).T, force_repr=REPR_CODE[d.velocity_representation])  # fmt: skip
+    assert out.dtype == dtype
+    assert helpers.rel_err(out, helpers.odata_to_block(model, ref)) < helpers.tol_of(dtype)
+
+
+def test_fp32_not_worse_than_reference_formulation(models):
+    """fp32: distance to the fp64 truth of (a) our frame-C kernel and (b) the reference's own
+    body-frame formulation evaluated in fp32 (the oracle run with float32 arrays)."""
+    ours, theirs = [], []
+    for name in ("anymal", "icub", "chain9f"):
+        model = models(name)
+        N = 16
+        d = models.random_data(name, N, seed=4, dtype=np.float32)
+        truth = helpers.odata_to_block(model, oracle.step(model, helpers.upcast(d)))
+        ours.append(helpers.rel_err(eb.run(model, eb.MODE_STEP, helpers.odata_to_block(model, d)), truth))
+        theirs.append(helpers.rel_err(helpers.odata_to_block(model, oracle.step(model, d)), truth))
+    assert max(ours) < helpers.FP32_TOL
+    assert max(ours) <= 1.5 * max(theirs) + 1e-5, (ours, theirs)
+
+
+def test_contacts_are_exercised(models):
+    """The contact configurations used above really have points in and out of contact."""
+    for name in ("box", "anymal", "icub"):
+        d = models.random_data(name, 32, seed=4)
+        p, _ = oracle.collidable_points_pos_vel(models(name), link_transforms=d.link_transforms, link_velocities=d.link_velocities)
+        assert (p[..., 2] < 0).any() and (p[..., 2] > 0).any()
+
+
+@pytest.mark.parametrize("name", ["chain9f", "icub"])
+@pytest.mark.parametrize("rep", [VelRepr.Inertial, VelRepr.Body, VelRepr.Mixed])
+def test_step_link_force_representations(models, name, rep):
+    model = models(name)
+    N = 4
+    d = models.random_data(name, N, seed=8, rep=rep)
+    tau, f = helpers.random_inputs(model, N, 9, np.float64)
+    ref = oracle.step(model, d, link_forces=f, joint_force_references=tau)
+    out = eb.run(model, eb.MODE_STEP, helpers.odata_to_block(model, d), tau=tau.T,
+                 link_forces=f.reshape(N, -1).T, force_repr=REPR_CODE[rep])  # fmt: skip
+    assert helpers.rel_err(out, helpers.odata_to_block(model, ref)) < helpers.FP64_TOL
+
+
+@pytest.mark.parametrize("name", ["cartpole", "anymal", "icub"])
+def test_multi_step_rollout(models, name):
+    model = models(name)
+    N = 3
+    d = models.random_data(name, N, seed=12)
+    blk = helpers.odata_to_block(model, d)
+    for _ in range(25):
+        d = oracle.step(model, d)
+        blk = eb.run(model, eb.MODE_STEP, blk)
+    assert helpers.rel_err(blk, helpers.odata_to_block(model, d)) < 1e-8
+
+
+def test_null_inputs_equal_zero_inputs(models):
+    model = models("icub")
+    d = models.random_data("icub", 3, seed=1)
+    blk = helpers.odata_to_block(model, d)
+    a = eb.run(model, eb.MODE_STEP, blk)
+    b = eb.run(model, eb.MODE_STEP, blk, tau=np.zeros((model.dofs(), 3)), link_forces=np.zeros((24 * 6, 3)), force_repr=2)
+    np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("name", ["double_pendulum", "cartpole", "chain5", "chain9f", "anymal", "icub"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_forward_dynamics_matches_oracle(models, name, dtype):
+    model = models(name)
+    N = 5
+    d = models.random_data(name, N, seed=6, dtype=dtype, rep=VelRepr.Inertial)
+    tau, f = helpers.random_inputs(model, N, 7, dtype)
+    vd, sdd = oracle.forward_dynamics_aba(model, helpers.upcast(d), joint_forces=tau.astype(np.float64), link_forces=f.astype(np.float64))
+    out = eb.run(model, eb.MODE_FD, helpers.odata_to_block(model, d), tau=tau.T, link_forces=f.reshape(N, -1).T, force_repr=0)
+    assert helpers.rel_err(out.T, np.concatenate([vd, sdd], -1)) < helpers.tol_of(dtype)
+
+
+@pytest.mark.parametrize("name", ["double_pendulum", "cartpole", "chain5", "chain9f", "anymal", "icub"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_inverse_dynamics_matches_oracle(models, name, dtype):
+    model = models(name)
+    N = 5
+    d = models.random_data(name, N, seed=16, dtype=dtype, rep=VelRepr.Inertial)
+    _, f = helpers.random_inputs(model, N, 17, dtype)
+    rng = np.random.default_rng(3)
+    acc = rng.uniform(-2, 2, size=(N, 6 + model.dofs())).astype(dtype)
+    a64 = acc.astype(np.float64)
+    fB, tau = oracle.inverse_dynamics(model, helpers.upcast(d), joint_accelerations=a64[:, 6:], base_acceleration=a64[:, :6],
+                                      link_forces=f.astype(np.float64))
+    out = eb.run(model, eb.MODE_ID, helpers.odata_to_block(model, d), link_forces=f.reshape(N, -1).T, force_repr=0, in_acc=acc.T)
+    ref = np.concatenate([fB, tau], -1)
+    if not model.floating_base():
+        ref[:, :6] = out.T[:, :6]  # base wrench of a fixed base is not part of the contract (always 0 in the reference)
+        assert np.all(out.T[:, :6] == 0)
+    # forces scale with the inertia: compare relative to the largest entry
+    scale = max(1.0, float(np.abs(ref).max()))
+    assert float(np.abs(out.T - ref).max()) / scale < helpers.tol_of(dtype)
+
+
+def test_bias_forces_null_acceleration(models):
+    model = models("icub")
+    d = models.random_data("icub", 4, seed=21, rep=VelRepr.Inertial)
+    h = oracle.free_floating_bias_forces(model, d)
+    out = eb.run(model, eb.MODE_ID, helpers.odata_to_block(model, d))
+    assert helpers.rel_err(out.T, h) < helpers.FP64_TOL
+
+
+@pytest.mark.parametrize("name", ["pendulum", "cartpole", "chain5", "chain9f", "icub"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_cached_kinematics_match_oracle(models, name, dtype):
+    model = models(name)
+    N, nL = 4, model.number_of_links()
+    d = models.random_data(name, N, seed=31, dtype=dtype)
+    H, V = eb.run(model, eb.MODE_KIN, helpers.odata_to_block(model, d))
+    H = H.T.reshape(N, nL, 3, 4)
+    d = helpers.upcast(d).update_caches(model)
+    assert helpers.rel_err(H, d.link_transforms[:, :, :3, :]) < helpers.tol_of(dtype)
+    assert helpers.rel_err(V.T.reshape(N, nL, 6), d.link_velocities) < helpers.tol_of(dtype)
+
+
+def test_far_from_origin_is_well_conditioned(models):
+    """Frame C is centred on the base: a robot 1 km from the world origin loses no accuracy
+    in fp32 beyond what its stored inertial-fixed velocity already carries."""
+    model = models("icub")
+    N = 4
+    d64 = models.random_data("icub", N, seed=41, dtype=np.float64, in_contact=False)
+    d64.base_position[:, 0] += 1000.0
+    d64.base_linear_velocity[:] = 0
+    d64.base_angular_velocity[:] = 0
+    d64 = d64.update_caches(model)
+    ref = oracle.forward_dynamics_aba(model, oracle.OracleData(**{**d64.__dict__, "velocity_representation": VelRepr.Inertial}))
+    blk32 = helpers.odata_to_block(model, d64, np.float32)
+    out = eb.run(model, eb.MODE_FD, blk32)
+    assert helpers.rel_err(out.T[:, 6:], ref[1]) < 5e-3  # joint accelerations stay accurate
+
+
+def test_disabled_points_keep_their_state(models):
+    model = helpers.enable_points(models("box"), [0, 1, 2, 3])
+    d = models.random_data("box", 4, seed=3)
+    ref = oracle.step(model, d)
+    out = eb.run(model, eb.MODE_STEP, helpers.odata_to_block(model, d))
+    assert helpers.rel_err(out, helpers.odata_to_block(model, ref)) < helpers.FP64_TOL
+    L = eb.layout(model)
+    np.testing.assert_array_equal(out[L.row_m + 12 :], helpers.odata_to_block(model, d)[L.row_m + 12 :])
+
+
+def test_non_default_contact_exponents(models):
+    import jaxsim_amd as ja
+
+    model = helpers.with_params(models("anymal"), contact_params=ja.SoftContactsParams.build(K=2e5, D=800, mu=0.8, p=0.7, q=0.4))
+    d = models.random_data("anymal", 6, seed=13)
+    ref = oracle.step(model, d)
+    out = eb.run(model, eb.MODE_STEP, helpers.odata_to_block(model, d))
+    assert helpers.rel_err(out, helpers.odata_to_block(model, ref)) < helpers.FP64_TOL
+
+
+def test_unsupported_models_are_rejected(models):
+    import jaxsim_amd as ja
+    from jaxsim_amd import robots
+
+    big = ja.JaxSimModel.build_from_model_description(robots.chain_urdf(70, fixed_base=True, seed=0))
+    with pytest.raises(RuntimeError, match="64 links"):
+        eb.layout(big)

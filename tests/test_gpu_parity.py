@@ -1,0 +1,244 @@
+"""GPU parity tests (``-m gpu``): the gfx950 kernels, called through the C-ABI via the Python
+mirror of the reference API, against the oracle on the same seeded inputs.  Tolerances are
+stated in ``helpers.py`` (fp64 1e-10, fp32 5e-4, relative to the fp64 oracle)."""
+
+import dataclasses
+
+import numpy as np
+import pytest
+
+import helpers
+import jaxsim_amd as ja
+import jaxsim_amd.api as js
+import oracle
+from jaxsim_amd import runtime
+from oracle import VelRepr
+
+pytestmark = pytest.mark.gpu
+
+REP = {VelRepr.Inertial: ja.VelRepr.Inertial, VelRepr.Body: ja.VelRepr.Body, VelRepr.Mixed: ja.VelRepr.Mixed}
+ALL = ["box", "sphere", "pendulum", "double_pendulum", "cartpole", "chain5", "chain9f", "anymal", "icub", "icub16"]
+
+
+def to_gpu(model, d: oracle.OracleData) -> js.data.JaxSimModelData:
+    return js.data.JaxSimModelData.from_state_block(model, helpers.odata_to_block(model, d), REP[d.velocity_representation])
+
+
+def test_native_library_is_the_one_in_tree():
+    from jaxsim_amd import _lib
+
+    assert runtime.device_count() >= 1
+    assert _lib.LIB_PATH.exists() and "jaxsim_amd/csrc/libjaxsim_amd.so" in str(_lib.LIB_PATH)
+    maps = open("/proc/self/maps").read()
+    _lib.load()
+    maps = open("/proc/self/maps").read()
+    assert "libjaxsim_amd.so" in maps
+
+
+@pytest.mark.parametrize("name", ALL)
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_step_matches_oracle(models, name, dtype):
+    model = models(name)
+    N = 70  # not a multiple of the environments per wave: exercises the tail masking
+    d = models.random_data(name, N, seed=4, dtype=dtype)
+    tau, f = helpers.random_inputs(model, N, 5, dtype)
+    ref = oracle.step(model, helpers.upcast(d), link_forces=f.astype(np.float64), joint_force_references=tau.astype(np.float64))
+    out = js.model.step(model, to_gpu(model, d), link_forces=f, joint_force_references=tau)
+    assert out.dtype == dtype
+    assert helpers.rel_err(out.state_block(), helpers.odata_to_block(model, ref)) < helpers.tol_of(dtype)
+
+
+@pytest.mark.parametrize("rep", [VelRepr.Inertial, VelRepr.Body, VelRepr.Mixed])
+def test_step_link_force_representations(models, rep):
+    model = models("icub")
+    N = 33
+    d = models.random_data("icub", N, seed=8, rep=rep)
+    tau, f = helpers.random_inputs(model, N, 9, np.float64)
+    ref = oracle.step(model, d, link_forces=f, joint_force_references=tau)
+    out = js.model.step(model, to_gpu(model, d), link_forces=f, joint_force_references=tau)
+    assert helpers.rel_err(out.state_block(), helpers.odata_to_block(model, ref)) < helpers.FP64_TOL
+
+
+def test_step_is_functional_and_inplace_variant_agrees(models):
+    model = models("icub")
+    d = models.random_data("icub", 16, seed=2, dtype=np.float32)
+    g = to_gpu(model, d)
+    before = g.state_block()
+    out = js.model.step(model, g)
+    np.testing.assert_array_equal(g.state_block(), before)  # input untouched
+    g2 = to_gpu(model, d)
+    out2 = js.model.step(model, g2, inplace=True)
+    np.testing.assert_array_equal(out.state_block(), out2.state_block())
+    np.testing.assert_array_equal(g2.state_block(), out2.state_block())
+
+
+@pytest.mark.parametrize("name", ["cartpole", "anymal", "icub"])
+def test_rollout_matches_oracle(models, name):
+    model = models(name)
+    d = models.random_data(name, 8, seed=12)
+    out = js.model.rollout(model, to_gpu(model, d), 25)
+    for _ in range(25):
+        d = oracle.step(model, d)
+    assert helpers.rel_err(out.state_block(), helpers.odata_to_block(model, d)) < 1e-8
+
+
+# reference known answer on the GPU: tests/test_simulations.py:194-242
+@pytest.mark.parametrize("dtype,atol", [(np.float64, 1e-9), (np.float32, 2e-5)])
+def test_box_settles_on_soft_ground_gpu(models, dtype, atol):
+    model = models("box")
+    params = js.contact.estimate_good_contact_parameters(
+        model, number_of_active_collidable_points_steady_state=4, static_friction_coefficient=1.0,
+        damping_ratio=1.0, max_penetration=0.001,
+    )  # fmt: skip
+    model = helpers.enable_points(helpers.with_params(model, contact_params=params), [0, 1, 2, 3])
+    data = js.data.JaxSimModelData.build(model, base_position=[0.0, 0.0, 0.2], velocity_representation=ja.VelRepr.Inertial, dtype=dtype)
+    data = js.model.rollout(model, data, 1000)
+    p = data.base_position
+    np.testing.assert_allclose(p[:2], 0.0, atol=atol)
+    np.testing.assert_allclose(p[2] + 0.001, 0.05, rtol=1e-7 if dtype == np.float64 else 1e-4, atol=atol)
+
+
+@pytest.mark.parametrize("name", ["double_pendulum", "cartpole", "chain5", "chain9f", "anymal", "icub"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("rep", [VelRepr.Inertial, VelRepr.Mixed, VelRepr.Body])
+def test_forward_dynamics_matches_oracle(models, name, dtype, rep):
+    model = models(name)
+    N = 21
+    d = models.random_data(name, N, seed=6, dtype=dtype, rep=rep)
+    tau, f = helpers.random_inputs(model, N, 7, dtype)
+    vd, sdd = oracle.forward_dynamics_aba(model, helpers.upcast(d), joint_forces=tau.astype(np.float64), link_forces=f.astype(np.float64))
+    gvd, gsdd = js.model.forward_dynamics_aba(model, to_gpu(model, d), joint_forces=tau, link_forces=f)
+    tol = helpers.tol_of(dtype)
+    assert helpers.rel_err(gsdd, sdd) < tol and helpers.rel_err(gvd, vd) < tol
+
+
+@pytest.mark.parametrize("name", ["cartpole", "chain9f", "anymal", "icub"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("rep", [VelRepr.Inertial, VelRepr.Mixed, VelRepr.Body])
+def test_inverse_dynamics_matches_oracle(models, name, dtype, rep):
+    model = models(name)
+    N = 21
+    d = models.random_data(name, N, seed=16, dtype=dtype, rep=rep)
+    _, f = helpers.random_inputs(model, N, 17, dtype)
+    acc = np.random.default_rng(3).uniform(-2, 2, size=(N, 6 + model.dofs())).astype(dtype)
+    a64 = acc.astype(np.float64)
+    fB, tau = oracle.inverse_dynamics(model, helpers.upcast(d), joint_accelerations=a64[:, 6:], base_acceleration=a64[:, :6],
+                                      link_forces=f.astype(np.float64))  # fmt: skip
+    gfB, gtau = js.model.inverse_dynamics(model, to_gpu(model, d), joint_accelerations=acc[:, 6:], base_acceleration=acc[:, :6], link_forces=f)
+    ref = np.concatenate([fB if model.floating_base() else np.zeros_like(fB), tau], -1)
+    got = np.concatenate([gfB if model.floating_base() else np.zeros_like(gfB), gtau], -1)
+    scale = max(1.0, float(np.abs(ref).max()))
+    assert float(np.abs(got - ref).max()) / scale < helpers.tol_of(dtype)
+
+
+def test_bias_and_gravity_forces(models):
+    model = models("anymal")
+    d = models.random_data("anymal", 9, seed=21)
+    g = to_gpu(model, d)
+    assert helpers.rel_err(js.model.free_floating_bias_forces(model, g), oracle.free_floating_bias_forces(model, d)) < 1e-9
+    assert helpers.rel_err(js.model.free_floating_gravity_forces(model, g), oracle.free_floating_gravity_forces(model, d)) < 1e-9
+
+
+@pytest.mark.parametrize("name", ["pendulum", "cartpole", "chain5", "chain9f", "icub"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_cached_kinematics_match_oracle(models, name, dtype):
+    model = models(name)
+    d = models.random_data(name, 10, seed=31, dtype=dtype)
+    g = to_gpu(model, d)
+    t = helpers.upcast(d).update_caches(model)
+    assert helpers.rel_err(g._link_transforms, t.link_transforms) < helpers.tol_of(dtype)
+    assert helpers.rel_err(g._link_velocities, t.link_velocities) < helpers.tol_of(dtype)
+
+
+def test_data_build_and_properties(models):
+    model = models("icub")
+    d = models.random_data("icub", 5, seed=3)
+    W_v = d.base_velocity(VelRepr.Mixed)
+    g = js.data.JaxSimModelData.build(
+        model, base_position=d.base_position, base_quaternion=d.base_quaternion, joint_positions=d.joint_positions,
+        base_linear_velocity=W_v[:, :3], base_angular_velocity=W_v[:, 3:], joint_velocities=d.joint_velocities,
+        velocity_representation=ja.VelRepr.Mixed,
+    )  # fmt: skip
+    np.testing.assert_allclose(g._base_linear_velocity, d.base_linear_velocity, atol=1e-12)  # stored inertial-fixed
+    np.testing.assert_allclose(g.base_velocity, W_v, atol=1e-12)
+    np.testing.assert_allclose(g.generalized_velocity[:, 6:], d.joint_velocities)
+    with g.switch_velocity_representation(ja.VelRepr.Body):
+        np.testing.assert_allclose(g.base_velocity, d.base_velocity(VelRepr.Body), atol=1e-12)
+    r = g.replace(model, base_quaternion=2 * d.base_quaternion)
+    np.testing.assert_allclose(r.base_quaternion, d.base_quaternion, atol=1e-12)  # re-normalised (data.py:434-440)
+    single = js.data.JaxSimModelData.build(model, base_position=[0, 0, 1.0])
+    assert single.base_position.shape == (3,) and single.joint_positions.shape == (23,)
+    with pytest.raises(ValueError):
+        js.data.JaxSimModelData.build(model, joint_positions=np.zeros(5))
+
+
+# ---- BASELINE.json full sizes: size-independent properties ---------------------------------------
+
+
+def test_full_size_round_trip_fd_id(models):
+    """N = 1024, iCub, fp32: RNEA(ABA(tau, f)) = tau and zero base wrench (tests/test_api_model.py:551-577)."""
+    model = models("icub")
+    N = 1024
+    d = models.random_data("icub", N, seed=77, dtype=np.float32, rep=VelRepr.Inertial)
+    tau, f = helpers.random_inputs(model, N, 78, np.float32)
+    g = to_gpu(model, d)
+    vd, sdd = js.model.forward_dynamics_aba(model, g, joint_forces=tau, link_forces=f)
+    fB, tau_id = js.model.inverse_dynamics(model, g, joint_accelerations=sdd, base_acceleration=vd, link_forces=f)
+    scale = float(np.abs(tau).max())
+    assert float(np.abs(tau_id - tau).max()) / scale < 2e-3
+    assert float(np.abs(fB).max()) / max(scale, float(np.abs(f).max())) < 5e-3
+
+
+def test_full_size_batch_independence(models):
+    """Environments never interact: stepping 1024 envs equals stepping two halves, bitwise."""
+    model = models("icub")
+    d = models.random_data("icub", 1024, seed=5, dtype=np.float32)
+    blk = helpers.odata_to_block(model, d)
+    full = js.model.rollout(model, js.data.JaxSimModelData.from_state_block(model, blk), 5).state_block()
+    a = js.model.rollout(model, js.data.JaxSimModelData.from_state_block(model, np.ascontiguousarray(blk[:, :512])), 5).state_block()
+    b = js.model.rollout(model, js.data.JaxSimModelData.from_state_block(model, np.ascontiguousarray(blk[:, 512:])), 5).state_block()
+    np.testing.assert_array_equal(full, np.concatenate([a, b], axis=1))
+
+
+def test_full_size_step_matches_oracle_and_keeps_unit_quaternion(models):
+    model = models("icub")
+    N = 1024
+    d = models.random_data("icub", N, seed=9, dtype=np.float32)
+    ref = oracle.step(model, helpers.upcast(d))
+    out = js.model.step(model, to_gpu(model, d))
+    assert helpers.rel_err(out.state_block(), helpers.odata_to_block(model, ref)) < helpers.FP32_TOL
+    q = js.model.rollout(model, out, 50).base_quaternion
+    np.testing.assert_allclose(np.linalg.norm(q, axis=-1), 1.0, atol=1e-6)
+
+
+def test_full_size_airborne_momentum_and_free_fall(models):
+    """No contact, no actuation, no joint friction: the CoM follows the free-fall parabola
+    and the angular momentum about the CoM is conserved (checked through the oracle's CoM)."""
+    model = models("icub")
+    N = 1024
+    d = oracle.random_model_data(model, batch_size=N, seed=13, dtype=np.float64, base_pos_bounds=((-1, -1, 2.0), (1, 1, 3.0)))
+    g = to_gpu(model, d)
+    com0 = oracle.com_position(model, d)
+    k = 100
+    out = js.model.rollout(model, g, k)
+    dk = helpers.block_to_odata(model, out.state_block())
+    comk = oracle.com_position(model, dk)
+    # the CoM velocity at t0 from a one-step finite difference of the oracle-free GPU rollout
+    d1 = helpers.block_to_odata(model, js.model.rollout(model, g, 1).state_block())
+    v0 = (oracle.com_position(model, d1) - com0) / model.time_step
+    t = k * model.time_step
+    expected = com0 + v0 * t
+    expected[:, 2] += 0.5 * model.gravity * (t * t - t * model.time_step)  # semi-implicit Euler parabola after the 1st step
+    np.testing.assert_allclose(comk, expected, atol=2e-4)
+
+
+def test_device_tables_follow_model_edits(models):
+    model = models("cartpole")
+    d = models.random_data("cartpole", 4, seed=1)
+    g = to_gpu(model, d)
+    a = js.model.step(model, g).state_block()
+    m2 = helpers.with_params(model, time_step=2e-3)
+    b = js.model.step(m2, to_gpu(m2, d)).state_block()
+    ref = oracle.step(m2, d)
+    assert not np.array_equal(a, b)
+    assert helpers.rel_err(b, helpers.odata_to_block(m2, ref)) < helpers.FP64_TOL

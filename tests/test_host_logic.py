@@ -1,0 +1,163 @@
+"""Host-side logic: URDF reader rules, static tables, state layout, boundary conversions."""
+
+import numpy as np
+import pytest
+
+import helpers
+import jaxsim_amd as ja
+import oracle
+from jaxsim_amd import _hostmath as hm
+from jaxsim_amd import data as jdata
+from jaxsim_amd import robots
+from jaxsim_amd import state as st
+from jaxsim_amd.parsers import urdf
+
+
+def test_bfs_indexing_children_sorted_by_name(models):
+    kdp = models("icub").kin_dyn_parameters
+    # reference rule: BFS from the base, children sorted by name (kinematic_graph.py:133-134,701)
+    assert kdp.link_names[:4] == ("root_link", "l_hip_1", "r_hip_1", "torso_1")
+    assert kdp.parent_array[0] == -1 and all(kdp.parent_array[i] < i for i in range(1, 24))
+    assert kdp.joint_names[0] == "l_hip_pitch"  # joint index = child link index
+    assert kdp.number_of_links() == 24 and kdp.number_of_joints() == 23
+    assert kdp.number_of_collidable_points() == 32
+    assert kdp.tree_depths().max() == 7
+    assert models("icub16").kin_dyn_parameters.number_of_collidable_points() == 16
+
+
+def test_cartpole_tables(models):
+    m = models("cartpole")
+    kdp = m.kin_dyn_parameters
+    assert not m.floating_base()
+    assert kdp.link_names == ("rail", "cart", "pole")
+    assert kdp.frame_names == ("rail_frame", "cart_frame") or set(kdp.frame_names) == {"rail_frame", "cart_frame"}
+    assert list(kdp.joint_types) == [2, 1]  # prismatic-y then continuous-x
+    np.testing.assert_allclose(kdp.motion_subspaces[1], [0, 1, 0, 0, 0, 0])
+    np.testing.assert_allclose(kdp.motion_subspaces[2], [0, 0, 0, 1, 0, 0])
+    np.testing.assert_allclose(kdp.lambda_H_pre[1][:3, 3], [0, 0, 1.2])
+    assert kdp.position_limits_min[0] == -2.4 and kdp.position_limits_max[1] == np.finfo(float).max
+    np.testing.assert_allclose(m.total_mass(), 6.5)
+    assert kdp.number_of_collidable_points() == 0  # cylinders are skipped, config C2 has no boxes
+
+
+def test_fixed_joint_lumping_conserves_mass_and_inertia():
+    # child rigidly attached 0.5 m above the parent: lumped inertia = parallel-axis sum
+    u = (
+        '<robot name="l"><link name="a"><inertial><origin xyz="0 0 0"/><mass value="2"/>'
+        '<inertia ixx="0.1" iyy="0.2" izz="0.3" ixy="0" ixz="0" iyz="0"/></inertial></link>'
+        '<link name="b"><inertial><origin xyz="0 0 0"/><mass value="3"/>'
+        '<inertia ixx="0.01" iyy="0.01" izz="0.01" ixy="0" ixz="0" iyz="0"/></inertial>'
+        '<collision><origin xyz="0 0 0"/><geometry><box size="0.2 0.2 0.2"/></geometry></collision></link>'
+        '<joint name="j" type="fixed"><origin xyz="0 0 0.5" rpy="0 0 1.5707963267948966"/><parent link="a"/><child link="b"/></joint></robot>'
+    )
+    d = urdf.parse_urdf(u)
+    assert [l.name for l in d.links] == ["a"] and [f.name for f in d.frames] == ["b"]
+    m, c, I = hm.inertia_to_params(d.links[0].inertia)
+    assert m == pytest.approx(5.0)
+    np.testing.assert_allclose(c, [0, 0, 0.3], atol=1e-12)
+    # inertia about the combined CoM
+    Ixx = 0.1 + 2 * 0.3**2 + 0.01 + 3 * 0.2**2
+    np.testing.assert_allclose(np.diag(I), [Ixx, 0.2 + 2 * 0.09 + 0.01 + 3 * 0.04, 0.31], atol=1e-12)
+    # the collision box moved with the lumped link: z in {0.4, 0.6}
+    z = sorted({round(float(p.position[2]), 6) for p in d.collidable_points})
+    assert z == [0.4, 0.6] and len(d.collidable_points) == 8
+
+
+def test_box_points_order_and_sphere_count(models):
+    pts = models("box").kin_dyn_parameters.contact_point
+    assert pts.shape == (8, 3)
+    np.testing.assert_allclose(pts[:4, 2], -0.05)  # bottom corners first (rod/utils.py:116-151)
+    np.testing.assert_allclose(pts[4:, 2], 0.05)
+    np.testing.assert_allclose(pts[0], [-0.15, -0.1, -0.05])
+    sp = models("sphere").kin_dyn_parameters.contact_point
+    assert sp.shape == (50, 3)
+    np.testing.assert_allclose(np.linalg.norm(sp, axis=1), 0.1)
+
+
+def test_link_inertia_round_trip(models):
+    kdp = models("chain9f").kin_dyn_parameters
+    for i in range(kdp.number_of_links()):
+        M = hm.inertia_to_sixd(kdp.link_mass[i], kdp.link_com[i], kdp.link_inertia_com[i])
+        np.testing.assert_allclose(M, kdp.link_spatial_inertia[i], atol=1e-12)
+        assert np.all(np.linalg.eigvalsh(M) > 0)
+
+
+def test_fixed_base_world_joint_offset_goes_to_base_pose(models):
+    kdp = models("pendulum").kin_dyn_parameters
+    np.testing.assert_allclose(kdp.suc_H_i[0][:3, 3], [0, 0, 1.0])
+    assert not models("pendulum").floating_base()
+
+
+def test_gravity_sign_and_defaults(models):
+    m = models("icub")
+    assert m.gravity == pytest.approx(-9.81) and m.time_step == pytest.approx(1e-3)
+    assert (m.contact_params.K, m.contact_params.D, m.contact_params.mu) == (1e6, 2000.0, 0.5)
+    assert (m.actuation_params.torque_max, m.actuation_params.omega_th, m.actuation_params.omega_max) == (3000.0, 30.0, 100.0)
+    with m.editable(validate=False) as m2:
+        m2.time_step = 5e-4
+    assert m.time_step == pytest.approx(1e-3) and m2.time_step == pytest.approx(5e-4)
+
+
+def test_state_layout_and_pack_round_trip(models):
+    m = models("icub")
+    L = st.StateLayout.of(m)
+    assert L.n_rows == 155  # 13 + 2*23 + 3*32
+    assert (L.row_s, L.row_vlin, L.row_sd, L.row_m) == (7, 30, 36, 59)
+    d = models.random_data("icub", 5, seed=1)
+    blk = helpers.odata_to_block(m, d)
+    assert blk.shape == (155, 5) and blk.flags.c_contiguous
+    f = st.unpack_state(L, blk)
+    np.testing.assert_array_equal(f["joint_velocities"], d.joint_velocities)
+    np.testing.assert_array_equal(f["tangential_deformation"], d.tangential_deformation)
+    np.testing.assert_array_equal(f["base_quaternion"], d.base_quaternion)
+
+
+@pytest.mark.parametrize("rep_o,rep_p", [(oracle.VelRepr.Body, ja.VelRepr.Body), (oracle.VelRepr.Mixed, ja.VelRepr.Mixed),
+                                         (oracle.VelRepr.Inertial, ja.VelRepr.Inertial)])  # fmt: skip
+@pytest.mark.parametrize("is_force", [False, True])
+def test_boundary_conversions_match_reference_formulas(rep_o, rep_p, is_force):
+    rng = np.random.default_rng(0)
+    N = 7
+    q = rng.normal(size=(N, 4))
+    q /= np.linalg.norm(q, axis=-1, keepdims=True)
+    H = np.zeros((N, 4, 4))
+    H[:, :3, :3] = hm.quaternion_to_rotation(q)
+    H[:, :3, 3] = rng.normal(size=(N, 3))
+    H[:, 3, 3] = 1
+    x = rng.normal(size=(N, 6))
+    np.testing.assert_allclose(jdata._other_to_inertial(x, rep_p, H, is_force),
+                               oracle.other_representation_to_inertial(x, rep_o, H, is_force=is_force), atol=1e-12)  # fmt: skip
+    np.testing.assert_allclose(jdata._inertial_to_other(x, rep_p, H, is_force),
+                               oracle.inertial_to_other_representation(x, rep_o, H, is_force=is_force), atol=1e-12)  # fmt: skip
+    back = jdata._inertial_to_other(jdata._other_to_inertial(x, rep_p, H, is_force), rep_p, H, is_force)
+    np.testing.assert_allclose(back, x, atol=1e-12)
+
+
+def test_estimate_good_contact_parameters_matches_oracle(models):
+    import jaxsim_amd.api as js
+
+    for name, nc in (("box", 4), ("icub", 16), ("anymal", 4)):
+        m = models(name)
+        p = js.contact.estimate_good_contact_parameters(m, number_of_active_collidable_points_steady_state=nc)
+        o = oracle.estimate_good_contact_parameters(m, number_of_active_collidable_points_steady_state=nc)
+        assert (p.K, p.D, p.mu) == pytest.approx((o["K"], o["D"], o["mu"]))
+
+
+def test_quaternion_helpers():
+    rpy = np.array([[0.3, -0.2, 1.1]])
+    q = hm.rpy_to_quaternion(rpy)
+    Rx = hm.rpy_to_rotation([0.3, 0, 0])
+    Ry = hm.rpy_to_rotation([0, -0.2, 0])
+    Rz = hm.rpy_to_rotation([0, 0, 1.1])
+    np.testing.assert_allclose(hm.quaternion_to_rotation(q)[0], Rx @ Ry @ Rz, atol=1e-12)  # intrinsic XYZ
+    np.testing.assert_allclose(oracle.refmath.so3_from_quaternion(2.5 * q)[0], Rx @ Ry @ Rz, atol=1e-12)
+
+
+def test_product_never_imports_the_oracle():
+    import pathlib
+    import re
+
+    root = pathlib.Path(ja.__file__).resolve().parent
+    for py in root.rglob("*.py"):
+        src = py.read_text()
+        assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), py
