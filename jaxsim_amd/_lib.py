@@ -201,7 +201,8 @@ def load(path: os.PathLike | None = None):
     global _lib, EXPORTED_SYMBOLS
     if _lib is not None and path is None:
         return _lib
-    p = pathlib.Path(path) if path is not None else LIB_PATH
+    override = os.environ.get("JAXSIM_AMD_LIB")  # developer knob: A/B-test another build of the library
+    p = pathlib.Path(path) if path is not None else (pathlib.Path(override) if override else LIB_PATH)
     if not p.exists():
         raise JaxsimAmdError(
             f"HIP extension not built: {p} is missing. Run `python -c 'import __graft_entry__ as g; g.build()'` "

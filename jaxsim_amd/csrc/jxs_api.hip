@@ -22,6 +22,7 @@
 namespace {
 
 thread_local std::string g_err;
+long long* g_dbg = nullptr;  // developer profiling build only (jxs_debug_set_stamp_buffer)
 
 int fail(int code, const std::string& msg) {
   g_err = msg;
@@ -158,7 +159,7 @@ int run_typed(jxs_model* model, int mode, const void* state_in, void* state_out,
   jxs::KArgs<T> a = mt->args(N);
   a.state_in = static_cast<const T*>(state_in);
   a.state_out = static_cast<T*>(state_out);
-  a.tau = static_cast<const T*>(tau);
+  a.tau = (mt->pk.P.n > 0) ? static_cast<const T*>(tau) : nullptr;  // no joints: nothing to read
   a.link_f = static_cast<const T*>(link_f);
   a.force_repr = force_repr;
   a.in_a = static_cast<const T*>(in_a);
@@ -169,6 +170,7 @@ int run_typed(jxs_model* model, int mode, const void* state_in, void* state_out,
     // rows of disabled collidable points are not touched by the kernel: carry them over
     JXS_HIP(hipMemcpyAsync(state_out, state_in, sizeof(T) * (size_t)mt->pk.P.n_rows * N, hipMemcpyDeviceToDevice, s));
   }
+  a.dbg = g_dbg;
   for (int it = 0; it < repeat; ++it) {
     hipError_t e = launch_mode<T>(mode, mt->pk.G, mt->pk.P, a, s);
     if (e != hipSuccess) return hip_fail(e, "kernel launch");
@@ -226,6 +228,12 @@ int rccl_fail(ncclResult_t r, const char* what) {
 }  // namespace
 
 extern "C" {
+
+// Not part of the public ABI: phase-stamp buffer of the -DJXS_PHASE_TIMING developer build.
+int jxs_debug_set_stamp_buffer(void* dptr) {
+  g_dbg = static_cast<long long*>(dptr);
+  return JXS_OK;
+}
 
 const char* jxs_last_error(void) { return g_err.c_str(); }
 

@@ -65,18 +65,53 @@ struct Core {
   template <int MODE>
   JXS_HD void run() {
     const VI lane = ln.lane();
+    ln.stamp(A, 0);
+
+    // ======================================================================================
+    // Batch 1 of global loads: every address below is known at launch, so all of them are in
+    // flight together (one memory round trip instead of one per phase; rocprof showed 44 % of the
+    // wave cycles parked in s_waitcnt before this was hoisted).  Loads are unconditional -- rows
+    // are clamped into range and the value masked afterwards -- so no exec-mask branches.
+    // ======================================================================================
     const VI jtype = ln.lconsti(A.lti, LI_JTYPE);
     const VI parent = ln.lconsti(A.lti, LI_PARENT);
     const VI level = ln.lconsti(A.lti, LI_LEVEL);
-    const VM is_joint = jtype != 0;
-    const VM is_rev = jtype == 1;
-    const VM is_pri = jtype == 2;
-    const VM is_root = level == 0;
-    const VI jrow = lane - 1;  // joint arrays are 0-based: ii = i - 1   (rbda/aba.py:133)
-
-    // ---- state (row D) -----------------------------------------------------------------
-    const V s = ln.gload(A.state_in, jrow + P.row_s, is_joint);
-    const V sd = ln.gload(A.state_in, jrow + P.row_sd, is_joint);
+    const VI lnk = ln.lconsti(A.lti, LI_LINK);   // reference link index of this lane
+    const VI jrow = ln.lconsti(A.lti, LI_JROW);  // joint arrays are 0-based: ii = i - 1 (rbda/aba.py:133)
+    VI jump[kMaxRounds], child[kMaxChildren];
+#pragma unroll
+    for (int k = 0; k < kMaxRounds; ++k) jump[k] = (k < P.n_rounds) ? ln.lconsti(A.lti, LI_JUMP + k) : lane * 0 - 1;
+#pragma unroll
+    for (int k = 0; k < kMaxChildren; ++k) child[k] = ln.lconsti(A.lti, LI_CHILD + k);
+    V ax[3], Rpre[9], ppre[3], cL[3], IL[6];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) ax[k] = ln.lconstf(A.ltf, LF_AXIS + k);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Rpre[k] = ln.lconstf(A.ltf, LF_RPRE + k);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) ppre[k] = ln.lconstf(A.ltf, LF_PPRE + k);
+    const V mass = ln.lconstf(A.ltf, LF_MASS);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) cL[k] = ln.lconstf(A.ltf, LF_COM + k);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) IL[k] = ln.lconstf(A.ltf, LF_ICOM + k);
+    V smin, smax, klim, dlim, kc, kv;
+    if (MODE == MODE_STEP) {
+      smin = ln.lconstf(A.ltf, LF_SMIN), smax = ln.lconstf(A.ltf, LF_SMAX);
+      klim = ln.lconstf(A.ltf, LF_KLIM), dlim = ln.lconstf(A.ltf, LF_DLIM);
+      kc = ln.lconstf(A.ltf, LF_KC), kv = ln.lconstf(A.ltf, LF_KV);
+    }
+    V Rsuc[9], psuc[3];
+    if (P.any_suc) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) Rsuc[k] = ln.lconstf(A.ltf, LF_RSUC + k);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) psuc[k] = ln.lconstf(A.ltf, LF_PSUC + k);
+    }
+    // state (row D)
+    const VI jrow_c = vsel(jrow >= 0, jrow, lane * 0);
+    V s = ln.gload(A.state_in, jrow_c + P.row_s);
+    V sd = ln.gload(A.state_in, jrow_c + P.row_sd);
     V pB[3], q[4], vW[3], om[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -86,12 +121,31 @@ struct Core {
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) q[k] = ln.gload_u(A.state_in, P.row_quat + k);
+    V tau = (A.tau != nullptr) ? ln.gload(A.tau, jrow_c) : V(T(0));
+    V f6in[6];
+    if (A.link_f != nullptr) {
+      const VI lrow = vsel(lnk >= 0, lnk, lane * 0) * 6;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) f6in[k] = ln.gload(A.link_f, lrow + k);
+    }
+    // collidable-point tables of chunk 0 (further chunks are loaded inside the contact loop)
+    PointSlot ps0;
+    const bool with_contacts = (MODE == MODE_STEP) && P.n_chunks > 0;
+    if (with_contacts) load_slot_tables(lane, 0, ps0);
+
+    const VM is_joint = jtype != 0;
+    const VM is_rev = jtype == 1;
+    const VM is_pri = jtype == 2;
+    const VM is_root = level == 0;
+    s = vsel(is_joint, s, V(T(0)));
+    sd = vsel(is_joint, sd, V(T(0)));
+    tau = vsel(is_joint, tau, V(T(0)));
+    // Batch 2: the tangential deformation rows depend on the slot table just loaded.
+    if (with_contacts) load_slot_state(ps0);
+    ln.stamp(A, 1);  // tables + state arrived
 
     // ---- B: joint torques (api/actuation_model.py:7-126) --------------------------------
-    V tau = (A.tau != nullptr) ? ln.gload(A.tau, jrow, is_joint) : V(T(0));
     if (MODE == MODE_STEP) {
-      const V smin = ln.lconstf(A.ltf, LF_SMIN), smax = ln.lconstf(A.ltf, LF_SMAX);
-      const V klim = ln.lconstf(A.ltf, LF_KLIM), dlim = ln.lconstf(A.ltf, LF_DLIM);
       const V lower = vmin(s - smin, V(T(0)));  // clip(max=0)
       const V upper = vmax(s - smax, V(T(0)));  // clip(min=0)
       V tau_pl = -(klim * (lower + upper));
@@ -99,14 +153,13 @@ struct Core {
       tau_pl = tau_pl - tau_pl * (dlim * sd);
       V tau_fr = V(T(0));
       if (P.enable_friction) {
-        const V kc = ln.lconstf(A.ltf, LF_KC), kv = ln.lconstf(A.ltf, LF_KV);
         const V sgn = vsel(sd > V(T(0)), V(T(1)), vsel(sd < V(T(0)), V(T(-1)), V(T(0))));
         tau_fr = -(kc * sgn + kv * sd);
       }
       const V tot = tau + tau_fr + tau_pl;
       const V av = vabs(sd);
       const V lim = vsel(av <= V(P.w_th), V(P.tau_max),
-                         vsel(av <= V(P.w_max), P.tau_max * (V(T(1)) - (av - P.w_th) / (P.w_max - P.w_th)), V(T(0))));
+                         vsel(av <= V(P.w_max), P.tau_max * (V(T(1)) - (av - P.w_th) * P.inv_w_range), V(T(0))));
       tau = vmax(vmin(tot, lim), -lim);  // clip(tot, -lim, lim)
     }
 
@@ -115,7 +168,7 @@ struct Core {
     {
       const V nsq = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
       const V nrm = vsqrt(nsq);
-      const V inv = V(T(1)) / (nrm + vsel(nrm == V(T(0)), V(P.eps), V(T(0))));
+      const V inv = vrcp(nrm + vsel(nrm == V(T(0)), V(P.eps), V(T(0))));
 #pragma unroll
       for (int k = 0; k < 4; ++k) q[k] = q[k] * inv;
     }
@@ -136,14 +189,14 @@ struct Core {
 
     // ---- H: local parent->child transform lambda_H_pre * pre_H_suc(s) * suc_H_i ----------
     //      (api/kin_dyn_parameters.py:396-451, math/joint_model.py:146-200, math/rotation.py:58-84)
-    V ax[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) ax[k] = ln.lconstf(A.ltf, LF_AXIS + k);
     {
-      V sn, cs;
-      vsincos(vsel(is_rev, s, V(T(0))), sn, cs);
-      const V hs = vsin(vsel(is_rev, s, V(T(0))) * T(0.5));
-      const V c1 = T(2) * hs * hs;  // 1 - cos, computed as 2 sin^2(theta/2) like the reference
+      // Rodrigues from the half angle: sin s = 2 sh ch, 1 - cos s = 2 sh^2 (the reference also
+      // forms 1 - cos as 2 sin^2(theta/2)), cos s = 1 - 2 sh^2.
+      V sh, chh;
+      vsincos(vsel(is_rev, s, V(T(0))) * T(0.5), sh, chh);
+      const V sn = T(2) * sh * chh;
+      const V c1 = T(2) * sh * sh;
+      const V cs = V(T(1)) - c1;
       V Rj[9];
       Rj[0] = cs + c1 * ax[0] * ax[0];
       Rj[1] = -sn * ax[2] + c1 * ax[0] * ax[1];
@@ -157,18 +210,9 @@ struct Core {
       V pj[3];
 #pragma unroll
       for (int k = 0; k < 3; ++k) pj[k] = vsel(is_pri, s * ax[k], V(T(0)));
-      V Rpre[9], ppre[3];
-#pragma unroll
-      for (int k = 0; k < 9; ++k) Rpre[k] = ln.lconstf(A.ltf, LF_RPRE + k);
-#pragma unroll
-      for (int k = 0; k < 3; ++k) ppre[k] = ln.lconstf(A.ltf, LF_PPRE + k);
       V Rl[9], pl[3];
       if (P.any_suc) {
-        V Rsuc[9], psuc[3], tmp[9], t3[3];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) Rsuc[k] = ln.lconstf(A.ltf, LF_RSUC + k);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) psuc[k] = ln.lconstf(A.ltf, LF_PSUC + k);
+        V tmp[9], t3[3];
         mat3mul(Rj, Rsuc, tmp);
         mat3mul(Rpre, tmp, Rl);
         mat3vec(Rj, psuc, t3);
@@ -187,25 +231,31 @@ struct Core {
 #pragma unroll
       for (int k = 0; k < 3; ++k) r[k] = vsel(is_root, V(T(0)), pl[k]);
     }
+    ln.stamp(A, 2);  // actuation + local transforms
 
     // ---- M: forward kinematics as a tree prefix product (pointer jumping) ----------------
     //      equals the scan of rbda/forward_kinematics.py:80-103 in exact arithmetic
-    for (int k = 0; k < P.n_rounds; ++k) {
-      const VI src = ln.lconsti(A.lti, LI_JUMP + k);
-      const VM ok = src >= 0;
-      V Ra[9], ra[3];
 #pragma unroll
-      for (int e = 0; e < 9; ++e) Ra[e] = ln.shfl(R[e], src);
+    for (int k = 0; k < kMaxRounds; ++k) {
+      if (k < P.n_rounds) {
+        const VI src = jump[k];
+        const VM ok = src >= 0;
+        V Ra[9], ra[3];
 #pragma unroll
-      for (int e = 0; e < 3; ++e) ra[e] = ln.shfl(r[e], src);
-      V Rn[9], rn[3];
-      mat3mul(Ra, R, Rn);
-      mat3vec(Ra, r, rn);
+        for (int e = 0; e < 9; ++e) Ra[e] = ln.shfl(R[e], src);
 #pragma unroll
-      for (int e = 0; e < 9; ++e) R[e] = vsel(ok, Rn[e], R[e]);
+        for (int e = 0; e < 3; ++e) ra[e] = ln.shfl(r[e], src);
+        ln.fence();
+        V Rn[9], rn[3];
+        mat3mul(Ra, R, Rn);
+        mat3vec(Ra, r, rn);
 #pragma unroll
-      for (int e = 0; e < 3; ++e) r[e] = vsel(ok, rn[e] + ra[e], r[e]);
+        for (int e = 0; e < 9; ++e) R[e] = vsel(ok, Rn[e], R[e]);
+#pragma unroll
+        for (int e = 0; e < 3; ++e) r[e] = vsel(ok, rn[e] + ra[e], r[e]);
+      }
     }
+    ln.stamp(A, 3);  // forward kinematics
 
     // Base velocity in C: [v_W + w x p_B ; w] (= mixed velocity).  ABA keeps v_0 = 0 for a
     // fixed base (rbda/aba.py:109-121) while the cached link velocities still start from the
@@ -237,7 +287,7 @@ struct Core {
       vl[k] = vsel(is_root, P.floating ? vBc[k] : V(T(0)), vJl[k]);
       va[k] = vsel(is_root, P.floating ? om[k] : V(T(0)), vJa[k]);
     }
-    prefix6(vl, va);
+    prefix6(jump, vl, va);
 
     // c_i = v_i x vJ_i   (Cross.vx, math/cross.py:14-43; rbda/aba.py:141)
     V cl[3], ca[3];
@@ -249,6 +299,7 @@ struct Core {
 #pragma unroll
       for (int k = 0; k < 3; ++k) cl[k] = t0[k] + t1[k];
     }
+    ln.stamp(A, 4);  // velocities
 
     // offset of the cached kinematics w.r.t. the ABA base frame (quirk 12): R0 * p(suc_H_i[0])
     V doff[3];
@@ -258,7 +309,7 @@ struct Core {
     }
 
     if (MODE == MODE_KIN) {
-      store_kinematics(lane, level, R, r, vl, va, pB, doff, vBc, om);
+      store_kinematics(lnk, level, R, r, vl, va, pB, doff, vBc, om);
       return;
     }
 
@@ -268,7 +319,7 @@ struct Core {
       const VM is_link = level >= 0;
       V f6[6];
 #pragma unroll
-      for (int k = 0; k < 6; ++k) f6[k] = ln.gload(A.link_f, lane * 6 + k, is_link);
+      for (int k = 0; k < 6; ++k) f6[k] = vsel(is_link, f6in[k], V(T(0)));
       V arm[3], t[3];
       if (A.force_repr == REPR_INERTIAL) {
         // [f; mu_W - p_B x f]
@@ -304,19 +355,14 @@ struct Core {
     }
 
     // ---- J,K,L,I: soft contacts ----------------------------------------------------------
-    if (MODE == MODE_STEP && P.n_chunks > 0) contacts(lane, R, r, vl, va, pB, doff, vBc, om, fl, fa);
+    if (with_contacts) contacts(lane, ps0, R, r, vl, va, pB, doff, vBc, om, fl, fa);
+    ln.stamp(A, 5);  // contacts
 
     // ---- link inertia in C and bias force --------------------------------------------------
     // M = [[m I, m S(c)^T],[m S(c), I_c + m S(c) S(c)^T]]  (math/inertia.py:14-41) with the CoM
     // c = r + R c_L and I_c = R I_L R^T expressed in C.
-    const V mass = ln.lconstf(A.ltf, LF_MASS);
     V cw[3], Ic[6];
     {
-      V cL[3], IL[6];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) cL[k] = ln.lconstf(A.ltf, LF_COM + k);
-#pragma unroll
-      for (int k = 0; k < 6; ++k) IL[k] = ln.lconstf(A.ltf, LF_ICOM + k);
       mat3vec(R, cL, cw);
 #pragma unroll
       for (int k = 0; k < 3; ++k) cw[k] = cw[k] + r[k];
@@ -358,7 +404,7 @@ struct Core {
     }
 
     if (MODE == MODE_ID) {
-      rnea(lane, jrow, level, parent, is_joint, is_root, Sl, Sa, cl, ca, mass, cw, Ic, bl, ba, fl, fa, pB);
+      rnea(lane, jrow, level, jump, child, is_joint, is_root, Sl, Sa, cl, ca, mass, cw, Ic, bl, ba, fl, fa, pB);
       return;
     }
 
@@ -394,17 +440,18 @@ struct Core {
     }
     const V S6[6] = {Sl[0], Sl[1], Sl[2], Sa[0], Sa[1], Sa[2]};
     const V c6[6] = {cl[0], cl[1], cl[2], ca[0], ca[1], ca[2]};
+    ln.stamp(A, 6);  // inertia + bias
 
     // Pass 2 (rbda/aba.py:184-224), leaves to base, one tree level per iteration.  In frame C
     // the propagation X^T Ma X is the identity congruence: parents simply add.
     V U[6], inv_d = V(T(0)), u = V(T(0));
 #pragma unroll
     for (int k = 0; k < 6; ++k) U[k] = V(T(0));
-    VI child[kMaxChildren];
-#pragma unroll
-    for (int k = 0; k < kMaxChildren; ++k) child[k] = ln.lconsti(A.lti, LI_CHILD + k);
     const int first_level = P.floating ? 1 : 2;  // fixed base: nothing propagates into link 0
-    for (int Lv = P.max_depth; Lv >= 1; --Lv) {
+    const int max_depth = P.max_depth;
+    const unsigned long long mc0 = P.maxch_nib[0], mc1 = P.maxch_nib[1], mc2 = P.maxch_nib[2], mc3 = P.maxch_nib[3];
+    const unsigned long long nonadj = P.nonadj_levels;
+    for (int Lv = max_depth; Lv >= 1; --Lv) {
       // U = MA S, d = S^T U, u = tau - S^T pA
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
@@ -420,7 +467,7 @@ struct Core {
         sp = sp + pA[i] * S6[i];
       }
       u = tau - sp;
-      inv_d = V(T(1)) / d;
+      inv_d = vsel(is_joint, vrcp(d), V(T(0)));  // finite everywhere: base / padding lanes have d = 0
       if (Lv < first_level) break;
       // Ma = MA - U U^T / d ;  pa = pA + Ma c + U u / d
       V Ma[21], pa[6], Ud[6];
@@ -437,21 +484,54 @@ struct Core {
         for (int j = 0; j < 6; ++j) acc = acc + Ma[sidx(i, j)] * c6[j];
         pa[i] = acc;
       }
-      // parents at level Lv-1 gather from their children (all at level Lv)
+      // parents at level Lv-1 gather from their children (all at level Lv).  In the depth-first
+      // lane order the first child sits in lane+1: a DPP lane shift, no LDS round trip.
       const VM is_par = level == (Lv - 1);
+      const unsigned long long mcw = Lv < 16 ? mc0 : Lv < 32 ? mc1 : Lv < 48 ? mc2 : mc3;
+      const int nch = (int)((mcw >> ((Lv & 15) * 4)) & 15ull);
+      if (nch >= 1) {
+        const V okf = vsel(is_par && (child[0] >= 0), V(T(1)), V(T(0)));
+        // 27 values = 3 blocks of 9 fused "acc += value(lane+1) * okf"
+        V acc9[9], src9[9];
+        ln.fmac9_from_next(MA, Ma, okf);
+        ln.fmac9_from_next(MA + 9, Ma + 9, okf);
 #pragma unroll
-      for (int k = 0; k < kMaxChildren; ++k) {
-        if (k < P.maxch[Lv]) {
-          const VM ok = is_par && (child[k] >= 0);
+        for (int e = 0; e < 3; ++e) {
+          acc9[e] = MA[18 + e];
+          src9[e] = Ma[18 + e];
+        }
 #pragma unroll
-          for (int e = 0; e < 21; ++e) MA[e] = MA[e] + vsel(ok, ln.shfl(Ma[e], child[k]), V(T(0)));
+        for (int e = 0; e < 6; ++e) {
+          acc9[3 + e] = pA[e];
+          src9[3 + e] = pa[e];
+        }
+        ln.fmac9_from_next(acc9, src9, okf);
 #pragma unroll
-          for (int e = 0; e < 6; ++e) pA[e] = pA[e] + vsel(ok, ln.shfl(pa[e], child[k]), V(T(0)));
+        for (int e = 0; e < 3; ++e) MA[18 + e] = acc9[e];
+#pragma unroll
+        for (int e = 0; e < 6; ++e) pA[e] = acc9[3 + e];
+      }
+#pragma unroll
+      for (int k = 1; k < kMaxChildren; ++k) {
+        if (k < nch) {
+          // 1.0 where this lane is a parent of the current level with a k-th child, else 0.0
+          const V okf = vsel(is_par && (child[k] >= 0), V(T(1)), V(T(0)));
+          // issue all 27 shuffles back to back, wait once, then consume (Ma/pa are finite in
+          // every lane, see inv_d above, so masking by multiplication is safe)
+          V gM[21], gp[6];
+#pragma unroll
+          for (int e = 0; e < 21; ++e) gM[e] = ln.shfl(Ma[e], child[k]);
+#pragma unroll
+          for (int e = 0; e < 6; ++e) gp[e] = ln.shfl(pa[e], child[k]);
+          ln.fence();
+#pragma unroll
+          for (int e = 0; e < 21; ++e) MA[e] = MA[e] + okf * gM[e];
+#pragma unroll
+          for (int e = 0; e < 6; ++e) pA[e] = pA[e] + okf * gp[e];
         }
       }
     }
-    // U, 1/d, u of every lane are final here: a link's MA stops changing once its children
-    // (one level deeper) have been gathered, and the last iteration recomputed them for all lanes.
+    ln.stamp(A, 7);  // pass 2
 
     // Pass 3 (rbda/aba.py:240-267): base acceleration, then top-down.
     V a6[6];
@@ -462,11 +542,21 @@ struct Core {
       for (int k = 0; k < 6; ++k) a6[k] = V(T(0));
       a6[2] = V(-P.g);  // a0 = -B_X_W W_g expressed in C
     }
+    ln.stamp(A, 8);  // base solve
     V sdd = V(T(0));
-    for (int Lv = 1; Lv <= P.max_depth; ++Lv) {
+    const VM par_adjacent = parent == (lane - 1);
+    for (int Lv = 1; Lv <= max_depth; ++Lv) {
       V ap[6];
 #pragma unroll
-      for (int k = 0; k < 6; ++k) ap[k] = ln.shfl(a6[k], parent);
+      for (int k = 0; k < 6; ++k) ap[k] = ln.from_prev(a6[k]);  // parent in lane-1 (first children)
+      if ((nonadj >> Lv) & 1ull) {
+        V aq[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) aq[k] = ln.shfl(a6[k], parent);
+        ln.fence();
+#pragma unroll
+        for (int k = 0; k < 6; ++k) ap[k] = vsel(par_adjacent, ap[k], aq[k]);
+      }
       const VM act = level == Lv;
       V ai[6];
 #pragma unroll
@@ -492,6 +582,7 @@ struct Core {
       }
       if (P.floating) acl[2] = acl[2] + P.g;
     }
+    ln.stamp(A, 9);  // pass 3
 
     if (MODE == MODE_FD) {
       // inertial-fixed base acceleration: a_lin^W = a_lin^C - wdot x p_B
@@ -533,7 +624,7 @@ struct Core {
       qn[2] = q[2] + dt * half * (q[2] * h0 - q[3] * omn[0] + q[0] * omn[1] + q[1] * omn[2]);
       qn[3] = q[3] + dt * half * (q[3] * h0 + q[2] * omn[0] - q[1] * omn[1] + q[0] * omn[2]);
       const V nn = vsqrt(qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3]);
-      const V invn = V(T(1)) / vsel(nn == V(T(0)), V(T(1)), nn);
+      const V invn = vrcp(vsel(nn == V(T(0)), V(T(1)), nn));
       const VI zl = lane * 0;
 #pragma unroll
       for (int k = 0; k < 4; ++k) ln.gstore(A.state_out, zl + (P.row_quat + k), qn[k] * invn, is_root);
@@ -544,44 +635,49 @@ struct Core {
         ln.gstore(A.state_out, zl + (P.row_vang + k), omn[k], is_root);
       }
     }
+    ln.stamp(A, 10);  // integrate + stores issued
   }
 
   // ==========================================================================================
   // inclusive prefix sum of a 6-vector over the ancestors of every lane (pointer jumping)
-  JXS_HD void prefix6(V* xl, V* xa) const {
-    for (int k = 0; k < P.n_rounds; ++k) {
-      const VI src = ln.lconsti(A.lti, LI_JUMP + k);
-      const VM ok = src >= 0;
-      V tl[3], ta[3];
+  JXS_HD void prefix6(const VI* jump, V* xl, V* xa) const {
 #pragma unroll
-      for (int e = 0; e < 3; ++e) {
-        tl[e] = ln.shfl(xl[e], src);
-        ta[e] = ln.shfl(xa[e], src);
-      }
+    for (int k = 0; k < kMaxRounds; ++k) {
+      if (k < P.n_rounds) {
+        const VI src = jump[k];
+        const VM ok = src >= 0;
+        V tl[3], ta[3];
 #pragma unroll
-      for (int e = 0; e < 3; ++e) {
-        xl[e] = xl[e] + vsel(ok, tl[e], V(T(0)));
-        xa[e] = xa[e] + vsel(ok, ta[e], V(T(0)));
+        for (int e = 0; e < 3; ++e) {
+          tl[e] = ln.shfl(xl[e], src);
+          ta[e] = ln.shfl(xa[e], src);
+        }
+        ln.fence();
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+          xl[e] = xl[e] + vsel(ok, tl[e], V(T(0)));
+          xa[e] = xa[e] + vsel(ok, ta[e], V(T(0)));
+        }
       }
     }
   }
 
   // a = -MA^-1 pA for the symmetric positive-definite 6x6 MA (LDL^T, no pivoting)
   JXS_HD void solve6(const V* MA, const V* pA, V* a) const {
-    V Lm[6][6], Dd[6];
+    V Lm[6][6], Dd[6], Di[6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
       V dj = MA[sidx(j, j)];
 #pragma unroll
       for (int k = 0; k < j; ++k) dj = dj - Lm[j][k] * Lm[j][k] * Dd[k];
       Dd[j] = dj;
-      const V inv = V(T(1)) / dj;
+      Di[j] = vrcp(dj);
 #pragma unroll
       for (int i = j + 1; i < 6; ++i) {
         V lij = MA[sidx(i, j)];
 #pragma unroll
         for (int k = 0; k < j; ++k) lij = lij - Lm[i][k] * Lm[j][k] * Dd[k];
-        Lm[i][j] = lij * inv;
+        Lm[i][j] = lij * Di[j];
       }
     }
     V y[6];
@@ -594,7 +690,7 @@ struct Core {
     }
 #pragma unroll
     for (int i = 5; i >= 0; --i) {
-      V acc = y[i] / Dd[i];
+      V acc = y[i] * Di[i];
 #pragma unroll
       for (int k = i + 1; k < 6; ++k) acc = acc - Lm[k][i] * a[k];
       a[i] = acc;
@@ -606,21 +702,52 @@ struct Core {
   // (rbda/contacts/common.py:25-63), Hunt-Crossley + stick/slip state
   // (rbda/contacts/soft.py:195-388), per-link wrench sum (api/contact.py:557-603) and the
   // Euler update of the tangential deformation (api/integrators.py:67-71).
-  JXS_HD void contacts(const VI& lane, const V* R, const V* r, const V* vl, const V* va, const V* pB,
-                       const V* doff, const V* vBc, const V* om, V* fl, V* fa) const {
+  template <int OFF>
+  JXS_HD void seg_step_dpp(const VI& tail, V* w6) const {
+    const VM take = tail >= OFF;
+    V g6[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) g6[k] = ln.template row_from_next<OFF>(w6[k]);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) w6[k] = w6[k] + vsel(take, g6[k], V(T(0)));
+  }
+
+  struct PointSlot {
+    VI body, prow, tail, hd;
+    V Lp[3], m[3];
+  };
+  JXS_HD void load_slot_tables(const VI& lane, int ch, PointSlot& ps) const {
+    const VI slot = lane + ch * G;
+    ps.body = ln.ploadi(A.pti, PI_BODY, P.n_slots, slot);
+    ps.prow = ln.ploadi(A.pti, PI_ROW, P.n_slots, slot);
+    ps.tail = ln.ploadi(A.pti, PI_TAIL, P.n_slots, slot);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) ps.Lp[k] = ln.ploadf(A.ptf, PF_POS + k, P.n_slots, slot);
+    ps.hd = ln.lconsti(A.head, ch);
+  }
+  JXS_HD void load_slot_state(PointSlot& ps) const {
+    // empty slots carry row 0: the load is in range and its value is masked by `valid` later
+#pragma unroll
+    for (int k = 0; k < 3; ++k) ps.m[k] = ln.gload(A.state_in, ps.prow * 3 + (P.row_m + k));
+  }
+
+  JXS_HD void contacts(const VI& lane, const PointSlot& ps0, const V* R, const V* r, const V* vl, const V* va,
+                       const V* pB, const V* doff, const V* vBc, const V* om, V* fl, V* fa) const {
     const V zero = V(T(0));
     for (int ch = 0; ch < P.n_chunks; ++ch) {
-      const VI slot = lane + ch * G;
-      const VI body = ln.ploadi(A.pti, PI_BODY, P.n_slots, slot);
-      const VI prow = ln.ploadi(A.pti, PI_ROW, P.n_slots, slot);
-      const VI tail = ln.ploadi(A.pti, PI_TAIL, P.n_slots, slot);
+      PointSlot ps = ps0;
+      if (ch > 0) {
+        load_slot_tables(lane, ch, ps);
+        load_slot_state(ps);
+      }
+      const VI body = ps.body, prow = ps.prow, tail = ps.tail;
       const VM valid = body >= 0;
-      V Lp[3];
+      V Lp[3], m[3];
 #pragma unroll
-      for (int k = 0; k < 3; ++k) Lp[k] = ln.ploadf(A.ptf, PF_POS + k, P.n_slots, slot);
-      V m[3];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) m[k] = ln.gload(A.state_in, prow * 3 + (P.row_m + k), valid);
+      for (int k = 0; k < 3; ++k) {
+        Lp[k] = ps.Lp[k];
+        m[k] = vsel(valid, ps.m[k], zero);
+      }
       // kinematics of the parent link
       V Rb[9], rb[3], vbl[3], vba[3];
 #pragma unroll
@@ -631,6 +758,7 @@ struct Core {
         vbl[e] = ln.shfl(vl[e], body);
         vba[e] = ln.shfl(va[e], body);
       }
+      ln.fence();
       V rc0[3], rc[3], pw[3], pd[3], t[3];
       mat3vec(Rb, Lp, rc0);
 #pragma unroll
@@ -680,7 +808,7 @@ struct Core {
       const VM no_contact = !in_contact;  // delta <= 0
       const VM sticking = no_contact || (ft2 <= mufn * mufn);
       const V nrm = vsqrt(ft2);
-      const V scale = vmin(mufn, nrm) / (nrm + vsel(nrm == zero, V(P.eps), zero));
+      const V scale = vmin(mufn, nrm) * vrcp(nrm + vsel(nrm == zero, V(P.eps), zero));
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         ft[k] = vsel(sticking, ft[k], scale * ft[k]);
@@ -688,7 +816,7 @@ struct Core {
       }
       // deformation rate: no contact | sticking | slipping
       V md[3];
-      const V inv_Ddq = V(T(1)) / Ddq;
+      const V inv_Ddq = vrcp(Ddq);
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         const V md_nc = -(P.K_over_D * m[k]);
@@ -705,32 +833,48 @@ struct Core {
       w6[1] = vsel(valid, ft[1], zero);
       w6[2] = vsel(valid, fn + ft[2], zero);
       cross(rc, w6, w6 + 3);
-      // segmented suffix-sum over the slots of one link (slots are sorted by link)
-      for (int st = 0, off = 1; st < P.seg_steps; ++st, off <<= 1) {
-        const VM take = tail >= off;
-        const VI src = lane + off;
+      // segmented suffix-sum over the slots of one link (slots are sorted by link); when every
+      // segment lies inside a 16-lane row the partner lane+off is reached by a DPP row shift
+      if (P.seg_dpp_ok) {
+        if (P.seg_steps > 0) seg_step_dpp<1>(tail, w6);
+        if (P.seg_steps > 1) seg_step_dpp<2>(tail, w6);
+        if (P.seg_steps > 2) seg_step_dpp<4>(tail, w6);
+        if (P.seg_steps > 3) seg_step_dpp<8>(tail, w6);
+      } else {
+        for (int st = 0, off = 1; st < P.seg_steps; ++st, off <<= 1) {
+          const VM take = tail >= off;
+          const VI src = lane + off;
+          V g6[6];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) w6[k] = w6[k] + vsel(take, ln.shfl(w6[k], src), zero);
+          for (int k = 0; k < 6; ++k) g6[k] = ln.shfl(w6[k], src);
+          ln.fence();
+#pragma unroll
+          for (int k = 0; k < 6; ++k) w6[k] = w6[k] + vsel(take, g6[k], zero);
+        }
       }
-      const VI hd = ln.lconsti(A.head, ch);
+      const VI hd = ps.hd;
       const VM has = hd >= 0;
+      V h6[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) h6[k] = ln.shfl(w6[k], hd);
+      ln.fence();
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        fl[k] = fl[k] + vsel(has, ln.shfl(w6[k], hd), zero);
-        fa[k] = fa[k] + vsel(has, ln.shfl(w6[3 + k], hd), zero);
+        fl[k] = fl[k] + vsel(has, h6[k], zero);
+        fa[k] = fa[k] + vsel(has, h6[3 + k], zero);
       }
     }
   }
 
   // ==========================================================================================
   // R: RNEA in frame C (rbda/rnea.py:12-238).  in_a = inertial base acceleration + sdd.
-  JXS_HD void rnea(const VI& lane, const VI& jrow, const VI& level, const VI& parent, const VM& is_joint,
-                   const VM& is_root, const V* Sl, const V* Sa, const V* cl, const V* ca, const V& mass,
-                   const V* cw, const V* Ic, const V* bl, const V* ba, const V* fl, const V* fa,
+  JXS_HD void rnea(const VI& lane, const VI& jrow, const VI& level, const VI* jump, const VI* child,
+                   const VM& is_joint, const VM& is_root, const V* Sl, const V* Sa, const V* cl, const V* ca,
+                   const V& mass, const V* cw, const V* Ic, const V* bl, const V* ba, const V* fl, const V* fa,
                    const V* pB) const {
-    (void)parent;
     const V zero = V(T(0));
-    const V sdd = (A.in_a != nullptr) ? ln.gload(A.in_a, jrow + 6, is_joint) : zero;
+    const VI jrow_c = vsel(jrow >= 0, jrow, lane * 0);
+    const V sdd = (A.in_a != nullptr) ? vsel(is_joint, ln.gload(A.in_a, jrow_c + 6), zero) : zero;
     // base acceleration in C: a_0 = (Wdot_v - W_g) moved to the C origin (floating) or -W_g
     V al[3], aa[3];
     {
@@ -752,7 +896,7 @@ struct Core {
       }
       al[2] = al[2] - vsel(is_root, V(P.g), zero);
     }
-    prefix6(al, aa);  // a_i = a_lambda + S sdd + v x vJ  (rnea.py:150-152)
+    prefix6(jump, al, aa);  // a_i = a_lambda + S sdd + v x vJ  (rnea.py:150-152)
     // f_i = M a + v x* M v - f_ext  (rnea.py:163-168)
     V f6[6];
     {
@@ -779,19 +923,25 @@ struct Core {
       }
     }
     // backward pass: f_lambda += f_i, one level per iteration (rnea.py:193-219)
-    VI child[kMaxChildren];
-#pragma unroll
-    for (int k = 0; k < kMaxChildren; ++k) child[k] = ln.lconsti(A.lti, LI_CHILD + k);
     const int first_level = P.floating ? 1 : 2;
     for (int Lv = P.max_depth; Lv >= first_level; --Lv) {
       const VM is_par = level == (Lv - 1);
+      const int nch = P.maxch(Lv);
+      // children push only when they are at the current level (f of deeper lanes is final, but a
+      // parent must not re-add a child it gathered in an earlier iteration)
+      if (nch >= 1) {
+        const VM ok = is_par && (child[0] >= 0);
 #pragma unroll
-      for (int k = 0; k < kMaxChildren; ++k) {
-        if (k < P.maxch[Lv]) {
+        for (int e = 0; e < 6; ++e) f6[e] = f6[e] + vsel(ok, ln.from_next(f6[e]), zero);
+      }
+#pragma unroll
+      for (int k = 1; k < kMaxChildren; ++k) {
+        if (k < nch) {
           const VM ok = is_par && (child[k] >= 0);
           V g6[6];
 #pragma unroll
           for (int e = 0; e < 6; ++e) g6[e] = ln.shfl(f6[e], child[k]);
+          ln.fence();
 #pragma unroll
           for (int e = 0; e < 6; ++e) f6[e] = f6[e] + vsel(ok, g6[e], zero);
         }
@@ -812,7 +962,7 @@ struct Core {
 
   // ==========================================================================================
   // N: cached kinematics -- W_H_L and inertial-fixed W_v_WL of every link (api/data.py:480-492)
-  JXS_HD void store_kinematics(const VI& lane, const VI& level, const V* R, const V* r, const V* vl,
+  JXS_HD void store_kinematics(const VI& lnk, const VI& level, const V* R, const V* r, const V* vl,
                                const V* va, const V* pB, const V* doff, const V* vBc, const V* om) const {
     const VM is_link = level >= 0;
     V p[3], vlin[3], vang[3], t[3];
@@ -849,15 +999,15 @@ struct Core {
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
 #pragma unroll
-        for (int j = 0; j < 3; ++j) ln.gstore(A.out_H, lane * 12 + (4 * i + j), R[3 * i + j], is_link);
-        ln.gstore(A.out_H, lane * 12 + (4 * i + 3), p[i], is_link);
+        for (int j = 0; j < 3; ++j) ln.gstore(A.out_H, lnk * 12 + (4 * i + j), R[3 * i + j], is_link);
+        ln.gstore(A.out_H, lnk * 12 + (4 * i + 3), p[i], is_link);
       }
     }
     if (A.out_V != nullptr) {
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        ln.gstore(A.out_V, lane * 6 + k, vlin[k], is_link);
-        ln.gstore(A.out_V, lane * 6 + (3 + k), vang[k], is_link);
+        ln.gstore(A.out_V, lnk * 6 + k, vlin[k], is_link);
+        ln.gstore(A.out_V, lnk * 6 + (3 + k), vang[k], is_link);
       }
     }
   }

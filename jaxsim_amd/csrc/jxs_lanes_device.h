@@ -9,12 +9,27 @@
 namespace jxs {
 
 // ---- scalar "vector" primitives (V = T on the device) --------------------------------------
+// fp32 uses the hardware reciprocal / square root refined to ~0.5-1 ulp instead of the IEEE
+// division / sqrt expansions (10+ instructions each on a path that is latency bound), and a
+// short Cody-Waite + minimax sincos (joint angles are O(1) rad; valid for |x| < 1e4).
 __device__ __forceinline__ float vsel(bool m, float a, float b) { return m ? a : b; }
 __device__ __forceinline__ double vsel(bool m, double a, double b) { return m ? a : b; }
 __device__ __forceinline__ int vsel(bool m, int a, int b) { return m ? a : b; }
-__device__ __forceinline__ float vsqrt(float x) { return sqrtf(x); }
+__device__ __forceinline__ float vrcp(float x) {
+  const float r = __builtin_amdgcn_rcpf(x);
+  return __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);  // one Newton step
+}
+__device__ __forceinline__ double vrcp(double x) { return 1.0 / x; }
+__device__ __forceinline__ float vsqrt(float x) {
+  // x * rsq(x) with one Newton step; exact zeros stay zero
+  const float y = __builtin_amdgcn_rsqf(x);
+  const float s = x * y;
+  const float e = __builtin_fmaf(-s, s, x);
+  const float r = __builtin_fmaf(0.5f * y, e, s);
+  return x > 0.0f ? r : x;
+}
 __device__ __forceinline__ double vsqrt(double x) { return sqrt(x); }
-__device__ __forceinline__ float vabs(float x) { return fabsf(x); }
+__device__ __forceinline__ float vabs(float x) { return __builtin_fabsf(x); }
 __device__ __forceinline__ double vabs(double x) { return fabs(x); }
 __device__ __forceinline__ float vmin(float a, float b) { return fminf(a, b); }
 __device__ __forceinline__ double vmin(double a, double b) { return fmin(a, b); }
@@ -22,10 +37,28 @@ __device__ __forceinline__ float vmax(float a, float b) { return fmaxf(a, b); }
 __device__ __forceinline__ double vmax(double a, double b) { return fmax(a, b); }
 __device__ __forceinline__ float vpow(float a, float b) { return powf(a, b); }
 __device__ __forceinline__ double vpow(double a, double b) { return pow(a, b); }
-__device__ __forceinline__ void vsincos(float x, float& s, float& c) { sincosf(x, &s, &c); }
+__device__ __forceinline__ void vsincos(float x, float& s, float& c) {
+  // k = round(x * 2/pi); r = x - k*pi/2 (3-term Cody-Waite); polynomials on [-pi/4, pi/4]
+  const float kf = __builtin_rintf(x * 0.63661977236758134f);
+  float r = __builtin_fmaf(kf, -1.5707962513e+00f, x);
+  r = __builtin_fmaf(kf, -7.5497894159e-08f, r);
+  r = __builtin_fmaf(kf, -5.3903029534e-15f, r);
+  const float r2 = r * r;
+  // sin(r) ~ r + r^3 * P(r^2), cos(r) ~ 1 - r^2/2 + r^4 * Q(r^2)   (cephes sinf/cosf kernels)
+  float ps = __builtin_fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f);
+  ps = __builtin_fmaf(r2, ps, -1.6666654611e-1f);
+  const float sr = __builtin_fmaf(r * r2, ps, r);
+  float pc = __builtin_fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
+  pc = __builtin_fmaf(r2, pc, 4.166664568298827e-2f);
+  const float cr = __builtin_fmaf(r2 * r2, pc, __builtin_fmaf(r2, -0.5f, 1.0f));
+  const int k = (int)kf;
+  const bool swap = (k & 1) != 0;
+  const float s0 = swap ? cr : sr;
+  const float c0 = swap ? sr : cr;
+  s = (k & 2) ? -s0 : s0;
+  c = ((k + 1) & 2) ? -c0 : c0;
+}
 __device__ __forceinline__ void vsincos(double x, double& s, double& c) { sincos(x, &s, &c); }
-__device__ __forceinline__ float vsin(float x) { return sinf(x); }
-__device__ __forceinline__ double vsin(double x) { return sin(x); }
 
 template <typename T_, int G_>
 struct DeviceLanes {
@@ -38,6 +71,7 @@ struct DeviceLanes {
   int lane_;    // lane within the group
   int base4_;   // (first wave lane of the group) * 4, for ds_bpermute byte addressing
   int env_;     // environment handled by this group
+  int envc_;    // the same, clamped into [0, N) for loads
   bool env_ok_;
   int N_;
 
@@ -47,10 +81,26 @@ struct DeviceLanes {
     base4_ = (wl & ~(G - 1)) << 2;
     env_ = blockIdx.x * (64 / G) + (wl / G);
     env_ok_ = env_ < N;
+    envc_ = env_ok_ ? env_ : N - 1;
   }
 
   __device__ __forceinline__ VI lane() const { return lane_; }
   __device__ __forceinline__ VM all_true() const { return true; }
+  // Scheduling fence: everything issued before it (a batch of shuffles) stays before, every
+  // consumer after -- the batch is pipelined through the LDS crossbar and waited for once.
+  __device__ __forceinline__ void fence() const { __builtin_amdgcn_sched_barrier(0); }
+  // Phase stamps for the developer profiling build; compiled out otherwise.
+  template <class KA>
+  __device__ __forceinline__ void stamp(const KA& A, int i) const {
+#ifdef JXS_PHASE_TIMING
+    __builtin_amdgcn_sched_barrier(0);
+    if (A.dbg != nullptr && threadIdx.x == 0) A.dbg[(size_t)blockIdx.x * 16 + i] = (long long)__builtin_readcyclecounter();
+    __builtin_amdgcn_sched_barrier(0);
+#else
+    (void)A;
+    (void)i;
+#endif
+  }
 
   __device__ __forceinline__ int src4(int src) const { return ((src & (G - 1)) << 2) + base4_; }
   __device__ __forceinline__ float shfl(float x, int src) const {
@@ -64,6 +114,46 @@ struct DeviceLanes {
     return __hiloint2double(hi, lo);
   }
 
+  // DPP lane shifts (VALU operand modifiers, no LDS round trip).  They act on the whole wave, so
+  // the first / last lane of a group sees a neighbour group's value: callers mask those lanes.
+  template <int CTRL>
+  static __device__ __forceinline__ float dpp(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
+  }
+  template <int CTRL>
+  static __device__ __forceinline__ double dpp(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+  }
+  __device__ __forceinline__ V from_next(V x) const { return dpp<0x130>(x); }  // wave_shl:1, lane i <- i+1
+  __device__ __forceinline__ V from_prev(V x) const { return dpp<0x138>(x); }  // wave_shr:1, lane i <- i-1
+  template <int OFF>
+  __device__ __forceinline__ V row_from_next(V x) const { return dpp<0x100 + OFF>(x); }  // row_shl:OFF
+  // acc[k] += x[k](lane+1) * m for 9 values: nine v_fmac_f32_dpp in one asm block.  hipcc does not
+  // fuse mov_dpp + fma itself; inside an asm block it does not see the "VALU write -> DPP read"
+  // hazard either, hence the leading s_nop 1 (2 wait states) -- operands are not rewritten inside.
+  __device__ __forceinline__ void fmac9_from_next(float* a, const float* x, float m) const {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_fmac_f32_dpp %0, %9, %18 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_dpp %1, %10, %18 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_dpp %2, %11, %18 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_dpp %3, %12, %18 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_dpp %4, %13, %18 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_dpp %5, %14, %18 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_dpp %6, %15, %18 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_dpp %7, %16, %18 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_dpp %8, %17, %18 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+        : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8])
+        : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]), "v"(x[8]), "v"(m));
+  }
+  __device__ __forceinline__ void fmac9_from_next(double* a, const double* x, double m) const {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) a[k] = a[k] + m * from_next(x[k]);
+  }
+
   // per-lane model constants
   __device__ __forceinline__ V lconstf(const T* tbl, int field) const { return tbl[field * G + lane_]; }
   __device__ __forceinline__ VI lconsti(const int* tbl, int field) const { return tbl[field * G + lane_]; }
@@ -74,13 +164,10 @@ struct DeviceLanes {
   __device__ __forceinline__ VI ploadi(const int* tbl, int field, int n_slots, int slot) const {
     return tbl[field * n_slots + slot];
   }
-  // [row][N] arrays at this group's environment
-  __device__ __forceinline__ V gload(const T* base, int row, bool mask) const {
-    return (mask && env_ok_) ? base[(size_t)row * N_ + env_] : T(0);
-  }
-  __device__ __forceinline__ V gload_u(const T* base, int row) const {
-    return env_ok_ ? base[(size_t)row * N_ + env_] : T(0);
-  }
+  // [row][N] arrays at this group's environment.  Loads are unconditional (callers clamp the
+  // row and mask the value): no exec-mask branch, and every load can be issued up front.
+  __device__ __forceinline__ V gload(const T* base, int row) const { return base[(size_t)row * N_ + envc_]; }
+  __device__ __forceinline__ V gload_u(const T* base, int row) const { return base[(size_t)row * N_ + envc_]; }
   __device__ __forceinline__ void gstore(T* base, int row, T val, bool mask) const {
     if (mask && env_ok_) base[(size_t)row * N_ + env_] = val;
   }

@@ -93,11 +93,28 @@ std::string pack_model(const jxs_model_desc& d, Packed<T>& out) {
   P.n_rounds = rounds;
   std::vector<std::vector<int>> children(nL);
   for (int i = 1; i < nL; ++i) children[d.parent[i]].push_back(i);
-  for (int L = 0; L <= kMaxDepth; ++L) P.maxch[L] = 0;
+  int maxch_level[kMaxDepth + 1] = {0};
   for (int i = 0; i < nL; ++i) {
     if ((int)children[i].size() > kMaxChildren) return "links with more than 6 children are not supported";
-    if (!children[i].empty()) P.maxch[level[i] + 1] = std::max(P.maxch[level[i] + 1], (int)children[i].size());
+    if (!children[i].empty()) maxch_level[level[i] + 1] = std::max(maxch_level[level[i] + 1], (int)children[i].size());
   }
+  for (int w = 0; w < (kMaxDepth + 1) / 16; ++w) P.maxch_nib[w] = 0;
+  for (int L = 0; L <= kMaxDepth; ++L) P.maxch_nib[L / 16] |= (unsigned long long)maxch_level[L] << ((L % 16) * 4);
+  // depth-first pre-order lane assignment: first child of lane j is lane j+1
+  std::vector<int> lane_of(nL, -1), link_of;
+  {
+    std::vector<int> stack{0};
+    while (!stack.empty()) {
+      const int i = stack.back();
+      stack.pop_back();
+      lane_of[i] = (int)link_of.size();
+      link_of.push_back(i);
+      for (int k = (int)children[i].size() - 1; k >= 0; --k) stack.push_back(children[i][k]);
+    }
+  }
+  P.nonadj_levels = 0;
+  for (int i = 1; i < nL; ++i)
+    if (lane_of[d.parent[i]] != lane_of[i] - 1) P.nonadj_levels |= 1ull << level[i];
 
   // state rows
   P.row_pos = 0;
@@ -123,6 +140,7 @@ std::string pack_model(const jxs_model_desc& d, Packed<T>& out) {
   P.tau_max = (T)d.torque_max;
   P.w_th = (T)d.omega_th;
   P.w_max = (T)d.omega_max;
+  P.inv_w_range = (T)(1.0 / (d.omega_max - d.omega_th));
   P.enable_friction = d.enable_friction ? 1 : 0;
   for (int k = 0; k < 3; ++k) P.base_off[k] = (T)d.suc_H_i[4 * k + 3];
   P.eps = std::numeric_limits<T>::epsilon();
@@ -149,57 +167,59 @@ std::string pack_model(const jxs_model_desc& d, Packed<T>& out) {
     I(LI_JTYPE, lane) = 0;
     I(LI_PARENT, lane) = -1;
     I(LI_LEVEL, lane) = -1;
+    I(LI_LINK, lane) = -1;
+    I(LI_JROW, lane) = -1;
     for (int k = 0; k < kMaxRounds; ++k) I(LI_JUMP + k, lane) = -1;
     for (int k = 0; k < kMaxChildren; ++k) I(LI_CHILD + k, lane) = -1;
     F(LF_SMIN, lane) = -big;
     F(LF_SMAX, lane) = big;
     if (lane >= nL) continue;
-    const int i = lane;
-    I(LI_LEVEL, i) = level[i];
-    F(LF_MASS, i) = (T)d.link_mass[i];
-    for (int k = 0; k < 3; ++k) F(LF_COM + k, i) = (T)d.link_com[3 * i + k];
+    const int i = link_of[lane];
+    I(LI_LINK, lane) = i;
+    I(LI_LEVEL, lane) = level[i];
+    F(LF_MASS, lane) = (T)d.link_mass[i];
+    for (int k = 0; k < 3; ++k) F(LF_COM + k, lane) = (T)d.link_com[3 * i + k];
     const double* Ii = d.link_inertia + 9 * i;
-    F(LF_ICOM + 0, i) = (T)Ii[0];
-    F(LF_ICOM + 1, i) = (T)(0.5 * (Ii[1] + Ii[3]));
-    F(LF_ICOM + 2, i) = (T)(0.5 * (Ii[2] + Ii[6]));
-    F(LF_ICOM + 3, i) = (T)Ii[4];
-    F(LF_ICOM + 4, i) = (T)(0.5 * (Ii[5] + Ii[7]));
-    F(LF_ICOM + 5, i) = (T)Ii[8];
-    for (int k = 0; k < (int)children[i].size(); ++k) I(LI_CHILD + k, i) = children[i][k];
+    F(LF_ICOM + 0, lane) = (T)Ii[0];
+    F(LF_ICOM + 1, lane) = (T)(0.5 * (Ii[1] + Ii[3]));
+    F(LF_ICOM + 2, lane) = (T)(0.5 * (Ii[2] + Ii[6]));
+    F(LF_ICOM + 3, lane) = (T)Ii[4];
+    F(LF_ICOM + 4, lane) = (T)(0.5 * (Ii[5] + Ii[7]));
+    F(LF_ICOM + 5, lane) = (T)Ii[8];
+    for (int k = 0; k < (int)children[i].size(); ++k) I(LI_CHILD + k, lane) = lane_of[children[i][k]];
+    if (!children[i].empty() && lane_of[children[i][0]] != lane + 1) return "internal error: DFS lane order";
     if (i == 0) continue;
-    I(LI_JTYPE, i) = d.joint_type[i];
-    I(LI_PARENT, i) = d.parent[i];
-    int anc = d.parent[i];
-    // jump[k] = ancestor at distance 2^k
+    I(LI_JTYPE, lane) = d.joint_type[i];
+    I(LI_JROW, lane) = i - 1;
+    I(LI_PARENT, lane) = lane_of[d.parent[i]];
     std::vector<int> chain;  // ancestors at distance 1,2,3,...
     for (int a = i; a != 0;) {
       a = d.parent[a];
       chain.push_back(a);
     }
-    (void)anc;
     for (int k = 0; k < kMaxRounds; ++k) {
-      const int dist = 1 << k;
-      I(LI_JUMP + k, i) = (dist <= (int)chain.size()) ? chain[dist - 1] : -1;
+      const int dist = 1 << k;  // jump[k] = lane of the ancestor at distance 2^k
+      I(LI_JUMP + k, lane) = (dist <= (int)chain.size()) ? lane_of[chain[dist - 1]] : -1;
     }
     const double* Hp = d.lambda_H_pre + 16 * i;
     const double* Hs = d.suc_H_i + 16 * i;
     for (int r = 0; r < 3; ++r) {
       for (int c = 0; c < 3; ++c) {
-        F(LF_RPRE + 3 * r + c, i) = (T)Hp[4 * r + c];
-        F(LF_RSUC + 3 * r + c, i) = (T)Hs[4 * r + c];
+        F(LF_RPRE + 3 * r + c, lane) = (T)Hp[4 * r + c];
+        F(LF_RSUC + 3 * r + c, lane) = (T)Hs[4 * r + c];
         if (std::fabs(Hs[4 * r + c] - (r == c ? 1.0 : 0.0)) > 0) any_suc = 1;
       }
-      F(LF_PPRE + r, i) = (T)Hp[4 * r + 3];
-      F(LF_PSUC + r, i) = (T)Hs[4 * r + 3];
+      F(LF_PPRE + r, lane) = (T)Hp[4 * r + 3];
+      F(LF_PSUC + r, lane) = (T)Hs[4 * r + 3];
       if (Hs[4 * r + 3] != 0.0) any_suc = 1;
     }
-    for (int k = 0; k < 3; ++k) F(LF_AXIS + k, i) = (T)d.joint_axis[3 * i + k];
-    F(LF_KC, i) = (T)d.friction_static[i];
-    F(LF_KV, i) = (T)d.friction_viscous[i];
-    F(LF_SMIN, i) = clampT(d.position_limit_min[i]);
-    F(LF_SMAX, i) = clampT(d.position_limit_max[i]);
-    F(LF_KLIM, i) = (T)d.position_limit_spring[i];
-    F(LF_DLIM, i) = (T)d.position_limit_damper[i];
+    for (int k = 0; k < 3; ++k) F(LF_AXIS + k, lane) = (T)d.joint_axis[3 * i + k];
+    F(LF_KC, lane) = (T)d.friction_static[i];
+    F(LF_KV, lane) = (T)d.friction_viscous[i];
+    F(LF_SMIN, lane) = clampT(d.position_limit_min[i]);
+    F(LF_SMAX, lane) = clampT(d.position_limit_max[i]);
+    F(LF_KLIM, lane) = (T)d.position_limit_spring[i];
+    F(LF_DLIM, lane) = (T)d.position_limit_damper[i];
   }
   P.any_suc = any_suc;
 
@@ -207,7 +227,7 @@ std::string pack_model(const jxs_model_desc& d, Packed<T>& out) {
   out.ptf.assign((size_t)PF_COUNT * std::max(n_slots, 1), T(0));
   out.pti.assign((size_t)PI_COUNT * std::max(n_slots, 1), 0);
   out.head.assign((size_t)std::max(n_chunks, 1) * G, -1);
-  int max_seg = 1;
+  int max_seg = 1, seg_dpp = 1;
   for (int s = 0; s < n_slots; ++s) {
     out.pti[(size_t)PI_BODY * n_slots + s] = -1;
     out.pti[(size_t)PI_ROW * n_slots + s] = 0;
@@ -215,7 +235,7 @@ std::string pack_model(const jxs_model_desc& d, Packed<T>& out) {
   }
   for (int s = 0; s < n_en; ++s) {
     const int k = en[s];
-    out.pti[(size_t)PI_BODY * n_slots + s] = d.point_body[k];
+    out.pti[(size_t)PI_BODY * n_slots + s] = lane_of[d.point_body[k]];
     out.pti[(size_t)PI_ROW * n_slots + s] = k;
     for (int c = 0; c < 3; ++c) out.ptf[(size_t)(PF_POS + c) * n_slots + s] = (T)d.point_position[3 * k + c];
   }
@@ -226,7 +246,8 @@ std::string pack_model(const jxs_model_desc& d, Packed<T>& out) {
       const int body = d.point_body[en[s]];
       int e = s;
       while (e + 1 < end && d.point_body[en[e + 1]] == body) ++e;
-      out.head[(size_t)ch * G + body] = s - ch * G;
+      out.head[(size_t)ch * G + lane_of[body]] = s - ch * G;
+      if ((s - ch * G) / 16 != (e - ch * G) / 16) seg_dpp = 0;
       for (int t = s; t <= e; ++t) out.pti[(size_t)PI_TAIL * n_slots + t] = e - t;
       max_seg = std::max(max_seg, e - s + 1);
       s = e + 1;
@@ -235,6 +256,7 @@ std::string pack_model(const jxs_model_desc& d, Packed<T>& out) {
   int seg_steps = 0;
   while ((1 << seg_steps) < max_seg) ++seg_steps;
   P.seg_steps = seg_steps;
+  P.seg_dpp_ok = seg_dpp;
   return std::string();
 }
 

@@ -2,9 +2,12 @@
 // kernels and the host lockstep emulation used by the CPU tests.
 //
 // Mapping: one environment is processed by a group of G lanes of a
-// wavefront (G = 4..64, power of two); lane j of the group owns link j of the kinematic tree
-// (reference link index, BFS order, `src/jaxsim/parsers/kinematic_graph.py:133-134`) and, in
-// the contact phase, collidable-point slot j of the current chunk.
+// wavefront (G = 4..64, power of two).  Links are assigned to lanes in depth-first pre-order
+// (NOT the reference's BFS link index, `src/jaxsim/parsers/kinematic_graph.py:133-134`): the
+// first child of the link in lane j sits in lane j+1, so the most frequent parent<->child
+// exchanges of the ABA sweeps are DPP lane shifts (VALU modifiers) instead of ds_bpermute
+// round trips (~190 cycles each, measured).  The per-lane tables carry the reference link /
+// joint index of every lane.  In the contact phase lane j owns point slot j of the chunk.
 #pragma once
 #include <cstdint>
 
@@ -47,8 +50,10 @@ enum LaneI : int {
   LI_PARENT = 1,  // parent lane, -1 for the base and padding lanes
   LI_LEVEL = 2,   // tree depth, -1 for padding lanes
   LI_JUMP = 3,    // kMaxRounds entries: ancestor at distance 2^k, -1 if beyond the base
-  LI_CHILD = LI_JUMP + kMaxRounds,  // kMaxChildren entries: child lanes, -1 if none
-  LI_COUNT = LI_CHILD + kMaxChildren
+  LI_CHILD = LI_JUMP + kMaxRounds,  // kMaxChildren entries: child lanes, -1 if none (child 0 = lane+1)
+  LI_LINK = LI_CHILD + kMaxChildren,  // reference link index of this lane, -1 for padding lanes
+  LI_JROW = LI_LINK + 1,              // joint row (link index - 1), -1 for the base / padding lanes
+  LI_COUNT = LI_JROW + 1
 };
 
 // ---- per-point-slot tables (slots = n_chunks * G): ptf[field * slots + slot] etc. ----------
@@ -75,7 +80,14 @@ template <typename T>
 struct KParams {
   // topology
   int nL, n, n_points, n_slots, n_chunks, seg_steps, n_rounds, max_depth, floating, any_suc;
-  int maxch[kMaxDepth + 1];  // maxch[L]: max #children (at level L) of any link at level L-1
+  // maxch(L): max #children (at level L) of any link at level L-1, 4 bits per level
+  unsigned long long maxch_nib[(kMaxDepth + 1) / 16];
+  unsigned long long nonadj_levels;  // bit L: some link at level L has its parent in a lane != lane-1
+  int seg_dpp_ok;                    // every (chunk, link) point segment lies inside one 16-lane row
+  JXS_HD int maxch(int L) const {
+    const unsigned long long w = L < 16 ? maxch_nib[0] : L < 32 ? maxch_nib[1] : L < 48 ? maxch_nib[2] : maxch_nib[3];
+    return (int)((w >> ((L & 15) * 4)) & 15ull);
+  }
   // state-block rows ([row][N], N fastest): SURVEY.md section 8(a) row D
   int row_pos, row_quat, row_s, row_vlin, row_vang, row_sd, row_m, n_rows;
   // model constants
@@ -84,6 +96,7 @@ struct KParams {
   int pq_half;                   // p == q == 0.5 -> sqrt instead of pow
   T terrain_h;                   // FlatTerrain height                   terrain/terrain.py:65-124
   T tau_max, w_th, w_max;        // ActuationParams                      rbda/actuation/common.py:16-19
+  T inv_w_range;                 // 1 / (w_max - w_th)
   int enable_friction;
   T base_off[3];                 // translation of suc_H_i[0] (quirk 12)
   T eps;                         // finfo(dtype).eps                     rbda/contacts/soft.py:246
@@ -108,6 +121,7 @@ struct KArgs {
   T* out_H;            // MODE_KIN: [nL*12][N] rows of [R|p] per link (row-major 3x4)
   T* out_V;            // MODE_KIN: [nL*6][N] inertial-fixed link velocities
   int N;               // batch size (leading dimension of every [row][N] array)
+  long long* dbg;      // developer builds (-DJXS_PHASE_TIMING): [blocks][16] cycle stamps, else null
 };
 
 }  // namespace jxs

@@ -151,12 +151,14 @@ ICUB_JOINTS = (
 )  # fmt: skip
 
 
-def icub23_urdf(sole_boxes_per_foot: int = 2, joint_limit: float = 1.0) -> str:
+def icub23_urdf(sole_boxes_per_foot: int = 2, joint_limit: float = 1.0, joint_damping: float = 1.0,
+                joint_friction: float = 0.2) -> str:
     """Synthetic 24-link / 23-DoF floating-base humanoid, total mass ~33 kg.
 
     ``sole_boxes_per_foot`` boxes per foot, 8 corner points each: 2 -> n_cp = 32 (the
     stated C3/C4 default), 1 -> n_cp = 16.
-    Standing height of the root link above the soles is ~0.60 m.
+    Standing height of the root link above the soles is ~0.60 m.  Every joint carries
+    viscous damping / Coulomb friction (URDF ``<dynamics>``), like the real robot's URDF.
     """
     out = ['<robot name="icub23_synthetic">']
 
@@ -169,18 +171,18 @@ def icub23_urdf(sole_boxes_per_foot: int = 2, joint_limit: float = 1.0) -> str:
     link("torso_1", 1.0, (0, 0, 0.02), (0.08, 0.08, 0.06))
     link("torso_2", 1.0, (0, 0, 0.02), (0.08, 0.08, 0.06))
     link("chest", 8.0, (0, 0, 0.12), (0.18, 0.26, 0.25))
-    out.append(_joint("torso_pitch", "revolute", "root_link", "torso_1", (0, 0, 0.08), (0, 1, 0), lower=-jl, upper=jl))
-    out.append(_joint("torso_roll", "revolute", "torso_1", "torso_2", (0, 0, 0.04), (1, 0, 0), lower=-jl, upper=jl))
-    out.append(_joint("torso_yaw", "revolute", "torso_2", "chest", (0, 0, 0.04), (0, 0, 1), lower=-jl, upper=jl))
+    out.append(_joint("torso_pitch", "revolute", "root_link", "torso_1", (0, 0, 0.08), (0, 1, 0), lower=-jl, upper=jl, damping=joint_damping, friction=joint_friction))
+    out.append(_joint("torso_roll", "revolute", "torso_1", "torso_2", (0, 0, 0.04), (1, 0, 0), lower=-jl, upper=jl, damping=joint_damping, friction=joint_friction))
+    out.append(_joint("torso_yaw", "revolute", "torso_2", "chest", (0, 0, 0.04), (0, 0, 1), lower=-jl, upper=jl, damping=joint_damping, friction=joint_friction))
     for s, sy in (("l", 1.0), ("r", -1.0)):
         link(f"{s}_shoulder_1", 0.5, (0, 0.02 * sy, 0), (0.06, 0.06, 0.06))
         link(f"{s}_shoulder_2", 0.5, (0, 0, -0.02), (0.06, 0.06, 0.06))
         link(f"{s}_shoulder_3", 1.2, (0, 0, -0.08), (0.06, 0.06, 0.16))
         link(f"{s}_forearm", 1.0, (0, 0, -0.08), (0.05, 0.05, 0.18))
-        out.append(_joint(f"{s}_shoulder_pitch", "revolute", "chest", f"{s}_shoulder_1", (0, 0.12 * sy, 0.2), (0, 1, 0), lower=-jl, upper=jl))
-        out.append(_joint(f"{s}_shoulder_roll", "revolute", f"{s}_shoulder_1", f"{s}_shoulder_2", (0, 0.05 * sy, 0), (1, 0, 0), lower=-jl, upper=jl))
-        out.append(_joint(f"{s}_shoulder_yaw", "revolute", f"{s}_shoulder_2", f"{s}_shoulder_3", (0, 0, -0.04), (0, 0, 1), lower=-jl, upper=jl))
-        out.append(_joint(f"{s}_elbow", "revolute", f"{s}_shoulder_3", f"{s}_forearm", (0, 0, -0.16), (0, 1, 0), lower=-jl, upper=jl))
+        out.append(_joint(f"{s}_shoulder_pitch", "revolute", "chest", f"{s}_shoulder_1", (0, 0.12 * sy, 0.2), (0, 1, 0), lower=-jl, upper=jl, damping=joint_damping, friction=joint_friction))
+        out.append(_joint(f"{s}_shoulder_roll", "revolute", f"{s}_shoulder_1", f"{s}_shoulder_2", (0, 0.05 * sy, 0), (1, 0, 0), lower=-jl, upper=jl, damping=joint_damping, friction=joint_friction))
+        out.append(_joint(f"{s}_shoulder_yaw", "revolute", f"{s}_shoulder_2", f"{s}_shoulder_3", (0, 0, -0.04), (0, 0, 1), lower=-jl, upper=jl, damping=joint_damping, friction=joint_friction))
+        out.append(_joint(f"{s}_elbow", "revolute", f"{s}_shoulder_3", f"{s}_forearm", (0, 0, -0.16), (0, 1, 0), lower=-jl, upper=jl, damping=joint_damping, friction=joint_friction))
         # legs
         sole = ""
         if sole_boxes_per_foot >= 1:
@@ -197,12 +199,12 @@ def icub23_urdf(sole_boxes_per_foot: int = 2, joint_limit: float = 1.0) -> str:
         link(f"{s}_lower_leg", 2.0, (0, 0, -0.1), (0.07, 0.07, 0.22))
         link(f"{s}_ankle_1", 0.5, (0, 0, 0), (0.05, 0.05, 0.05))
         link(f"{s}_ankle_2", 0.8, (0.03, 0, -0.04), (0.18, 0.08, 0.04), extra=sole)
-        out.append(_joint(f"{s}_hip_pitch", "revolute", "root_link", f"{s}_hip_1", (0, 0.07 * sy, -0.06), (0, 1, 0), lower=-jl, upper=jl))
-        out.append(_joint(f"{s}_hip_roll", "revolute", f"{s}_hip_1", f"{s}_hip_2", (0, 0, -0.02), (1, 0, 0), lower=-jl, upper=jl))
-        out.append(_joint(f"{s}_hip_yaw", "revolute", f"{s}_hip_2", f"{s}_upper_leg", (0, 0, -0.04), (0, 0, 1), lower=-jl, upper=jl))
-        out.append(_joint(f"{s}_knee", "revolute", f"{s}_upper_leg", f"{s}_lower_leg", (0, 0, -0.22), (0, 1, 0), lower=-jl, upper=jl))
-        out.append(_joint(f"{s}_ankle_pitch", "revolute", f"{s}_lower_leg", f"{s}_ankle_1", (0, 0, -0.2), (0, 1, 0), lower=-jl, upper=jl))
-        out.append(_joint(f"{s}_ankle_roll", "revolute", f"{s}_ankle_1", f"{s}_ankle_2", (0, 0, 0), (1, 0, 0), lower=-jl, upper=jl))
+        out.append(_joint(f"{s}_hip_pitch", "revolute", "root_link", f"{s}_hip_1", (0, 0.07 * sy, -0.06), (0, 1, 0), lower=-jl, upper=jl, damping=joint_damping, friction=joint_friction))
+        out.append(_joint(f"{s}_hip_roll", "revolute", f"{s}_hip_1", f"{s}_hip_2", (0, 0, -0.02), (1, 0, 0), lower=-jl, upper=jl, damping=joint_damping, friction=joint_friction))
+        out.append(_joint(f"{s}_hip_yaw", "revolute", f"{s}_hip_2", f"{s}_upper_leg", (0, 0, -0.04), (0, 0, 1), lower=-jl, upper=jl, damping=joint_damping, friction=joint_friction))
+        out.append(_joint(f"{s}_knee", "revolute", f"{s}_upper_leg", f"{s}_lower_leg", (0, 0, -0.22), (0, 1, 0), lower=-jl, upper=jl, damping=joint_damping, friction=joint_friction))
+        out.append(_joint(f"{s}_ankle_pitch", "revolute", f"{s}_lower_leg", f"{s}_ankle_1", (0, 0, -0.2), (0, 1, 0), lower=-jl, upper=jl, damping=joint_damping, friction=joint_friction))
+        out.append(_joint(f"{s}_ankle_roll", "revolute", f"{s}_ankle_1", f"{s}_ankle_2", (0, 0, 0), (1, 0, 0), lower=-jl, upper=jl, damping=joint_damping, friction=joint_friction))
     out.append("</robot>")
     return "".join(out)
 

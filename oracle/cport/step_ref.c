@@ -508,12 +508,13 @@ int FN(oracle_step)(const jxs_model_desc* d, const REAL* state_in, REAL* state_o
 #else
   nt = 1;
 #endif
-  for (int it = 0; it < n_steps; ++it) {
+  /* Environments never interact, so each thread advances its environments through all the
+   * steps: one parallel region, no per-step barrier. */
 #ifdef _OPENMP
 #pragma omp parallel for schedule(static) num_threads(nt)
 #endif
-    for (int e = 0; e < N; ++e) step_env(c, state_out, state_out, tau, link_forces, N, e);
-  }
+  for (int e = 0; e < N; ++e)
+    for (int it = 0; it < n_steps; ++it) step_env(c, state_out, state_out, tau, link_forces, N, e);
   free(c);
   return 0;
 }

@@ -48,7 +48,7 @@ int run_typed(const jxs_model_desc* d, int mode, const void* state_in, void* sta
   jxs::KArgs<T> a{};
   a.state_in = static_cast<const T*>(state_in);
   a.state_out = static_cast<T*>(state_out);
-  a.tau = static_cast<const T*>(tau);
+  a.tau = (pk.P.n > 0) ? static_cast<const T*>(tau) : nullptr;
   a.link_f = static_cast<const T*>(link_f);
   a.force_repr = force_repr;
   a.in_a = static_cast<const T*>(in_a);

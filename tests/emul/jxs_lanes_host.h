@@ -56,6 +56,11 @@ struct Vec {
     for (int i = 0; i < G; ++i) r.v[i] = std::sqrt(a.v[i]);
     return r;
   }
+  friend Vec vrcp(const Vec& a) {
+    Vec r;
+    for (int i = 0; i < G; ++i) r.v[i] = T(1) / a.v[i];
+    return r;
+  }
   friend Vec vabs(const Vec& a) {
     Vec r;
     for (int i = 0; i < G; ++i) r.v[i] = std::fabs(a.v[i]);
@@ -132,11 +137,35 @@ struct HostLanes {
     return r;
   }
   VM all_true() const { return VM(true); }
+  void fence() const {}
+  template <class KA>
+  void stamp(const KA&, int) const {}
 
   template <typename U>
   Vec<U, G> shfl(const Vec<U, G>& x, const VI& src) const {
     Vec<U, G> r;
     for (int i = 0; i < G; ++i) r.v[i] = x.v[src.v[i] & (G - 1)];
+    return r;
+  }
+  // lane shifts: out-of-group sources read as 0 here (on the device they read the neighbouring
+  // group; every caller masks those lanes)
+  V from_next(const V& x) const {
+    V r;
+    for (int i = 0; i < G; ++i) r.v[i] = (i + 1 < G) ? x.v[i + 1] : T(0);
+    return r;
+  }
+  V from_prev(const V& x) const {
+    V r;
+    for (int i = 0; i < G; ++i) r.v[i] = (i >= 1) ? x.v[i - 1] : T(0);
+    return r;
+  }
+  void fmac9_from_next(V* a, const V* x, const V& m) const {
+    for (int k = 0; k < 9; ++k) a[k] = a[k] + m * from_next(x[k]);
+  }
+  template <int OFF>
+  V row_from_next(const V& x) const {
+    V r;
+    for (int i = 0; i < G; ++i) r.v[i] = ((i % 16) + OFF < 16 && i + OFF < G) ? x.v[i + OFF] : T(0);
     return r;
   }
   V lconstf(const T* tbl, int field) const {
@@ -159,9 +188,9 @@ struct HostLanes {
     for (int i = 0; i < G; ++i) r.v[i] = tbl[field * n_slots + slot.v[i]];
     return r;
   }
-  V gload(const T* base, const VI& row, const VM& mask) const {
+  V gload(const T* base, const VI& row) const {
     V r;
-    for (int i = 0; i < G; ++i) r.v[i] = mask.v[i] ? base[(size_t)row.v[i] * N_ + env_] : T(0);
+    for (int i = 0; i < G; ++i) r.v[i] = base[(size_t)row.v[i] * N_ + env_];
     return r;
   }
   V gload_u(const T* base, int row) const { return V(base[(size_t)row * N_ + env_]); }

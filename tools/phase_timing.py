@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Developer tool: per-phase cycle breakdown of the step kernel (needs the library built with
+-DJXS_PHASE_TIMING, e.g. JAXSIM_AMD_LIB=.../libjaxsim_amd_timing.so)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from jaxsim_amd import _lib, runtime  # noqa: E402
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+model = bench.build_model("icub23")
+data = bench.synthetic_state(model, N, seed=0, dtype=np.float32)
+lib = _lib.load()
+dm = runtime.device_model(model, np.float32)
+blocks = (N + 1) // 2
+buf = C.c_void_p()
+lib.jxs_malloc(C.byref(buf), blocks * 16 * 8)
+lib.jxs_memset(buf, 0, blocks * 16 * 8, None)
+lib.jxs_debug_set_stamp_buffer.argtypes = [C.c_void_p]
+lib.jxs_debug_set_stamp_buffer(buf)
+ptr = C.c_void_p(data._state.ptr)
+for _ in range(20):
+    lib.jxs_step(dm.handle, ptr, ptr, None, None, 2, N, None)
+runtime.synchronize()
+out = np.zeros((blocks, 16), dtype=np.int64)
+lib.jxs_memcpy_d2h(out.ctypes.data_as(C.c_void_p), buf, out.nbytes, None)
+d = np.diff(out[:, :11], axis=1)
+names = ["loads arrive", "actuation+local xform", "FK (pointer jumping)", "velocities", "contacts", "inertia+bias",
+         "pass 2", "base solve", "pass 3", "integrate+stores"]
+print(f"N={N}: mean cycles per phase over {blocks} waves (s_memtime ticks)")
+for n, m, mx in zip(names, d.mean(axis=0), d.max(axis=0)):
+    print(f"  {n:24s} {m:9.0f}  (max {mx})")
+print(f"  {'total':24s} {(out[:, 10] - out[:, 0]).mean():9.0f}")
+span = out[:, 10].max() - out[:, 0].min()
+print(f"  first start -> last end: {span} ticks")

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Developer tool: time the step kernel for several batch sizes (HIP events, in place)."""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from jaxsim_amd import _lib, runtime  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--sizes", default="1024,2048,4096,8192,65536")
+ap.add_argument("--steps", type=int, default=500)
+ap.add_argument("--model", default="icub23")
+ap.add_argument("--dtype", default="float32")
+args = ap.parse_args()
+model = bench.build_model(args.model)
+dtype = np.dtype(args.dtype)
+lib = _lib.load()
+stream = runtime.Stream()
+for N in [int(x) for x in args.sizes.split(",")]:
+    data = bench.synthetic_state(model, N, seed=0, dtype=dtype)
+    runtime.set_stream(stream)
+    dm = runtime.device_model(model, dtype)
+    ptr = C.c_void_p(data._state.ptr)
+    for _ in range(20):
+        lib.jxs_step(dm.handle, ptr, ptr, None, None, 2, N, stream.handle)
+    stream.synchronize()
+    e0, e1 = runtime.Event(), runtime.Event()
+    e0.record(stream)
+    for _ in range(args.steps):
+        lib.jxs_step(dm.handle, ptr, ptr, None, None, 2, N, stream.handle)
+    e1.record(stream)
+    stream.synchronize()
+    us = e0.elapsed_ms(e1) / args.steps * 1e3
+    fin = np.isfinite(data.state_block()).all(axis=0).mean()
+    print(f"lib={os.environ.get('JAXSIM_AMD_LIB', 'default')} model={args.model} {dtype.name} N={N:7d}  {us:9.2f} us/step  "
+          f"{N / us:9.2f} M env-steps/s  finite={fin:.4f}", flush=True)
+    runtime.set_stream(None)
