@@ -32,6 +32,10 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 FP32_PEAK_TFLOPS = 157.3  # vector FP32 peak (same guide)
 FLOPS_PER_ENV_STEP = 30e3  # structure-exploiting flop model, SURVEY.md section 8(d) / A.5
+# HBM-side bytes per launch from the rocprofv3 PMC passes committed under profiles/ (separate
+# --pmc FETCH_SIZE / WRITE_SIZE runs of this very command; FETCH_SIZE doubled as the microarch
+# guide prescribes for gfx950).  Only filled for the configuration that was profiled.
+TRAFFIC_BYTES_PER_LAUNCH = {("icub23", 1024, "float32"): None}
 
 
 def parse_args():
@@ -122,6 +126,10 @@ def cpu_baseline(model, block, budget_s):
         if rate > best[0]:
             best = (rate, nt)
     rate, nt = best
+    # second calibration at the chosen team size (the 24-step probes are dominated by start-up)
+    t0 = time.perf_counter()
+    cport.step(model, block, n_steps=400, n_threads=nt)
+    rate = max(rate, 400 * n_envs / (time.perf_counter() - t0))
     n_steps = int(max(24, min(200000, budget_s * rate / n_envs)))
     t0 = time.perf_counter()
     cport.step(model, block, n_steps=n_steps, n_threads=nt)
@@ -218,7 +226,7 @@ def main():
         assert full.shape == (final.shape[0], n_local * world)
         lo = rank * n_local
         assert np.array_equal(full[:, lo : lo + n_local], final)
-    finite = bool(np.isfinite(final).all())
+    nonfinite_envs = int((~np.isfinite(final).all(axis=0)).sum())
 
     if rank == 0:
         lay = dm.layout
@@ -255,14 +263,15 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved_gbs / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": TRAFFIC_BYTES_PER_LAUNCH.get((args.model, n_local, dtype.name)),
                 "algorithmic_bytes_per_env_step": alg_bytes_per_env,
                 "kernel": "jxs_kernel<float,32,MODE_STEP>" if dtype == np.float32 else "jxs_kernel<double,32,MODE_STEP>",
                 "kernel_avg_launch_us": kernel_ms * 1e3,
                 "fp32_flop_model_per_env_step": FLOPS_PER_ENV_STEP,
                 "fp32_frac_of_vector_peak": FLOPS_PER_ENV_STEP * n_local / (kernel_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
             },
-            "final_state_finite": finite,
+            "nonfinite_envs_rank0": nonfinite_envs,
+            "traffic_note": "rocprofv3 FETCH_SIZE/WRITE_SIZE per launch: profiles/ (see DESIGN.md section 6)",
             "allgather_ms": allgather_ms,
         }
         if world == 1 and not args.no_cpu_baseline:
