@@ -247,3 +247,19 @@ def test_device_tables_follow_model_edits(models):
     ref = oracle.step(m2, d)
     assert not np.array_equal(a, b)
     assert helpers.rel_err(b, helpers.odata_to_block(m2, ref)) < helpers.FP64_TOL
+
+
+@pytest.mark.parametrize("name", ["double_pendulum", "cartpole", "box", "chain9f", "anymal", "icub"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_gpu_golden(models, name, dtype):
+    """The committed golden fixtures (tests/golden, oracle-generated) through the C-ABI."""
+    import pathlib
+
+    g = dict(np.load(pathlib.Path(__file__).resolve().parent / "golden" / f"{name}.npz"))
+    model = models(name)
+    data = js.data.JaxSimModelData.from_state_block(model, g["state"].astype(dtype), ja.VelRepr.Inertial)
+    out = js.model.step(model, data, link_forces=g["link_forces"], joint_force_references=g["tau"])
+    assert helpers.rel_err(out.state_block(), g["step"]) < helpers.tol_of(dtype)
+    vd, sdd = js.model.forward_dynamics_aba(model, data, joint_forces=g["tau"], link_forces=g["link_forces"])
+    assert helpers.rel_err(np.concatenate([vd, sdd], -1), g["fd"]) < helpers.tol_of(dtype)
+    assert helpers.rel_err(data._link_transforms, g["link_transforms"]) < helpers.tol_of(dtype)
