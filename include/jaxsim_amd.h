@@ -9,8 +9,11 @@
  * Conventions
  *  - plain C types only; no torch / HIP types in signatures (streams are `void*`
  *    = hipStream_t, NULL = default stream);
- *  - every batched array is a *device* pointer laid out [row][N] with the batch index N
- *    fastest (struct-of-arrays), dtype = the model's dtype (float or double);
+ *  - every batched array is a *device* pointer, struct-of-arrays with the batch index fastest,
+ *    tile-interleaved: written below as [rows][N], stored as [ceil(N/T)][rows][T] where
+ *    T = jxs_layout.tile environments (the environments one wavefront processes; T = 2 for the
+ *    24-link humanoid).  Element (row, env) lives at ((env/T)*rows + row)*T + env%T; arrays are
+ *    allocated in whole tiles.  dtype = the model's dtype (float or double);
  *  - state block rows (reference `JaxSimModelData`, src/jaxsim/api/data.py:46-63; the base
  *    velocity is stored inertial-fixed like the reference, :151-156,187-188):
  *        base_position[3] base_quaternion[4] (wxyz) joint_positions[n]
@@ -85,6 +88,7 @@ typedef struct jxs_layout {
   int32_t n_links, n_joints, n_points, n_rows;
   int32_t row_pos, row_quat, row_s, row_vlin, row_vang, row_sd, row_m;
   int32_t group; /* lanes per environment chosen for this model */
+  int32_t tile;  /* T = 64 / group: environments per tile of every batched array */
   int32_t dtype;
 } jxs_layout;
 

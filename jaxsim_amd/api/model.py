@@ -18,7 +18,7 @@ from ..model import JaxSimModel, VelRepr  # noqa: F401
 from ..runtime import DeviceArray
 
 
-def _as_device(x, rows: int, N: int, dtype, trailing_shape) -> DeviceArray | None:
+def _as_device(x, rows: int, N: int, dtype, trailing_shape, tile: int) -> DeviceArray | None:
     """Accept None | DeviceArray ([rows][N]) | host array ([N, *trailing] or [*trailing])."""
     if x is None:
         return None
@@ -32,7 +32,7 @@ def _as_device(x, rows: int, N: int, dtype, trailing_shape) -> DeviceArray | Non
         a = np.broadcast_to(a, (N,) + tuple(trailing_shape))
     if a.shape != (N,) + tuple(trailing_shape):
         raise ValueError((a.shape, (N,) + tuple(trailing_shape)))  # cf. rbda/utils.py:102-133
-    return DeviceArray.from_host(np.ascontiguousarray(a.reshape(N, rows).T), dtype=dtype)
+    return DeviceArray.from_host(np.ascontiguousarray(a.reshape(N, rows).T), tile=tile, dtype=dtype)
 
 
 def _ptr(d: DeviceArray | None):
@@ -56,9 +56,9 @@ def step(
     """
     dm = runtime.device_model(model, data.dtype)
     N, nL, n = data.batch_size, model.number_of_links(), model.dofs()
-    f = _as_device(link_forces, nL * 6, N, data.dtype, (nL, 6))
-    tau = _as_device(joint_force_references, n, N, data.dtype, (n,))
-    out = data._state if inplace else DeviceArray(data._state.rows, N, data.dtype)
+    f = _as_device(link_forces, nL * 6, N, data.dtype, (nL, 6), data._state.tile)
+    tau = _as_device(joint_force_references, n, N, data.dtype, (n,), data._state.tile)
+    out = data._state if inplace else DeviceArray(data._state.rows, N, data.dtype, tile=data._state.tile)
     _lib.check(
         _lib.load().jxs_step(
             dm.handle, C.c_void_p(data._state.ptr), C.c_void_p(out.ptr), _ptr(tau), _ptr(f),
@@ -75,8 +75,8 @@ def rollout(model: JaxSimModel, data: JaxSimModelData, n_steps: int, *, link_for
     ``step`` does in the reference's notebooks); the input data is not modified."""
     dm = runtime.device_model(model, data.dtype)
     N, nL, n = data.batch_size, model.number_of_links(), model.dofs()
-    f = _as_device(link_forces, nL * 6, N, data.dtype, (nL, 6))
-    tau = _as_device(joint_force_references, n, N, data.dtype, (n,))
+    f = _as_device(link_forces, nL * 6, N, data.dtype, (nL, 6), data._state.tile)
+    tau = _as_device(joint_force_references, n, N, data.dtype, (n,), data._state.tile)
     out = data._state.copy()
     _lib.check(
         _lib.load().jxs_rollout(
@@ -115,9 +115,9 @@ def forward_dynamics_aba(model: JaxSimModel, data: JaxSimModelData, *, joint_for
     the active representation of ``data`` and joint accelerations."""
     dm = runtime.device_model(model, data.dtype)
     N, nL, n = data.batch_size, model.number_of_links(), model.dofs()
-    f = _as_device(link_forces, nL * 6, N, data.dtype, (nL, 6))
-    tau = _as_device(joint_forces, n, N, data.dtype, (n,))
-    out = DeviceArray(6 + n, N, data.dtype)
+    f = _as_device(link_forces, nL * 6, N, data.dtype, (nL, 6), data._state.tile)
+    tau = _as_device(joint_forces, n, N, data.dtype, (n,), data._state.tile)
+    out = DeviceArray(6 + n, N, data.dtype, tile=data._state.tile)
     _lib.check(
         _lib.load().jxs_forward_dynamics_aba(
             dm.handle, C.c_void_p(data._state.ptr), _ptr(tau), _ptr(f), int(data.velocity_representation),
@@ -150,9 +150,11 @@ def inverse_dynamics(model: JaxSimModel, data: JaxSimModelData, *, joint_acceler
     W_H_C, W_v_WC = _mixed_frame(data)
     C_v_WC = _inertial_to_other(W_v_WC, VelRepr.Body, W_H_C, False)
     W_vd = _other_to_inertial(vd + _vx(C_v_WC, data._base_velocity_batched()), VelRepr.Body, W_H_C, False)
-    in_acc = DeviceArray.from_host(np.ascontiguousarray(np.concatenate([W_vd, sdd], -1).T), dtype=data.dtype)
-    f = _as_device(link_forces, nL * 6, N, data.dtype, (nL, 6))
-    out = DeviceArray(6 + n, N, data.dtype)
+    in_acc = DeviceArray.from_host(
+        np.ascontiguousarray(np.concatenate([W_vd, sdd], -1).T), tile=data._state.tile, dtype=data.dtype
+    )
+    f = _as_device(link_forces, nL * 6, N, data.dtype, (nL, 6), data._state.tile)
+    out = DeviceArray(6 + n, N, data.dtype, tile=data._state.tile)
     _lib.check(
         _lib.load().jxs_inverse_dynamics(
             dm.handle, C.c_void_p(data._state.ptr), C.c_void_p(in_acc.ptr), _ptr(f),

@@ -55,7 +55,7 @@ struct DeviceTables {
 
 template <typename T, int G, int MODE>
 hipError_t launch_one(const jxs::KParams<T>& P, const jxs::KArgs<T>& A, hipStream_t s) {
-  const int envs_per_wave = 64 / G;
+  const int envs_per_wave = 64 / G;  // = the tile of every batched array: block b owns tile b
   const int blocks = (A.N + envs_per_wave - 1) / envs_per_wave;
   hipLaunchKernelGGL((jxs_kernel<T, G, MODE>), dim3(blocks), dim3(64), 0, s, P, A);
   return hipGetLastError();
@@ -168,7 +168,9 @@ int run_typed(jxs_model* model, int mode, const void* state_in, void* state_out,
   a.out_V = static_cast<T*>(out_V);
   if (mode == jxs::MODE_STEP && state_out != state_in && mt->pk.n_disabled > 0) {
     // rows of disabled collidable points are not touched by the kernel: carry them over
-    JXS_HIP(hipMemcpyAsync(state_out, state_in, sizeof(T) * (size_t)mt->pk.P.n_rows * N, hipMemcpyDeviceToDevice, s));
+    const int tile = 64 / mt->pk.G;
+    const size_t elems = (size_t)((N + tile - 1) / tile) * tile * mt->pk.P.n_rows;
+    JXS_HIP(hipMemcpyAsync(state_out, state_in, sizeof(T) * elems, hipMemcpyDeviceToDevice, s));
   }
   a.dbg = g_dbg;
   for (int it = 0; it < repeat; ++it) {
@@ -342,7 +344,7 @@ int jxs_model_layout(const jxs_model* model, jxs_layout* out) {
   auto fill = [&](const auto& pk) {
     const auto& P = pk.P;
     *out = jxs_layout{P.nL, P.n, P.n_points, P.n_rows, P.row_pos, P.row_quat, P.row_s,
-                      P.row_vlin, P.row_vang, P.row_sd, P.row_m, pk.G, model->dtype};
+                      P.row_vlin, P.row_vang, P.row_sd, P.row_m, pk.G, 64 / pk.G, model->dtype};
   };
   if (model->dtype == JXS_F64) fill(model->f64->pk); else fill(model->f32->pk);
   return JXS_OK;

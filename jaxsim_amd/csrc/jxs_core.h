@@ -110,23 +110,23 @@ struct Core {
     }
     // state (row D)
     const VI jrow_c = vsel(jrow >= 0, jrow, lane * 0);
-    V s = ln.gload(A.state_in, jrow_c + P.row_s);
-    V sd = ln.gload(A.state_in, jrow_c + P.row_sd);
+    V s = ln.gload(A.state_in, jrow_c + P.row_s, P.n_rows);
+    V sd = ln.gload(A.state_in, jrow_c + P.row_sd, P.n_rows);
     V pB[3], q[4], vW[3], om[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      pB[k] = ln.gload_u(A.state_in, P.row_pos + k);
-      vW[k] = ln.gload_u(A.state_in, P.row_vlin + k);
-      om[k] = ln.gload_u(A.state_in, P.row_vang + k);
+      pB[k] = ln.gload_u(A.state_in, P.row_pos + k, P.n_rows);
+      vW[k] = ln.gload_u(A.state_in, P.row_vlin + k, P.n_rows);
+      om[k] = ln.gload_u(A.state_in, P.row_vang + k, P.n_rows);
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) q[k] = ln.gload_u(A.state_in, P.row_quat + k);
-    V tau = (A.tau != nullptr) ? ln.gload(A.tau, jrow_c) : V(T(0));
+    for (int k = 0; k < 4; ++k) q[k] = ln.gload_u(A.state_in, P.row_quat + k, P.n_rows);
+    V tau = (A.tau != nullptr) ? ln.gload(A.tau, jrow_c, P.n) : V(T(0));
     V f6in[6];
     if (A.link_f != nullptr) {
       const VI lrow = vsel(lnk >= 0, lnk, lane * 0) * 6;
 #pragma unroll
-      for (int k = 0; k < 6; ++k) f6in[k] = ln.gload(A.link_f, lrow + k);
+      for (int k = 0; k < 6; ++k) f6in[k] = ln.gload(A.link_f, lrow + k, P.nL * 6);
     }
     // collidable-point tables of chunk 0 (further chunks are loaded inside the contact loop)
     PointSlot ps0;
@@ -590,10 +590,10 @@ struct Core {
       cross(aca, pB, t);
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        ln.gstore(A.out_a, lane * 0 + k, acl[k] - t[k], is_root);
-        ln.gstore(A.out_a, lane * 0 + (3 + k), aca[k], is_root);
+        ln.gstore(A.out_a, lane * 0 + k, acl[k] - t[k], is_root, 6 + P.n);
+        ln.gstore(A.out_a, lane * 0 + (3 + k), aca[k], is_root, 6 + P.n);
       }
-      ln.gstore(A.out_a, jrow + 6, sdd, is_joint);
+      ln.gstore(A.out_a, jrow + 6, sdd, is_joint, 6 + P.n);
       return;
     }
 
@@ -602,8 +602,8 @@ struct Core {
       const V dt = V(P.dt);
       const V sd_new = sd + dt * sdd;
       const V s_new = s + dt * sd_new;
-      ln.gstore(A.state_out, jrow + P.row_s, s_new, is_joint);
-      ln.gstore(A.state_out, jrow + P.row_sd, sd_new, is_joint);
+      ln.gstore(A.state_out, jrow + P.row_s, s_new, is_joint, P.n_rows);
+      ln.gstore(A.state_out, jrow + P.row_sd, sd_new, is_joint, P.n_rows);
       // base: w+ = w + dt wdot ; pdot = (v_W + dt a_W) + w+ x p_B = vBc + dt a_lin^C
       V omn[3], pd[3], t[3], vWn[3];
       cross(aca, pB, t);
@@ -627,12 +627,12 @@ struct Core {
       const V invn = vrcp(vsel(nn == V(T(0)), V(T(1)), nn));
       const VI zl = lane * 0;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) ln.gstore(A.state_out, zl + (P.row_quat + k), qn[k] * invn, is_root);
+      for (int k = 0; k < 4; ++k) ln.gstore(A.state_out, zl + (P.row_quat + k), qn[k] * invn, is_root, P.n_rows);
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        ln.gstore(A.state_out, zl + (P.row_pos + k), pB[k] + dt * pd[k], is_root);
-        ln.gstore(A.state_out, zl + (P.row_vlin + k), vWn[k], is_root);
-        ln.gstore(A.state_out, zl + (P.row_vang + k), omn[k], is_root);
+        ln.gstore(A.state_out, zl + (P.row_pos + k), pB[k] + dt * pd[k], is_root, P.n_rows);
+        ln.gstore(A.state_out, zl + (P.row_vlin + k), vWn[k], is_root, P.n_rows);
+        ln.gstore(A.state_out, zl + (P.row_vang + k), omn[k], is_root, P.n_rows);
       }
     }
     ln.stamp(A, 10);  // integrate + stores issued
@@ -728,7 +728,7 @@ struct Core {
   JXS_HD void load_slot_state(PointSlot& ps) const {
     // empty slots carry row 0: the load is in range and its value is masked by `valid` later
 #pragma unroll
-    for (int k = 0; k < 3; ++k) ps.m[k] = ln.gload(A.state_in, ps.prow * 3 + (P.row_m + k));
+    for (int k = 0; k < 3; ++k) ps.m[k] = ln.gload(A.state_in, ps.prow * 3 + (P.row_m + k), P.n_rows);
   }
 
   JXS_HD void contacts(const VI& lane, const PointSlot& ps0, const V* R, const V* r, const V* vl, const V* va,
@@ -826,7 +826,7 @@ struct Core {
       }
 #pragma unroll
       for (int k = 0; k < 3; ++k)
-        ln.gstore(A.state_out, prow * 3 + (P.row_m + k), m[k] + P.dt * md[k], valid);
+        ln.gstore(A.state_out, prow * 3 + (P.row_m + k), m[k] + P.dt * md[k], valid, P.n_rows);
       // wrench in C: [f; r_C x f]  (W_f = [f; p x f], soft.py:377-388, moved to the C origin)
       V w6[6];
       w6[0] = vsel(valid, ft[0], zero);
@@ -874,7 +874,7 @@ struct Core {
                    const V* pB) const {
     const V zero = V(T(0));
     const VI jrow_c = vsel(jrow >= 0, jrow, lane * 0);
-    const V sdd = (A.in_a != nullptr) ? vsel(is_joint, ln.gload(A.in_a, jrow_c + 6), zero) : zero;
+    const V sdd = (A.in_a != nullptr) ? vsel(is_joint, ln.gload(A.in_a, jrow_c + 6, 6 + P.n), zero) : zero;
     // base acceleration in C: a_0 = (Wdot_v - W_g) moved to the C origin (floating) or -W_g
     V al[3], aa[3];
     {
@@ -882,8 +882,8 @@ struct Core {
       if (P.floating && A.in_a != nullptr) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-          wl[k] = ln.gload_u(A.in_a, k);
-          wa[k] = ln.gload_u(A.in_a, 3 + k);
+          wl[k] = ln.gload_u(A.in_a, k, 6 + P.n);
+          wa[k] = ln.gload_u(A.in_a, 3 + k, 6 + P.n);
         }
       }
       V t[3];
@@ -948,15 +948,15 @@ struct Core {
       }
     }
     V tq = Sl[0] * f6[0] + Sl[1] * f6[1] + Sl[2] * f6[2] + Sa[0] * f6[3] + Sa[1] * f6[4] + Sa[2] * f6[5];
-    ln.gstore(A.out_a, jrow + 6, tq, is_joint);
+    ln.gstore(A.out_a, jrow + 6, tq, is_joint, 6 + P.n);
     // W_f0 = B_X_W^T f_0: move the base wrench from the C origin back to the world origin
     V t[3];
     cross(pB, f6, t);
     const VI zl = lane * 0;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      ln.gstore(A.out_a, zl + k, f6[k], is_root);
-      ln.gstore(A.out_a, zl + (3 + k), f6[3 + k] + t[k], is_root);
+      ln.gstore(A.out_a, zl + k, f6[k], is_root, 6 + P.n);
+      ln.gstore(A.out_a, zl + (3 + k), f6[3 + k] + t[k], is_root, 6 + P.n);
     }
   }
 
@@ -999,15 +999,15 @@ struct Core {
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
 #pragma unroll
-        for (int j = 0; j < 3; ++j) ln.gstore(A.out_H, lnk * 12 + (4 * i + j), R[3 * i + j], is_link);
-        ln.gstore(A.out_H, lnk * 12 + (4 * i + 3), p[i], is_link);
+        for (int j = 0; j < 3; ++j) ln.gstore(A.out_H, lnk * 12 + (4 * i + j), R[3 * i + j], is_link, P.nL * 12);
+        ln.gstore(A.out_H, lnk * 12 + (4 * i + 3), p[i], is_link, P.nL * 12);
       }
     }
     if (A.out_V != nullptr) {
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        ln.gstore(A.out_V, lnk * 6 + k, vlin[k], is_link);
-        ln.gstore(A.out_V, lnk * 6 + (3 + k), vang[k], is_link);
+        ln.gstore(A.out_V, lnk * 6 + k, vlin[k], is_link, P.nL * 6);
+        ln.gstore(A.out_V, lnk * 6 + (3 + k), vang[k], is_link, P.nL * 6);
       }
     }
   }

@@ -71,7 +71,7 @@ struct DeviceLanes {
   int lane_;    // lane within the group
   int base4_;   // (first wave lane of the group) * 4, for ds_bpermute byte addressing
   int env_;     // environment handled by this group
-  int envc_;    // the same, clamped into [0, N) for loads
+  int sub_;     // index of the environment inside its tile
   bool env_ok_;
   int N_;
 
@@ -81,7 +81,7 @@ struct DeviceLanes {
     base4_ = (wl & ~(G - 1)) << 2;
     env_ = blockIdx.x * (64 / G) + (wl / G);
     env_ok_ = env_ < N;
-    envc_ = env_ok_ ? env_ : N - 1;
+    sub_ = wl / G;
   }
 
   __device__ __forceinline__ VI lane() const { return lane_; }
@@ -164,12 +164,20 @@ struct DeviceLanes {
   __device__ __forceinline__ VI ploadi(const int* tbl, int field, int n_slots, int slot) const {
     return tbl[field * n_slots + slot];
   }
-  // [row][N] arrays at this group's environment.  Loads are unconditional (callers clamp the
-  // row and mask the value): no exec-mask branch, and every load can be issued up front.
-  __device__ __forceinline__ V gload(const T* base, int row) const { return base[(size_t)row * N_ + envc_]; }
-  __device__ __forceinline__ V gload_u(const T* base, int row) const { return base[(size_t)row * N_ + envc_]; }
-  __device__ __forceinline__ void gstore(T* base, int row, T val, bool mask) const {
-    if (mask && env_ok_) base[(size_t)row * N_ + env_] = val;
+  // Batched arrays are tile-interleaved: [N/T][rows][T] with T = 64/G environments per tile = the
+  // environments of ONE wave.  A wave therefore touches one contiguous
+  // rows*T*sizeof(T) span per array and a load instruction whose lanes read consecutive rows is
+  // fully coalesced.  Loads are unconditional (callers clamp the row and mask the value): no
+  // exec-mask branch, and every load can be issued up front.  Arrays are allocated in whole tiles,
+  // so the environments beyond N of the last tile are readable (their stores are masked).
+  static constexpr int TILE = 64 / G;
+  __device__ __forceinline__ size_t at(int row, int nrows) const {
+    return ((size_t)blockIdx.x * nrows + row) * TILE + sub_;
+  }
+  __device__ __forceinline__ V gload(const T* base, int row, int nrows) const { return base[at(row, nrows)]; }
+  __device__ __forceinline__ V gload_u(const T* base, int row, int nrows) const { return base[at(row, nrows)]; }
+  __device__ __forceinline__ void gstore(T* base, int row, T val, bool mask, int nrows) const {
+    if (mask && env_ok_) base[at(row, nrows)] = val;
   }
 };
 

@@ -152,8 +152,8 @@ class JaxSimModelData:
             tangential_deformation=m,
             dtype=np.dtype(dtype),
         )
-        runtime.require_device()
-        return JaxSimModelData(model, runtime.DeviceArray.from_host(block), velocity_representation, batched)
+        tile = runtime.device_model(model, dtype).layout.tile
+        return JaxSimModelData(model, runtime.DeviceArray.from_host(block, tile=tile), velocity_representation, batched)
 
     @staticmethod
     def zero(model, velocity_representation: VelRepr = VelRepr.Mixed, **kwargs) -> "JaxSimModelData":
@@ -163,11 +163,11 @@ class JaxSimModelData:
     @staticmethod
     def from_state_block(model, block: np.ndarray, velocity_representation=VelRepr.Mixed) -> "JaxSimModelData":
         """Wrap a host ``[rows, N]`` block (inertial-fixed base velocity) -- no conversion."""
-        runtime.require_device()
         lay = StateLayout.of(model)
         if block.shape[0] != lay.n_rows:
             raise ValueError((block.shape, lay.n_rows))
-        return JaxSimModelData(model, runtime.DeviceArray.from_host(block), velocity_representation, True)
+        tile = runtime.device_model(model, block.dtype).layout.tile
+        return JaxSimModelData(model, runtime.DeviceArray.from_host(block, tile=tile), velocity_representation, True)
 
     # -- host views ---------------------------------------------------------------------------
     @property
@@ -278,8 +278,8 @@ class JaxSimModelData:
             model = self._model_ref
             dm = runtime.device_model(model, self.dtype)
             nL, N = model.number_of_links(), self.batch_size
-            H = runtime.DeviceArray(nL * 12, N, self.dtype)
-            V = runtime.DeviceArray(nL * 6, N, self.dtype)
+            H = runtime.DeviceArray(nL * 12, N, self.dtype, tile=self._state.tile)
+            V = runtime.DeviceArray(nL * 6, N, self.dtype, tile=self._state.tile)
             _lib.check(
                 _lib.load().jxs_refresh_kinematics(
                     dm.handle, C.c_void_p(self._state.ptr), C.c_void_p(H.ptr), C.c_void_p(V.ptr), N, runtime._sp()
@@ -355,7 +355,9 @@ class JaxSimModelData:
             tangential_deformation=m,
             dtype=self.dtype,
         )
-        return JaxSimModelData(model, runtime.DeviceArray.from_host(block), self.velocity_representation, self._batched)
+        return JaxSimModelData(
+            model, runtime.DeviceArray.from_host(block, tile=self._state.tile), self.velocity_representation, self._batched
+        )
 
     def valid(self, model) -> bool:
         """Shape compatibility check (``src/jaxsim/api/data.py:525-549``)."""

@@ -60,11 +60,11 @@ class Communicator:
         return bytes(buf.raw)
 
     def all_gather(self, shard: runtime.DeviceArray) -> runtime.DeviceArray:
-        """Gather equal-sized ``[rows][n_local]`` shards into ``[world*rows][n_local]``."""
-        out = runtime.DeviceArray(shard.rows * self.world_size, shard.cols, shard.dtype)
+        """Gather equal-sized shards; the result stores rank r's tiles at ``[r]`` of ``[world][...]``."""
+        out = runtime.DeviceArray(shard.rows * self.world_size, shard.cols, shard.dtype, tile=shard.tile)
         _lib.check(
             _lib.load().jxs_allgather(
-                self.handle, C.c_void_p(shard.ptr), C.c_void_p(out.ptr), shard.rows * shard.cols,
+                self.handle, C.c_void_p(shard.ptr), C.c_void_p(out.ptr), shard.n_tiles * shard.rows * shard.tile,
                 _lib.dtype_code(shard.dtype), runtime._sp(),
             ),
             "jxs_allgather",
@@ -105,7 +105,9 @@ def all_gather_state_blocks_host(local_block: np.ndarray) -> np.ndarray:
 def all_gather_state(comm: Communicator, data) -> np.ndarray:
     """GPU path of the final concat: RCCL all-gather of the device state, returned on the
     host as one ``[rows, N_total]`` block (every rank gets the full batch)."""
-    gathered = comm.all_gather(data._state)
-    rows = data._state.rows
-    host = gathered.to_host().reshape(comm.world_size, rows, data._state.cols)
-    return concat_shards(host)
+    from .state import untile_block
+
+    st = data._state
+    gathered = comm.all_gather(st)  # storage: [world][n_tiles][rows][tile]
+    raw = gathered.to_host_raw().reshape(comm.world_size, -1)
+    return concat_shards(np.stack([untile_block(raw[r], st.rows, st.cols, st.tile) for r in range(comm.world_size)]))

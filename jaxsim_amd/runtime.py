@@ -97,12 +97,14 @@ class Event:
 
 
 class DeviceArray:
-    """A 2-D ``[rows][N]`` device array (N fastest) of float32/float64."""
+    """A logical ``[rows][N]`` device array of float32/float64 (batch index fastest), stored
+    tile-interleaved as ``[ceil(N/T)][rows][T]`` -- see ``state.tile_block``."""
 
-    def __init__(self, rows: int, cols: int, dtype, *, zero: bool = False):
-        self.rows, self.cols = int(rows), int(cols)
+    def __init__(self, rows: int, cols: int, dtype, *, tile: int, zero: bool = False):
+        self.rows, self.cols, self.tile = int(rows), int(cols), int(tile)
         self.dtype = np.dtype(dtype)
-        self.nbytes = self.rows * self.cols * self.dtype.itemsize
+        self.n_tiles = -(-self.cols // self.tile)
+        self.nbytes = self.n_tiles * self.tile * self.rows * self.dtype.itemsize
         self._bucket = max(self.nbytes, 1)
         lib = _lib.load()
         ptr = None
@@ -130,27 +132,38 @@ class DeviceArray:
             self.ptr = None
 
     @staticmethod
-    def from_host(a: np.ndarray, dtype=None) -> "DeviceArray":
+    def from_host(a: np.ndarray, *, tile: int, dtype=None) -> "DeviceArray":
+        """Upload a host ``[rows, N]`` array (tiling happens here, outside any timed loop)."""
+        from .state import tile_block
+
         a = np.ascontiguousarray(a, dtype=dtype or a.dtype)
         if a.ndim != 2:
             raise ValueError("expected a [rows, N] array")
-        out = DeviceArray(a.shape[0], a.shape[1], a.dtype)
+        out = DeviceArray(a.shape[0], a.shape[1], a.dtype, tile=tile)
+        flat = tile_block(a, tile)
         _lib.check(
-            _lib.load().jxs_memcpy_h2d(C.c_void_p(out.ptr), a.ctypes.data_as(C.c_void_p), out.nbytes, _sp()),
+            _lib.load().jxs_memcpy_h2d(C.c_void_p(out.ptr), flat.ctypes.data_as(C.c_void_p), out.nbytes, _sp()),
             "jxs_memcpy_h2d",
         )
         return out
 
-    def to_host(self) -> np.ndarray:
-        out = np.empty((self.rows, self.cols), dtype=self.dtype)
+    def to_host_raw(self) -> np.ndarray:
+        """Download the storage as is: ``[n_tiles, rows, tile]``."""
+        out = np.empty((self.n_tiles, self.rows, self.tile), dtype=self.dtype)
         _lib.check(
             _lib.load().jxs_memcpy_d2h(out.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr), self.nbytes, _sp()),
             "jxs_memcpy_d2h",
         )
         return out
 
+    def to_host(self) -> np.ndarray:
+        """Download as a host ``[rows, N]`` array."""
+        from .state import untile_block
+
+        return untile_block(self.to_host_raw().reshape(-1), self.rows, self.cols, self.tile)
+
     def copy(self) -> "DeviceArray":
-        out = DeviceArray(self.rows, self.cols, self.dtype)
+        out = DeviceArray(self.rows, self.cols, self.dtype, tile=self.tile)
         _lib.check(
             _lib.load().jxs_memcpy_d2d(C.c_void_p(out.ptr), C.c_void_p(self.ptr), self.nbytes, _sp()),
             "jxs_memcpy_d2d",

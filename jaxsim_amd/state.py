@@ -102,3 +102,23 @@ def unpack_state(layout: StateLayout, block: np.ndarray) -> dict[str, np.ndarray
         joint_velocities=block[L.row_sd : L.row_sd + L.n_joints].T.copy(),
         tangential_deformation=block[L.row_m :].T.reshape(N, L.n_points, 3).copy(),
     )
+
+
+def tile_block(block: np.ndarray, tile: int) -> np.ndarray:
+    """Host ``[rows, N]`` array -> the device storage order ``[ceil(N/T), rows, T]`` (flat).
+
+    ``T`` environments (those one wavefront processes, ``jxs_layout.tile``) are interleaved per row
+    so that a wave's rows are contiguous in HBM; the last tile is zero-padded."""
+    rows, N = block.shape
+    nt = -(-N // tile)
+    out = np.zeros((nt, rows, tile), dtype=block.dtype)
+    pad = np.zeros((rows, nt * tile), dtype=block.dtype)
+    pad[:, :N] = block
+    out[:] = pad.reshape(rows, nt, tile).transpose(1, 0, 2)
+    return out.reshape(-1)
+
+
+def untile_block(flat: np.ndarray, rows: int, N: int, tile: int) -> np.ndarray:
+    """Inverse of :func:`tile_block`."""
+    nt = -(-N // tile)
+    return np.ascontiguousarray(flat.reshape(nt, rows, tile).transpose(1, 0, 2).reshape(rows, nt * tile)[:, :N])

@@ -57,7 +57,10 @@ int run_typed(const jxs_model_desc* d, int mode, const void* state_in, void* sta
   a.out_V = static_cast<T*>(out_V);
   a.N = N;
   if (mode == jxs::MODE_STEP && state_out != state_in && pk.n_disabled > 0)
-    std::memcpy(state_out, state_in, sizeof(T) * (size_t)pk.P.n_rows * N);
+{
+    const int tile = 64 / pk.G;
+    std::memcpy(state_out, state_in, sizeof(T) * (size_t)((N + tile - 1) / tile) * tile * pk.P.n_rows);
+  }
   switch (pk.G) {
     case 4: run_group<T, 4>(pk, a, mode); break;
     case 8: run_group<T, 8>(pk, a, mode); break;
@@ -84,7 +87,7 @@ int jxs_emul_layout(const jxs_model_desc* d, jxs_layout* out) {
   }
   const auto& P = pk.P;
   *out = jxs_layout{P.nL, P.n, P.n_points, P.n_rows, P.row_pos, P.row_quat, P.row_s,
-                    P.row_vlin, P.row_vang, P.row_sd, P.row_m, pk.G, d->dtype};
+                    P.row_vlin, P.row_vang, P.row_sd, P.row_m, pk.G, 64 / pk.G, d->dtype};
   return JXS_OK;
 }
 

@@ -188,15 +188,18 @@ struct HostLanes {
     for (int i = 0; i < G; ++i) r.v[i] = tbl[field * n_slots + slot.v[i]];
     return r;
   }
-  V gload(const T* base, const VI& row) const {
+  // tile-interleaved arrays: [N/TILE][rows][TILE], TILE = 64/G (see jxs_lanes_device.h)
+  static constexpr int TILE = 64 / G;
+  size_t at(int row, int nrows) const { return ((size_t)(env_ / TILE) * nrows + row) * TILE + (env_ % TILE); }
+  V gload(const T* base, const VI& row, int nrows) const {
     V r;
-    for (int i = 0; i < G; ++i) r.v[i] = base[(size_t)row.v[i] * N_ + env_];
+    for (int i = 0; i < G; ++i) r.v[i] = base[at(row.v[i], nrows)];
     return r;
   }
-  V gload_u(const T* base, int row) const { return V(base[(size_t)row * N_ + env_]); }
-  void gstore(T* base, const VI& row, const V& val, const VM& mask) const {
+  V gload_u(const T* base, int row, int nrows) const { return V(base[at(row, nrows)]); }
+  void gstore(T* base, const VI& row, const V& val, const VM& mask, int nrows) const {
     for (int i = 0; i < G; ++i)
-      if (mask.v[i]) base[(size_t)row.v[i] * N_ + env_] = val.v[i];
+      if (mask.v[i]) base[at(row.v[i], nrows)] = val.v[i];
   }
 };
 

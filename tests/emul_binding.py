@@ -13,6 +13,7 @@ import subprocess
 import numpy as np
 
 from jaxsim_amd import _lib
+from jaxsim_amd.state import tile_block, untile_block
 
 _HERE = pathlib.Path(__file__).resolve().parent
 _SRC = _HERE / "emul" / "jxs_emul.cpp"
@@ -66,20 +67,29 @@ def run(model, mode, state, *, tau=None, link_forces=None, force_repr=0, in_acc=
     d, keep = _lib.make_desc(model, dtype)
     N = state.shape[1]
     nL, n = model.number_of_links(), model.dofs()
-    c = lambda a: None if a is None else np.ascontiguousarray(a, dtype=dtype)  # noqa: E731
-    state, tau, link_forces, in_acc = c(state), c(tau), c(link_forces), c(in_acc)
-    state_out = state.copy() if mode == MODE_STEP else None
-    out_a = np.zeros((6 + n, N), dtype=dtype) if mode in (MODE_FD, MODE_ID) else None
-    out_H = np.zeros((nL * 12, N), dtype=dtype) if mode == MODE_KIN else None
-    out_V = np.zeros((nL * 6, N), dtype=dtype) if mode == MODE_KIN else None
+    tile = 64 // layout(model, dtype).group
+    nt = -(-N // tile)
+    rows_state = state.shape[0]
+
+    def up(a):  # host [rows, N] -> tiled storage
+        return None if a is None else tile_block(np.ascontiguousarray(a, dtype=dtype), tile)
+
+    def alloc(rows):
+        return np.zeros(nt * rows * tile, dtype=dtype)
+
+    st, tau, link_forces, in_acc = up(state), up(tau), up(link_forces), up(in_acc)
+    state_out = st.copy() if mode == MODE_STEP else None
+    out_a = alloc(6 + n) if mode in (MODE_FD, MODE_ID) else None
+    out_H = alloc(nL * 12) if mode == MODE_KIN else None
+    out_V = alloc(nL * 6) if mode == MODE_KIN else None
     rc = lib().jxs_emul_run(
-        C.byref(d), mode, _p(state), _p(state_out), _p(tau), _p(link_forces), int(force_repr), _p(in_acc),
+        C.byref(d), mode, _p(st), _p(state_out), _p(tau), _p(link_forces), int(force_repr), _p(in_acc),
         _p(out_a), _p(out_H), _p(out_V), N,
     )  # fmt: skip
     if rc != 0:
         raise RuntimeError(lib().jxs_emul_last_error().decode())
     if mode == MODE_STEP:
-        return state_out
+        return untile_block(state_out, rows_state, N, tile)
     if mode == MODE_KIN:
-        return out_H, out_V
-    return out_a
+        return untile_block(out_H, nL * 12, N, tile), untile_block(out_V, nL * 6, N, tile)
+    return untile_block(out_a, 6 + n, N, tile)

@@ -161,3 +161,17 @@ def test_product_never_imports_the_oracle():
     for py in root.rglob("*.py"):
         src = py.read_text()
         assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), py
+
+
+@pytest.mark.parametrize("tile", [1, 2, 4, 16])
+@pytest.mark.parametrize("N", [1, 5, 16, 33])
+def test_tile_interleaved_layout_round_trip(tile, N):
+    rows = 7
+    blk = np.arange(rows * N, dtype=np.float32).reshape(rows, N)
+    flat = st.tile_block(blk, tile)
+    nt = -(-N // tile)
+    assert flat.shape == (nt * rows * tile,)
+    # element (row, env) lives at ((env // T) * rows + row) * T + env % T   (include/jaxsim_amd.h)
+    for row, env in ((0, 0), (3, N - 1), (rows - 1, N // 2)):
+        assert flat[((env // tile) * rows + row) * tile + env % tile] == blk[row, env]
+    np.testing.assert_array_equal(st.untile_block(flat, rows, N, tile), blk)
