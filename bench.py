@@ -35,7 +35,15 @@ FLOPS_PER_ENV_STEP = 30e3  # structure-exploiting flop model, SURVEY.md section 
 # HBM-side bytes per launch from the rocprofv3 PMC passes committed under profiles/ (separate
 # --pmc FETCH_SIZE / WRITE_SIZE runs of this very command; FETCH_SIZE doubled as the microarch
 # guide prescribes for gfx950).  Only filled for the configuration that was profiled.
-TRAFFIC_BYTES_PER_LAUNCH = {("icub23", 1024, "float32"): None}
+def _profiled_traffic():
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc.json")) as f:
+            return {("icub23", 1024, "float32"): json.load(f).get("traffic_bytes_per_launch")}
+    except (OSError, ValueError):
+        return {}
+
+
+TRAFFIC_BYTES_PER_LAUNCH = _profiled_traffic()
 
 
 def parse_args():
@@ -47,7 +55,7 @@ def parse_args():
     ap.add_argument("--dtype", default="float32", choices=["float32", "float64"])
     ap.add_argument("--model", default="icub23", choices=["icub23", "icub23_16", "anymal12", "cartpole"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=10.0)
     return ap.parse_args()
 
 
@@ -126,14 +134,21 @@ def cpu_baseline(model, block, budget_s):
         if rate > best[0]:
             best = (rate, nt)
     rate, nt = best
-    # second calibration at the chosen team size (the 24-step probes are dominated by start-up)
-    t0 = time.perf_counter()
-    cport.step(model, block, n_steps=400, n_threads=nt)
-    rate = max(rate, 400 * n_envs / (time.perf_counter() - t0))
-    n_steps = int(max(24, min(200000, budget_s * rate / n_envs)))
-    t0 = time.perf_counter()
-    cport.step(model, block, n_steps=n_steps, n_threads=nt)
-    dt = time.perf_counter() - t0
+    # time-boxed measurement at the chosen team size: chunks grow until one takes >= 1 s, then
+    # chunks are repeated until the budget is spent (the first, warm-up, chunk is not counted)
+    chunk = 500
+    while True:
+        t0 = time.perf_counter()
+        cport.step(model, block, n_steps=chunk, n_threads=nt)
+        if time.perf_counter() - t0 >= 1.0 or chunk >= 1 << 20:
+            break
+        chunk *= 2
+    n_steps, dt = 0, 0.0
+    while dt < budget_s:
+        t0 = time.perf_counter()
+        cport.step(model, block, n_steps=chunk, n_threads=nt)
+        dt += time.perf_counter() - t0
+        n_steps += chunk
     return {
         "value": n_steps * n_envs / dt,
         "unit": "env-steps/s",
@@ -255,6 +270,7 @@ def main():
                 "envs_per_gpu": n_local,
                 "global_batch": n_total,
                 "lanes_per_env": int(lay.group),
+                "aba_layout": "row-distributed (8 lanes per active link)" if lay.row_mode else "link per lane",
                 "parallelism": f"batch-sharded x{world}, no per-step communication",
             },
             "roofline": {

@@ -90,6 +90,7 @@ typedef struct jxs_layout {
   int32_t group; /* lanes per environment chosen for this model */
   int32_t tile;  /* T = 64 / group: environments per tile of every batched array */
   int32_t dtype;
+  int32_t row_mode; /* 1: ABA passes run row-distributed (8 lanes per active link), 0: link per lane */
 } jxs_layout;
 
 /* ---- library / device ---------------------------------------------------------------- */

@@ -67,7 +67,7 @@ class Layout(C.Structure):
 
     _fields_ = [(n, C.c_int32) for n in (
         "n_links", "n_joints", "n_points", "n_rows", "row_pos", "row_quat", "row_s", "row_vlin",
-        "row_vang", "row_sd", "row_m", "group", "tile", "dtype")]  # fmt: skip
+        "row_vang", "row_sd", "row_m", "group", "tile", "dtype", "row_mode")]  # fmt: skip
 
 
 def dtype_code(dtype) -> int:

@@ -39,7 +39,8 @@ int hip_fail(hipError_t e, const char* what) {
 
 template <typename T, int G, int MODE>
 __global__ __launch_bounds__(64) void jxs_kernel(const jxs::KParams<T> P, const jxs::KArgs<T> A) {
-  const jxs::DeviceLanes<T, G> ln(A.N);
+  extern __shared__ __align__(16) unsigned char jxs_smem[];
+  const jxs::DeviceLanes<T, G> ln(A.N, reinterpret_cast<T*>(jxs_smem), jxs::lds_words_per_env(G));
   jxs::Core<jxs::DeviceLanes<T, G>> core(P, A, ln);
   core.template run<MODE>();
 }
@@ -51,13 +52,16 @@ struct DeviceTables {
   T* ptf = nullptr;
   int* pti = nullptr;
   int* head = nullptr;
+  int* rti = nullptr;
 };
 
 template <typename T, int G, int MODE>
 hipError_t launch_one(const jxs::KParams<T>& P, const jxs::KArgs<T>& A, hipStream_t s) {
   const int envs_per_wave = 64 / G;  // = the tile of every batched array: block b owns tile b
   const int blocks = (A.N + envs_per_wave - 1) / envs_per_wave;
-  hipLaunchKernelGGL((jxs_kernel<T, G, MODE>), dim3(blocks), dim3(64), 0, s, P, A);
+  const bool rows = P.row_mode && (MODE == jxs::MODE_STEP || MODE == jxs::MODE_FD);
+  const size_t lds_bytes = rows ? sizeof(T) * (size_t)envs_per_wave * jxs::lds_words_per_env(G) : 0;
+  hipLaunchKernelGGL((jxs_kernel<T, G, MODE>), dim3(blocks), dim3(64), lds_bytes, s, P, A);
   return hipGetLastError();
 }
 
@@ -93,6 +97,7 @@ struct ModelT {
     (void)hipFree(dev.ptf);
     (void)hipFree(dev.pti);
     (void)hipFree(dev.head);
+    (void)hipFree(dev.rti);
   }
 
   template <typename U>
@@ -108,7 +113,8 @@ struct ModelT {
     if ((e = upload(&dev.lti, pk.lti)) != hipSuccess) return e;
     if ((e = upload(&dev.ptf, pk.ptf)) != hipSuccess) return e;
     if ((e = upload(&dev.pti, pk.pti)) != hipSuccess) return e;
-    return upload(&dev.head, pk.head);
+    if ((e = upload(&dev.head, pk.head)) != hipSuccess) return e;
+    return upload(&dev.rti, pk.rti);
   }
   jxs::KArgs<T> args(int N) const {
     jxs::KArgs<T> a{};
@@ -117,6 +123,7 @@ struct ModelT {
     a.ptf = dev.ptf;
     a.pti = dev.pti;
     a.head = dev.head;
+    a.rti = dev.rti;
     a.N = N;
     return a;
   }
@@ -344,7 +351,7 @@ int jxs_model_layout(const jxs_model* model, jxs_layout* out) {
   auto fill = [&](const auto& pk) {
     const auto& P = pk.P;
     *out = jxs_layout{P.nL, P.n, P.n_points, P.n_rows, P.row_pos, P.row_quat, P.row_s,
-                      P.row_vlin, P.row_vang, P.row_sd, P.row_m, pk.G, 64 / pk.G, model->dtype};
+                      P.row_vlin, P.row_vang, P.row_sd, P.row_m, pk.G, 64 / pk.G, model->dtype, P.row_mode};
   };
   if (model->dtype == JXS_F64) fill(model->f64->pk); else fill(model->f32->pk);
   return JXS_OK;

@@ -129,6 +129,9 @@ struct Core {
       for (int k = 0; k < 6; ++k) f6in[k] = ln.gload(A.link_f, lrow + k, P.nL * 6);
     }
     // collidable-point tables of chunk 0 (further chunks are loaded inside the contact loop)
+    RowTabs rt;
+    const bool with_rows = P.row_mode && (MODE == MODE_STEP || MODE == MODE_FD);
+    if (with_rows) load_row_tabs(rt);
     PointSlot ps0;
     const bool with_contacts = (MODE == MODE_STEP) && P.n_chunks > 0;
     if (with_contacts) load_slot_tables(lane, 0, ps0);
@@ -442,146 +445,158 @@ struct Core {
     const V c6[6] = {cl[0], cl[1], cl[2], ca[0], ca[1], ca[2]};
     ln.stamp(A, 6);  // inertia + bias
 
-    // Pass 2 (rbda/aba.py:184-224), leaves to base, one tree level per iteration.  In frame C
-    // the propagation X^T Ma X is the identity congruence: parents simply add.
-    V U[6], inv_d = V(T(0)), u = V(T(0));
-#pragma unroll
-    for (int k = 0; k < 6; ++k) U[k] = V(T(0));
-    const int first_level = P.floating ? 1 : 2;  // fixed base: nothing propagates into link 0
-    const int max_depth = P.max_depth;
-    const unsigned long long mc0 = P.maxch_nib[0], mc1 = P.maxch_nib[1], mc2 = P.maxch_nib[2], mc3 = P.maxch_nib[3];
-    const unsigned long long nonadj = P.nonadj_levels;
-    for (int Lv = max_depth; Lv >= 1; --Lv) {
-      // U = MA S, d = S^T U, u = tau - S^T pA
-#pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        V acc = MA[sidx(i, 0)] * S6[0];
-#pragma unroll
-        for (int j = 1; j < 6; ++j) acc = acc + MA[sidx(i, j)] * S6[j];
-        U[i] = acc;
-      }
-      V d = U[0] * S6[0], sp = pA[0] * S6[0];
-#pragma unroll
-      for (int i = 1; i < 6; ++i) {
-        d = d + U[i] * S6[i];
-        sp = sp + pA[i] * S6[i];
-      }
-      u = tau - sp;
-      inv_d = vsel(is_joint, vrcp(d), V(T(0)));  // finite everywhere: base / padding lanes have d = 0
-      if (Lv < first_level) break;
-      // Ma = MA - U U^T / d ;  pa = pA + Ma c + U u / d
-      V Ma[21], pa[6], Ud[6];
-#pragma unroll
-      for (int i = 0; i < 6; ++i) Ud[i] = U[i] * inv_d;
-#pragma unroll
-      for (int i = 0; i < 6; ++i)
-#pragma unroll
-        for (int j = i; j < 6; ++j) Ma[sidx(i, j)] = MA[sidx(i, j)] - Ud[i] * U[j];
-#pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        V acc = pA[i] + Ud[i] * u;
-#pragma unroll
-        for (int j = 0; j < 6; ++j) acc = acc + Ma[sidx(i, j)] * c6[j];
-        pa[i] = acc;
-      }
-      // parents at level Lv-1 gather from their children (all at level Lv).  In the depth-first
-      // lane order the first child sits in lane+1: a DPP lane shift, no LDS round trip.
-      const VM is_par = level == (Lv - 1);
-      const unsigned long long mcw = Lv < 16 ? mc0 : Lv < 32 ? mc1 : Lv < 48 ? mc2 : mc3;
-      const int nch = (int)((mcw >> ((Lv & 15) * 4)) & 15ull);
-      if (nch >= 1) {
-        const V okf = vsel(is_par && (child[0] >= 0), V(T(1)), V(T(0)));
-        // 27 values = 3 blocks of 9 fused "acc += value(lane+1) * okf"
-        V acc9[9], src9[9];
-        ln.fmac9_from_next(MA, Ma, okf);
-        ln.fmac9_from_next(MA + 9, Ma + 9, okf);
-#pragma unroll
-        for (int e = 0; e < 3; ++e) {
-          acc9[e] = MA[18 + e];
-          src9[e] = Ma[18 + e];
-        }
-#pragma unroll
-        for (int e = 0; e < 6; ++e) {
-          acc9[3 + e] = pA[e];
-          src9[3 + e] = pa[e];
-        }
-        ln.fmac9_from_next(acc9, src9, okf);
-#pragma unroll
-        for (int e = 0; e < 3; ++e) MA[18 + e] = acc9[e];
-#pragma unroll
-        for (int e = 0; e < 6; ++e) pA[e] = acc9[3 + e];
-      }
-#pragma unroll
-      for (int k = 1; k < kMaxChildren; ++k) {
-        if (k < nch) {
-          // 1.0 where this lane is a parent of the current level with a k-th child, else 0.0
-          const V okf = vsel(is_par && (child[k] >= 0), V(T(1)), V(T(0)));
-          // issue all 27 shuffles back to back, wait once, then consume (Ma/pa are finite in
-          // every lane, see inv_d above, so masking by multiplication is safe)
-          V gM[21], gp[6];
-#pragma unroll
-          for (int e = 0; e < 21; ++e) gM[e] = ln.shfl(Ma[e], child[k]);
-#pragma unroll
-          for (int e = 0; e < 6; ++e) gp[e] = ln.shfl(pa[e], child[k]);
-          ln.fence();
-#pragma unroll
-          for (int e = 0; e < 21; ++e) MA[e] = MA[e] + okf * gM[e];
-#pragma unroll
-          for (int e = 0; e < 6; ++e) pA[e] = pA[e] + okf * gp[e];
-        }
-      }
-    }
-    ln.stamp(A, 7);  // pass 2
-
-    // Pass 3 (rbda/aba.py:240-267): base acceleration, then top-down.
-    V a6[6];
-    if (P.floating) {
-      solve6(MA, pA, a6);  // a0 = solve(-MA_0, pA_0), meaningful in the base lane only
-    } else {
-#pragma unroll
-      for (int k = 0; k < 6; ++k) a6[k] = V(T(0));
-      a6[2] = V(-P.g);  // a0 = -B_X_W W_g expressed in C
-    }
-    ln.stamp(A, 8);  // base solve
     V sdd = V(T(0));
-    const VM par_adjacent = parent == (lane - 1);
-    for (int Lv = 1; Lv <= max_depth; ++Lv) {
-      V ap[6];
-#pragma unroll
-      for (int k = 0; k < 6; ++k) ap[k] = ln.from_prev(a6[k]);  // parent in lane-1 (first children)
-      if ((nonadj >> Lv) & 1ull) {
-        V aq[6];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) aq[k] = ln.shfl(a6[k], parent);
-        ln.fence();
-#pragma unroll
-        for (int k = 0; k < 6; ++k) ap[k] = vsel(par_adjacent, ap[k], aq[k]);
-      }
-      const VM act = level == Lv;
-      V ai[6];
-#pragma unroll
-      for (int k = 0; k < 6; ++k) ai[k] = ap[k] + c6[k];
-      V ua = U[0] * ai[0];
-#pragma unroll
-      for (int k = 1; k < 6; ++k) ua = ua + U[k] * ai[k];
-      const V sdd_i = (u - ua) * inv_d;
-      sdd = vsel(act, sdd_i, sdd);
-#pragma unroll
-      for (int k = 0; k < 6; ++k) a6[k] = vsel(act, ai[k] + S6[k] * sdd_i, a6[k]);
-    }
-
-    // Base acceleration: W_a = a_0 + W_g (rbda/aba.py:284-292); the angular part is frame
-    // independent, the linear part is shifted back to the world origin at the end.
-    V acl[3], aca[3];  // base spatial acceleration in C (broadcast from the base lane)
-    {
-      const VI zero_lane = lane * 0;
+    V acl[3], aca[3];  // base spatial acceleration in C incl. gravity (valid in every lane)
+    if (P.row_mode && (MODE == MODE_STEP || MODE == MODE_FD)) {
+      V a0[6];
+      aba_rows(lane, rt, MA, pA, S6, c6, tau, sdd, a0);
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        acl[k] = P.floating ? ln.shfl(a6[k], zero_lane) : V(T(0));
-        aca[k] = P.floating ? ln.shfl(a6[3 + k], zero_lane) : V(T(0));
+        acl[k] = P.floating ? a0[k] : V(T(0));
+        aca[k] = P.floating ? a0[3 + k] : V(T(0));
       }
       if (P.floating) acl[2] = acl[2] + P.g;
+    } else {
+      // Pass 2 (rbda/aba.py:184-224), leaves to base, one tree level per iteration.  In frame C
+      // the propagation X^T Ma X is the identity congruence: parents simply add.
+      V U[6], inv_d = V(T(0)), u = V(T(0));
+  #pragma unroll
+      for (int k = 0; k < 6; ++k) U[k] = V(T(0));
+      const int first_level = P.floating ? 1 : 2;  // fixed base: nothing propagates into link 0
+      const int max_depth = P.max_depth;
+      const unsigned long long mc0 = P.maxch_nib[0], mc1 = P.maxch_nib[1], mc2 = P.maxch_nib[2], mc3 = P.maxch_nib[3];
+      const unsigned long long nonadj = P.nonadj_levels;
+      for (int Lv = max_depth; Lv >= 1; --Lv) {
+        // U = MA S, d = S^T U, u = tau - S^T pA
+  #pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          V acc = MA[sidx(i, 0)] * S6[0];
+  #pragma unroll
+          for (int j = 1; j < 6; ++j) acc = acc + MA[sidx(i, j)] * S6[j];
+          U[i] = acc;
+        }
+        V d = U[0] * S6[0], sp = pA[0] * S6[0];
+  #pragma unroll
+        for (int i = 1; i < 6; ++i) {
+          d = d + U[i] * S6[i];
+          sp = sp + pA[i] * S6[i];
+        }
+        u = tau - sp;
+        inv_d = vsel(is_joint, vrcp(d), V(T(0)));  // finite everywhere: base / padding lanes have d = 0
+        if (Lv < first_level) break;
+        // Ma = MA - U U^T / d ;  pa = pA + Ma c + U u / d
+        V Ma[21], pa[6], Ud[6];
+  #pragma unroll
+        for (int i = 0; i < 6; ++i) Ud[i] = U[i] * inv_d;
+  #pragma unroll
+        for (int i = 0; i < 6; ++i)
+  #pragma unroll
+          for (int j = i; j < 6; ++j) Ma[sidx(i, j)] = MA[sidx(i, j)] - Ud[i] * U[j];
+  #pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          V acc = pA[i] + Ud[i] * u;
+  #pragma unroll
+          for (int j = 0; j < 6; ++j) acc = acc + Ma[sidx(i, j)] * c6[j];
+          pa[i] = acc;
+        }
+        // parents at level Lv-1 gather from their children (all at level Lv).  In the depth-first
+        // lane order the first child sits in lane+1: a DPP lane shift, no LDS round trip.
+        const VM is_par = level == (Lv - 1);
+        const unsigned long long mcw = Lv < 16 ? mc0 : Lv < 32 ? mc1 : Lv < 48 ? mc2 : mc3;
+        const int nch = (int)((mcw >> ((Lv & 15) * 4)) & 15ull);
+        if (nch >= 1) {
+          const V okf = vsel(is_par && (child[0] >= 0), V(T(1)), V(T(0)));
+          // 27 values = 3 blocks of 9 fused "acc += value(lane+1) * okf"
+          V acc9[9], src9[9];
+          ln.fmac9_from_next(MA, Ma, okf);
+          ln.fmac9_from_next(MA + 9, Ma + 9, okf);
+  #pragma unroll
+          for (int e = 0; e < 3; ++e) {
+            acc9[e] = MA[18 + e];
+            src9[e] = Ma[18 + e];
+          }
+  #pragma unroll
+          for (int e = 0; e < 6; ++e) {
+            acc9[3 + e] = pA[e];
+            src9[3 + e] = pa[e];
+          }
+          ln.fmac9_from_next(acc9, src9, okf);
+  #pragma unroll
+          for (int e = 0; e < 3; ++e) MA[18 + e] = acc9[e];
+  #pragma unroll
+          for (int e = 0; e < 6; ++e) pA[e] = acc9[3 + e];
+        }
+  #pragma unroll
+        for (int k = 1; k < kMaxChildren; ++k) {
+          if (k < nch) {
+            // 1.0 where this lane is a parent of the current level with a k-th child, else 0.0
+            const V okf = vsel(is_par && (child[k] >= 0), V(T(1)), V(T(0)));
+            // issue all 27 shuffles back to back, wait once, then consume (Ma/pa are finite in
+            // every lane, see inv_d above, so masking by multiplication is safe)
+            V gM[21], gp[6];
+  #pragma unroll
+            for (int e = 0; e < 21; ++e) gM[e] = ln.shfl(Ma[e], child[k]);
+  #pragma unroll
+            for (int e = 0; e < 6; ++e) gp[e] = ln.shfl(pa[e], child[k]);
+            ln.fence();
+  #pragma unroll
+            for (int e = 0; e < 21; ++e) MA[e] = MA[e] + okf * gM[e];
+  #pragma unroll
+            for (int e = 0; e < 6; ++e) pA[e] = pA[e] + okf * gp[e];
+          }
+        }
+      }
+      ln.stamp(A, 7);  // pass 2
+
+      // Pass 3 (rbda/aba.py:240-267): base acceleration, then top-down.
+      V a6[6];
+      if (P.floating) {
+        solve6(MA, pA, a6);  // a0 = solve(-MA_0, pA_0), meaningful in the base lane only
+      } else {
+  #pragma unroll
+        for (int k = 0; k < 6; ++k) a6[k] = V(T(0));
+        a6[2] = V(-P.g);  // a0 = -B_X_W W_g expressed in C
+      }
+      ln.stamp(A, 8);  // base solve
+      const VM par_adjacent = parent == (lane - 1);
+      for (int Lv = 1; Lv <= max_depth; ++Lv) {
+        V ap[6];
+  #pragma unroll
+        for (int k = 0; k < 6; ++k) ap[k] = ln.from_prev(a6[k]);  // parent in lane-1 (first children)
+        if ((nonadj >> Lv) & 1ull) {
+          V aq[6];
+  #pragma unroll
+          for (int k = 0; k < 6; ++k) aq[k] = ln.shfl(a6[k], parent);
+          ln.fence();
+  #pragma unroll
+          for (int k = 0; k < 6; ++k) ap[k] = vsel(par_adjacent, ap[k], aq[k]);
+        }
+        const VM act = level == Lv;
+        V ai[6];
+  #pragma unroll
+        for (int k = 0; k < 6; ++k) ai[k] = ap[k] + c6[k];
+        V ua = U[0] * ai[0];
+  #pragma unroll
+        for (int k = 1; k < 6; ++k) ua = ua + U[k] * ai[k];
+        const V sdd_i = (u - ua) * inv_d;
+        sdd = vsel(act, sdd_i, sdd);
+  #pragma unroll
+        for (int k = 0; k < 6; ++k) a6[k] = vsel(act, ai[k] + S6[k] * sdd_i, a6[k]);
+      }
+
+      // Base acceleration: W_a = a_0 + W_g (rbda/aba.py:284-292); the angular part is frame
+      // independent, the linear part is shifted back to the world origin at the end.
+      {
+        const VI zero_lane = lane * 0;
+  #pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          acl[k] = P.floating ? ln.shfl(a6[k], zero_lane) : V(T(0));
+          aca[k] = P.floating ? ln.shfl(a6[3 + k], zero_lane) : V(T(0));
+        }
+        if (P.floating) acl[2] = acl[2] + P.g;
+      }
     }
+
     ln.stamp(A, 9);  // pass 3
 
     if (MODE == MODE_FD) {
@@ -702,6 +717,200 @@ struct Core {
   // (rbda/contacts/common.py:25-63), Hunt-Crossley + stick/slip state
   // (rbda/contacts/soft.py:195-388), per-link wrench sum (api/contact.py:557-603) and the
   // Euler update of the tangential deformation (api/integrators.py:67-71).
+  // ==========================================================================================
+  // Row-distributed ABA passes.  Pass 2 in the link-per-lane layout spends
+  // ~180 VALU per tree level with one lane in eight doing useful work (measured: 42 % of the
+  // step).  Here lane = 8*slot + row: the 8 lanes of a slot hold the rows of the articulated
+  // inertia of the ONE link that slot owns at the current level; link lanes publish
+  // (M, S, c, pA, tau) once through LDS, row lanes read their row per level.  A first child
+  // inherits its parent's slot, so along a chain "propagate to the parent" is a register add in
+  // the same lane; only extra children cross slots (one 7-value shuffle batch).  U = MA S is a
+  // column all-reduce over the 8 lanes (3 DPP adds per entry, MA symmetric).
+  struct RowTabs {
+    VI rec[kRowLevels], ppull[kRowLevels], pull[kRowLevels][kRowExtra], fcbits;
+  };
+  JXS_HD void load_row_tabs(RowTabs& rt) const {
+#pragma unroll
+    for (int Lv = 0; Lv < kRowLevels; ++Lv) {
+      rt.rec[Lv] = ln.lconsti(A.rti, RT_REC + Lv);
+      rt.ppull[Lv] = ln.lconsti(A.rti, RT_PPULL + Lv);
+#pragma unroll
+      for (int k = 0; k < kRowExtra; ++k) rt.pull[Lv][k] = ln.lconsti(A.rti, RT_PULL + Lv * kRowExtra + k);
+    }
+    rt.fcbits = ln.lconsti(A.rti, RT_FC);
+  }
+
+  struct RowLevel {
+    V Mrow[6], S[6], c[6], pr, S_r, c_r, tau;
+  };
+  JXS_HD void load_row_level(const VI& rec, const VI& row6, const VI& lane, RowLevel& o) const {
+    const VI base = vsel(rec >= 0, rec, lane * 0);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      o.Mrow[j] = ln.lds_read(base + row6 * 6 + (RL_M + j));
+      o.S[j] = ln.lds_read(base + (RL_S + j));
+      o.c[j] = ln.lds_read(base + (RL_C + j));
+    }
+    o.pr = ln.lds_read(base + row6 + RL_PA);
+    o.S_r = ln.lds_read(base + row6 + RL_S);
+    o.c_r = ln.lds_read(base + row6 + RL_C);
+    o.tau = ln.lds_read(base + RL_TAU);
+  }
+
+  JXS_HD void aba_rows(const VI& lane, const RowTabs& rt, const V* MA, const V* pA, const V* S6, const V* c6,
+                       const V& tau, V& sdd, V* a0) const {
+    const V zero = V(T(0));
+    const VI rec_me = lane * kRowRec;
+    // ---- link lanes publish their record -------------------------------------------------
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int j = 0; j < 6; ++j) ln.lds_write(rec_me + (RL_M + 6 * i + j), MA[sidx(i, j)]);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      ln.lds_write(rec_me + (RL_S + k), S6[k]);
+      ln.lds_write(rec_me + (RL_C + k), c6[k]);
+      ln.lds_write(rec_me + (RL_PA + k), pA[k]);
+    }
+    ln.lds_write(rec_me + RL_TAU, tau);
+    ln.lds_write(rec_me + RL_SDD, zero);
+    const int XB = G * kRowRec;  // base rows: [XB + 7 r + j], j < 6 inertia row, j = 6 bias force
+
+    const VI row = lane & 7;
+    const VM rowok = row < 6;
+    const VI row6 = vsel(rowok, row, lane * 0);
+    const int max_depth = P.max_depth;
+
+    // ---- pass 2, leaves to base (rbda/aba.py:184-224) -------------------------------------
+    // Wave-uniform flags are pinned in SGPRs up front (the compiler otherwise re-loads them from
+    // the kernel argument inside every level: one ~200-cycle scalar-load stall per level), and
+    // the LDS reads of level L-1 are issued before level L is computed (software pipelining).
+    const unsigned cross_levels = ln.pin(P.row_cross_levels);
+    const unsigned ppull_levels = ln.pin(P.row_ppull_levels);
+    const int floating = ln.pin(P.floating);
+    V Ur[kRowLevels], Sr[kRowLevels], cr[kRowLevels], invd[kRowLevels], uu[kRowLevels];
+    V accM[6], accp = zero, MA0[6], p0 = zero;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) accM[j] = zero, MA0[j] = zero;
+    RowLevel cur, nxt;
+    load_row_level(rt.rec[kRowLevels - 1], row6, lane, cur);
+#pragma unroll
+    for (int Lv = kRowLevels - 1; Lv >= 0; --Lv) {
+      Ur[Lv] = zero, Sr[Lv] = zero, cr[Lv] = zero, invd[Lv] = zero, uu[Lv] = zero;
+      if (Lv >= 1) load_row_level(rt.rec[Lv - 1], row6, lane, nxt);  // prefetch the next level
+      if (Lv <= max_depth && (Lv >= 1 || floating)) {
+        const VM has = rt.rec[Lv] >= 0;
+        const VM live = has && rowok;
+        V MArow[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) MArow[j] = vsel(live, cur.Mrow[j], zero) + accM[j];
+        const V pr = vsel(live, cur.pr, zero) + accp;
+        const V S_r = vsel(live, cur.S_r, zero);
+        const V c_r = vsel(live, cur.c_r, zero);
+        if (Lv == 0) {
+#pragma unroll
+          for (int j = 0; j < 6; ++j) MA0[j] = MArow[j];
+          p0 = pr;
+        } else {
+          // U = MA S in every lane of the slot: column sums over the rows (MA symmetric); the six
+          // reductions + the one of S^T pA advance stage by stage so that no DPP waits on its source
+          V red[7];
+#pragma unroll
+          for (int j = 0; j < 6; ++j) red[j] = MArow[j] * S_r;
+          red[6] = S_r * pr;
+          ln.allreduce8x7(red);
+          const V* U = red;
+          V U_r = MArow[0] * cur.S[0], d = cur.S[0] * U[0];
+#pragma unroll
+          for (int j = 1; j < 6; ++j) {
+            U_r = U_r + MArow[j] * cur.S[j];
+            d = d + cur.S[j] * U[j];
+          }
+          const V u = cur.tau - red[6];
+          const V inv = vsel(has, vrcp(vsel(has, d, V(T(1)))), zero);
+          const V Ud = U_r * inv;
+          V Ma[6], pa = pr + Ud * u;
+#pragma unroll
+          for (int j = 0; j < 6; ++j) {
+            Ma[j] = MArow[j] - Ud * U[j];
+            pa = pa + Ma[j] * cur.c[j];
+          }
+          Ur[Lv] = U_r, Sr[Lv] = S_r, cr[Lv] = c_r, invd[Lv] = inv, uu[Lv] = u;
+          // propagate: first children stay in their lanes, extra children are pulled by the
+          // parent's lanes.  A fixed base receives nothing (rbda/aba.py:217-222).
+          if (Lv >= 2 || floating) {
+            const VM fc = ((rt.fcbits >> Lv) & 1) != 0;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) accM[j] = vsel(fc, Ma[j], zero);
+            accp = vsel(fc, pa, zero);
+            if ((cross_levels >> Lv) & 1u) {
+#pragma unroll
+              for (int k = 0; k < kRowExtra; ++k) {
+                const VI src = rt.pull[Lv][k];
+                const VM ok = src >= 0;
+                V g[7];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) g[j] = ln.shfl(Ma[j], src);
+                g[6] = ln.shfl(pa, src);
+                ln.fence();
+#pragma unroll
+                for (int j = 0; j < 6; ++j) accM[j] = accM[j] + vsel(ok, g[j], zero);
+                accp = accp + vsel(ok, g[6], zero);
+              }
+            }
+          }
+        }
+      }
+      cur = nxt;
+    }
+
+    ln.stamp(A, 7);  // pass 2 (row-distributed)
+    // ---- base acceleration (rbda/aba.py:240-243) --------------------------------------------
+    if (floating) {
+      // the six row lanes of slot 0 publish the base rows; every lane then solves the same 6x6
+#pragma unroll
+      for (int j = 0; j < 6; ++j) ln.lds_write(row6 * 7 + (XB + j), MA0[j], lane < 6);
+      ln.lds_write(row6 * 7 + (XB + 6), p0, lane < 6);
+      V MAs[21], pAs[6];
+      const VI z = lane * 0;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+#pragma unroll
+        for (int j = i; j < 6; ++j) MAs[sidx(i, j)] = ln.lds_read(z + (XB + 7 * i + j));
+        pAs[i] = ln.lds_read(z + (XB + 7 * i + 6));
+      }
+      solve6(MAs, pAs, a0);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) a0[k] = zero;
+      a0[2] = V(-P.g);  // a0 = -B_X_W W_g expressed in C
+    }
+
+    ln.stamp(A, 8);  // base solve
+    // ---- pass 3, base to leaves (rbda/aba.py:251-267) -----------------------------------------
+    V acar = vsel(row == 0, a0[0], vsel(row == 1, a0[1], vsel(row == 2, a0[2],
+             vsel(row == 3, a0[3], vsel(row == 4, a0[4], vsel(row == 5, a0[5], zero))))));
+#pragma unroll
+    for (int Lv = 1; Lv < kRowLevels; ++Lv) {
+      if (Lv <= max_depth) {
+        const VM has = rt.rec[Lv] >= 0;
+        V apar = acar;
+        if ((ppull_levels >> Lv) & 1u) {
+          const V q = ln.shfl(acar, rt.ppull[Lv]);
+          ln.fence();
+          apar = vsel(rt.ppull[Lv] >= 0, q, acar);
+        }
+        V ai = apar + cr[Lv];
+        const V tot = ln.allreduce8(Ur[Lv] * ai);
+        const V sd = (uu[Lv] - tot) * invd[Lv];
+        ai = ai + Sr[Lv] * sd;
+        acar = vsel(has, ai, acar);
+        ln.lds_write(vsel(has, rt.rec[Lv], lane * 0) + RL_SDD, sd, has && (row == 0));
+      }
+    }
+    sdd = ln.lds_read(rec_me + RL_SDD);
+  }
+
   template <int OFF>
   JXS_HD void seg_step_dpp(const VI& tail, V* w6) const {
     const VM take = tail >= OFF;

@@ -74,14 +74,16 @@ struct DeviceLanes {
   int sub_;     // index of the environment inside its tile
   bool env_ok_;
   int N_;
+  T* lds_;      // LDS scratch of this environment (row-distributed ABA), else unused
 
-  __device__ __forceinline__ DeviceLanes(int N) : N_(N) {
+  __device__ __forceinline__ DeviceLanes(int N, T* lds_base, int lds_words_per_env) : N_(N) {
     const int wl = threadIdx.x & 63;
     lane_ = wl & (G - 1);
     base4_ = (wl & ~(G - 1)) << 2;
     env_ = blockIdx.x * (64 / G) + (wl / G);
     env_ok_ = env_ < N;
     sub_ = wl / G;
+    lds_ = lds_base + sub_ * lds_words_per_env;
   }
 
   __device__ __forceinline__ VI lane() const { return lane_; }
@@ -153,6 +155,42 @@ struct DeviceLanes {
 #pragma unroll
     for (int k = 0; k < 9; ++k) a[k] = a[k] + m * from_next(x[k]);
   }
+
+  // sum over the 8 lanes of a slot (row-distributed ABA), result in all 8: three DPP adds
+  __device__ __forceinline__ V allreduce8(V x) const {
+    x = x + dpp<0xB1>(x);   // quad_perm:[1,0,3,2]
+    x = x + dpp<0x4E>(x);   // quad_perm:[2,3,0,1]
+    x = x + dpp<0x141>(x);  // row_half_mirror
+    return x;
+  }
+  // seven independent 8-lane reductions advanced stage by stage: consecutive DPP instructions
+  // never read a register written by their predecessor (no s_nop between them)
+  __device__ __forceinline__ void allreduce8x7(V* x) const {
+#pragma unroll
+    for (int k = 0; k < 7; ++k) x[k] = x[k] + dpp<0xB1>(x[k]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 7; ++k) x[k] = x[k] + dpp<0x4E>(x[k]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 7; ++k) x[k] = x[k] + dpp<0x141>(x[k]);
+  }
+  // keep a wave-uniform kernel-argument value in an SGPR from here on
+  static __device__ __forceinline__ unsigned pin(unsigned x) {
+    asm volatile("" : "+s"(x));
+    return x;
+  }
+  static __device__ __forceinline__ int pin(int x) {
+    asm volatile("" : "+s"(x));
+    return x;
+  }
+  // LDS scratch of this group's environment (the workgroup is one wave: program order is the
+  // only synchronisation needed between a ds_write and a later ds_read of another lane)
+  __device__ __forceinline__ void lds_write(int addr, T v) const { lds_[addr] = v; }
+  __device__ __forceinline__ void lds_write(int addr, T v, bool mask) const {
+    if (mask) lds_[addr] = v;
+  }
+  __device__ __forceinline__ V lds_read(int addr) const { return lds_[addr]; }
 
   // per-lane model constants
   __device__ __forceinline__ V lconstf(const T* tbl, int field) const { return tbl[field * G + lane_]; }

@@ -4,6 +4,7 @@
 #pragma once
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <limits>
 #include <string>
 #include <vector>
@@ -22,6 +23,7 @@ struct Packed {
   std::vector<T> ptf;
   std::vector<int> pti;
   std::vector<int> head;
+  std::vector<int> rti;
   int n_disabled = 0;
 };
 
@@ -251,6 +253,67 @@ std::string pack_model(const jxs_model_desc& d, Packed<T>& out) {
       for (int t = s; t <= e; ++t) out.pti[(size_t)PI_TAIL * n_slots + t] = e - t;
       max_seg = std::max(max_seg, e - s + 1);
       s = e + 1;
+    }
+  }
+  // ---- row-distributed ABA tables ---------------------------------------------------------------
+  P.row_mode = 0;
+  P.row_cross_levels = 0;
+  P.row_ppull_levels = 0;
+  out.rti.assign((size_t)RT_COUNT * G, -1);
+  {
+    const int n_slots_row = G / 8;
+    bool ok = G >= 8 && max_depth < kRowLevels && max_depth >= 1;
+    if (std::getenv("JXS_DISABLE_ROW_MODE") != nullptr) ok = false;  // developer knob: A/B the two ABA layouts
+    std::vector<int> width(kRowLevels, 0);
+    for (int i = 0; ok && i < nL; ++i) {
+      if (++width[level[i]] > n_slots_row) ok = false;
+      if ((int)children[i].size() > 1 + kRowExtra) ok = false;
+    }
+    if (ok) {
+      // slots: a first child inherits its parent's slot, other children take the lowest free one
+      std::vector<int> slot(nL, -1);
+      std::vector<std::vector<int>> by_level(kRowLevels);
+      for (int lane = 0; lane < nL; ++lane) by_level[level[link_of[lane]]].push_back(link_of[lane]);  // DFS order
+      slot[0] = 0;
+      for (int L = 1; L <= max_depth; ++L) {
+        std::vector<char> used(n_slots_row, 0);
+        for (int i : by_level[L])
+          if (children[d.parent[i]][0] == i) {
+            slot[i] = slot[d.parent[i]];
+            used[slot[i]] = 1;
+          }
+        for (int i : by_level[L])
+          if (slot[i] < 0) {
+            int s2 = 0;
+            while (used[s2]) ++s2;
+            slot[i] = s2;
+            used[s2] = 1;
+          }
+      }
+      auto RI = [&](int f, int lane) -> int& { return out.rti[(size_t)f * G + lane]; };
+      for (int lane = 0; lane < G; ++lane) RI(RT_FC, lane) = 0;
+      for (int i = 0; i < nL; ++i) {
+        const int L = level[i], s2 = slot[i];
+        for (int r = 0; r < 8; ++r) {
+          const int lane = 8 * s2 + r;
+          RI(RT_REC + L, lane) = lane_of[i] * kRowRec;
+          if (i != 0) {
+            const int pi = d.parent[i];
+            if (children[pi][0] == i) {
+              RI(RT_FC, lane) |= 1 << L;  // same slot as the parent by construction
+            } else {
+              RI(RT_PPULL + L, lane) = 8 * slot[pi] + r;
+              P.row_ppull_levels |= 1u << L;
+              // the parent's lanes pull this child
+              int k = 0;
+              while (children[pi][k + 1] != i) ++k;
+              RI(RT_PULL + L * kRowExtra + k, 8 * slot[pi] + r) = lane;
+              P.row_cross_levels |= 1u << L;
+            }
+          }
+        }
+      }
+      P.row_mode = 1;
     }
   }
   int seg_steps = 0;

@@ -66,6 +66,25 @@ enum PointI : int {
 };
 // head[chunk * G + lane]: slot-lane of the first point of link `lane` in that chunk, -1 if none.
 
+// ---- row-distributed ABA: per-lane int table rti[field * G + lane] ---
+// In this phase lane = 8 * slot + row: the 8 lanes of a slot hold the 6 rows (2 idle) of the
+// articulated inertia of ONE link per tree level; a first child inherits its parent's slot, so a
+// serial chain never leaves its lanes.
+constexpr int kRowLevels = 8;     // tree levels 0..7 (deeper trees use the link-per-lane sweeps)
+constexpr int kRowExtra = 3;      // extra (non-first) children per link handled by cross-slot pulls
+constexpr int kRowRec = 57;       // LDS words per link record (odd stride: conflict-free b32 access)
+enum RowI : int {
+  RT_REC = 0,                         // [kRowLevels] LDS word offset of the record of link(L, slot), -1 if none
+  RT_FC = RT_REC + kRowLevels,        // bit L: link(L, slot) is the first child of link(L-1, slot)
+  RT_PULL = RT_FC + 1,                // [kRowLevels][kRowExtra] lane to pull an extra child (level L) from, -1
+  RT_PPULL = RT_PULL + kRowLevels * kRowExtra,  // [kRowLevels] lane holding the parent's row, -1 = same lane
+  RT_COUNT = RT_PPULL + kRowLevels
+};
+// LDS record layout (words): 0..35 M (6x6), 36..41 S, 42..47 c, 48..53 pA, 54 tau
+// exchange area after the G records: base rows 42 words, a0 6 words, sdd G words
+enum RowLds : int { RL_M = 0, RL_S = 36, RL_C = 42, RL_PA = 48, RL_TAU = 54, RL_SDD = 55 };
+JXS_HD constexpr int lds_words_per_env(int G) { return G * kRowRec + 48; }  // records + base rows (42) + pad
+
 enum Mode : int {
   MODE_STEP = 0,  // js.model.step                         api/model.py:2601-2681
   MODE_FD = 1,    // forward_dynamics_aba (no contacts)    api/model.py:1269-1406
@@ -84,6 +103,9 @@ struct KParams {
   unsigned long long maxch_nib[(kMaxDepth + 1) / 16];
   unsigned long long nonadj_levels;  // bit L: some link at level L has its parent in a lane != lane-1
   int seg_dpp_ok;                    // every (chunk, link) point segment lies inside one 16-lane row
+  int row_mode;                      // 1: ABA passes run row-distributed (tables in KArgs::rti)
+  unsigned int row_cross_levels;     // bit L: some parent pulls an extra child of level L across slots
+  unsigned int row_ppull_levels;     // bit L: some link of level L has its parent in another slot
   JXS_HD int maxch(int L) const {
     const unsigned long long w = L < 16 ? maxch_nib[0] : L < 32 ? maxch_nib[1] : L < 48 ? maxch_nib[2] : maxch_nib[3];
     return (int)((w >> ((L & 15) * 4)) & 15ull);
@@ -111,6 +133,7 @@ struct KArgs {
   const T* ptf;        // [PF_COUNT][n_slots]
   const int* pti;      // [PI_COUNT][n_slots]
   const int* head;     // [n_chunks][G]
+  const int* rti;      // [RT_COUNT][G] row-distributed ABA tables (row_mode only)
   const T* state_in;   // [n_rows][N]
   T* state_out;        // [n_rows][N] (may alias state_in)
   const T* tau;        // [n][N] or null            joint_force_references / joint_forces

@@ -23,6 +23,7 @@ void run_group(const jxs::Packed<T>& pk, jxs::KArgs<T> a, int mode) {
   a.ptf = pk.ptf.data();
   a.pti = pk.pti.data();
   a.head = pk.head.data();
+  a.rti = pk.rti.data();
   for (int env = 0; env < a.N; ++env) {
     jxs::HostLanes<T, G> ln(a.N, env);
     jxs::Core<jxs::HostLanes<T, G>> core(pk.P, a, ln);
@@ -87,7 +88,7 @@ int jxs_emul_layout(const jxs_model_desc* d, jxs_layout* out) {
   }
   const auto& P = pk.P;
   *out = jxs_layout{P.nL, P.n, P.n_points, P.n_rows, P.row_pos, P.row_quat, P.row_s,
-                    P.row_vlin, P.row_vang, P.row_sd, P.row_m, pk.G, 64 / pk.G, d->dtype};
+                    P.row_vlin, P.row_vang, P.row_sd, P.row_m, pk.G, 64 / pk.G, d->dtype, P.row_mode};
   return JXS_OK;
 }
 

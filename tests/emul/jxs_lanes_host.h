@@ -8,6 +8,7 @@
 #pragma once
 #include <cmath>
 #include <cstddef>
+#include <vector>
 
 #include "jxs_params.h"
 
@@ -28,7 +29,7 @@ struct Vec {
     for (int i = 0; i < G; ++i) r.v[i] = a.v[i] op b.v[i];    \
     return r;                                                 \
   }
-  JXS_BIN(+) JXS_BIN(-) JXS_BIN(*) JXS_BIN(/) JXS_BIN(&)
+  JXS_BIN(+) JXS_BIN(-) JXS_BIN(*) JXS_BIN(/) JXS_BIN(&) JXS_BIN(>>)
 #undef JXS_BIN
 #define JXS_CMP(op)                                              \
   friend Vec<bool, G> operator op(const Vec& a, const Vec& b) {  \
@@ -129,7 +130,8 @@ struct HostLanes {
 
   int env_;
   int N_;
-  HostLanes(int N, int env) : env_(env), N_(N) {}
+  mutable std::vector<T_> lds_;
+  HostLanes(int N, int env) : env_(env), N_(N), lds_((size_t)G_ * kRowRec + 64 + G_, T_(0)) {}
 
   VI lane() const {
     VI r;
@@ -157,6 +159,32 @@ struct HostLanes {
   V from_prev(const V& x) const {
     V r;
     for (int i = 0; i < G; ++i) r.v[i] = (i >= 1) ? x.v[i - 1] : T(0);
+    return r;
+  }
+  V allreduce8(const V& x) const {
+    V r;
+    for (int i = 0; i < G; ++i) {
+      T acc = T(0);
+      for (int k = 0; k < 8; ++k) acc += x.v[(i & ~7) + k];
+      r.v[i] = acc;
+    }
+    return r;
+  }
+  void allreduce8x7(V* x) const {
+    for (int k = 0; k < 7; ++k) x[k] = allreduce8(x[k]);
+  }
+  static unsigned pin(unsigned x) { return x; }
+  static int pin(int x) { return x; }
+  void lds_write(const VI& addr, const V& v) const {
+    for (int i = 0; i < G; ++i) lds_[addr.v[i]] = v.v[i];
+  }
+  void lds_write(const VI& addr, const V& v, const VM& mask) const {
+    for (int i = 0; i < G; ++i)
+      if (mask.v[i]) lds_[addr.v[i]] = v.v[i];
+  }
+  V lds_read(const VI& addr) const {
+    V r;
+    for (int i = 0; i < G; ++i) r.v[i] = lds_[addr.v[i]];
     return r;
   }
   void fmac9_from_next(V* a, const V* x, const V& m) const {

@@ -1,7 +1,7 @@
 """CPU parity: the kernel core (jaxsim_amd/csrc/jxs_core.h), compiled against the host
 lockstep lane backend, versus the oracle.  Same tables, same shuffles, same level loops as
 the gfx950 kernels -- only the lane backend differs -- so this is the -m "not gpu" check of
-the kernel *logic*.  Tolerances (helpers.py): fp64 1e-10, fp32 1e-3 relative to the fp64 oracle on the same inputs.
+the kernel *logic*.  Tolerances (helpers.py): fp64 1e-10, fp32 3e-3 worst-case relative to the fp64 oracle on the same inputs.
 """
 
 import numpy as np
