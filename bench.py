@@ -221,6 +221,19 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_ms(ev1) / max(args.steps, 1)  # HIP events on the launch stream
 
+    # secondary figure: the same K steps as ONE fused jxs_rollout launch (state in registers
+    # between steps; what jax.lax.fori_loop over step is to the reference).  Not the headline.
+    lib.jxs_rollout.argtypes  # noqa: B018  (declared in _lib)
+    rc = lib.jxs_rollout(dm.handle, state_ptr, None, None, 2, n_local, 10, stream.handle)
+    runtime.synchronize(stream)
+    ev2, ev3 = runtime.Event(), runtime.Event()
+    ev2.record(stream)
+    rc = rc or lib.jxs_rollout(dm.handle, state_ptr, None, None, 2, n_local, args.steps, stream.handle)
+    ev3.record(stream)
+    runtime.synchronize(stream)
+    _lib.check(rc, "jxs_rollout")
+    rollout_ms_per_step = ev2.elapsed_ms(ev3) / max(args.steps, 1)
+
     if dist is not None:
         import torch
 
@@ -289,6 +302,8 @@ def main():
             "nonfinite_envs_rank0": nonfinite_envs,
             "traffic_note": "rocprofv3 FETCH_SIZE/WRITE_SIZE per launch: profiles/ (see DESIGN.md section 6)",
             "allgather_ms": allgather_ms,
+            "fused_rollout": {"us_per_step": rollout_ms_per_step * 1e3, "env_steps_per_s_rank0": n_local / (rollout_ms_per_step * 1e-3),
+                              "note": "same steps as one jxs_rollout launch; secondary figure, not `value`"},
         }
         if world == 1 and not args.no_cpu_baseline:
             try:

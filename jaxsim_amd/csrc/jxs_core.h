@@ -64,6 +64,7 @@ struct Core {
   // ==========================================================================================
   template <int MODE>
   JXS_HD void run() {
+    constexpr bool kStep = (MODE == MODE_STEP || MODE == MODE_ROLLOUT);
     const VI lane = ln.lane();
     ln.stamp(A, 0);
 
@@ -96,7 +97,7 @@ struct Core {
 #pragma unroll
     for (int k = 0; k < 6; ++k) IL[k] = ln.lconstf(A.ltf, LF_ICOM + k);
     V smin, smax, klim, dlim, kc, kv;
-    if (MODE == MODE_STEP) {
+    if (kStep) {
       smin = ln.lconstf(A.ltf, LF_SMIN), smax = ln.lconstf(A.ltf, LF_SMAX);
       klim = ln.lconstf(A.ltf, LF_KLIM), dlim = ln.lconstf(A.ltf, LF_DLIM);
       kc = ln.lconstf(A.ltf, LF_KC), kv = ln.lconstf(A.ltf, LF_KV);
@@ -121,7 +122,7 @@ struct Core {
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) q[k] = ln.gload_u(A.state_in, P.row_quat + k, P.n_rows);
-    V tau = (A.tau != nullptr) ? ln.gload(A.tau, jrow_c, P.n) : V(T(0));
+    V tau_in = (A.tau != nullptr) ? ln.gload(A.tau, jrow_c, P.n) : V(T(0));
     V f6in[6];
     if (A.link_f != nullptr) {
       const VI lrow = vsel(lnk >= 0, lnk, lane * 0) * 6;
@@ -130,10 +131,10 @@ struct Core {
     }
     // collidable-point tables of chunk 0 (further chunks are loaded inside the contact loop)
     RowTabs rt;
-    const bool with_rows = P.row_mode && (MODE == MODE_STEP || MODE == MODE_FD);
+    const bool with_rows = P.row_mode && (kStep || MODE == MODE_FD);
     if (with_rows) load_row_tabs(rt);
     PointSlot ps0;
-    const bool with_contacts = (MODE == MODE_STEP) && P.n_chunks > 0;
+    const bool with_contacts = (kStep) && P.n_chunks > 0;
     if (with_contacts) load_slot_tables(lane, 0, ps0);
 
     const VM is_joint = jtype != 0;
@@ -142,13 +143,18 @@ struct Core {
     const VM is_root = level == 0;
     s = vsel(is_joint, s, V(T(0)));
     sd = vsel(is_joint, sd, V(T(0)));
-    tau = vsel(is_joint, tau, V(T(0)));
+    tau_in = vsel(is_joint, tau_in, V(T(0)));
     // Batch 2: the tangential deformation rows depend on the slot table just loaded.
     if (with_contacts) load_slot_state(ps0);
     ln.stamp(A, 1);  // tables + state arrived
 
+    // Fused rollout: `n_steps` consecutive steps with the state carried in registers -- tables,
+    // inputs and state are read once, the state is written once (jxs_rollout).  One step otherwise.
+    const int n_steps = (MODE == MODE_ROLLOUT) ? A.n_steps : 1;  // compile-time 1 for a plain step
+    for (int it = 0; it < n_steps; ++it) {
+    V tau = tau_in;
     // ---- B: joint torques (api/actuation_model.py:7-126) --------------------------------
-    if (MODE == MODE_STEP) {
+    if (kStep) {
       const V lower = vmin(s - smin, V(T(0)));  // clip(max=0)
       const V upper = vmax(s - smax, V(T(0)));  // clip(min=0)
       V tau_pl = -(klim * (lower + upper));
@@ -358,7 +364,7 @@ struct Core {
     }
 
     // ---- J,K,L,I: soft contacts ----------------------------------------------------------
-    if (with_contacts) contacts(lane, ps0, R, r, vl, va, pB, doff, vBc, om, fl, fa);
+    if (with_contacts) contacts(lane, ps0, R, r, vl, va, pB, doff, vBc, om, fl, fa);  // updates ps0.m
     ln.stamp(A, 5);  // contacts
 
     // ---- link inertia in C and bias force --------------------------------------------------
@@ -447,7 +453,7 @@ struct Core {
 
     V sdd = V(T(0));
     V acl[3], aca[3];  // base spatial acceleration in C incl. gravity (valid in every lane)
-    if (P.row_mode && (MODE == MODE_STEP || MODE == MODE_FD)) {
+    if (P.row_mode && (kStep || MODE == MODE_FD)) {
       V a0[6];
       aba_rows(lane, rt, MA, pA, S6, c6, tau, sdd, a0);
 #pragma unroll
@@ -615,18 +621,16 @@ struct Core {
     // ---- C: semi-implicit Euler (api/integrators.py:14-88) ---------------------------------
     {
       const V dt = V(P.dt);
-      const V sd_new = sd + dt * sdd;
-      const V s_new = s + dt * sd_new;
-      ln.gstore(A.state_out, jrow + P.row_s, s_new, is_joint, P.n_rows);
-      ln.gstore(A.state_out, jrow + P.row_sd, sd_new, is_joint, P.n_rows);
+      sd = sd + dt * sdd;
+      s = s + dt * sd;
       // base: w+ = w + dt wdot ; pdot = (v_W + dt a_W) + w+ x p_B = vBc + dt a_lin^C
-      V omn[3], pd[3], t[3], vWn[3];
+      V omn[3], pd[3], t[3];
       cross(aca, pB, t);
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         omn[k] = om[k] + dt * aca[k];
         pd[k] = vBc[k] + dt * acl[k];
-        vWn[k] = vW[k] + dt * (acl[k] - t[k]);
+        vW[k] = vW[k] + dt * (acl[k] - t[k]);
       }
       // Qdot = 1/2 Q_inertial(q) [K |w| (1 - |q|); w]   (math/quaternion.py:68-132)
       const V nw = vsqrt(omn[0] * omn[0] + omn[1] * omn[1] + omn[2] * omn[2]);
@@ -640,14 +644,33 @@ struct Core {
       qn[3] = q[3] + dt * half * (q[3] * h0 + q[2] * omn[0] - q[1] * omn[1] + q[0] * omn[2]);
       const V nn = vsqrt(qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3]);
       const V invn = vrcp(vsel(nn == V(T(0)), V(T(1)), nn));
-      const VI zl = lane * 0;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) ln.gstore(A.state_out, zl + (P.row_quat + k), qn[k] * invn, is_root, P.n_rows);
+      for (int k = 0; k < 4; ++k) q[k] = qn[k] * invn;
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        ln.gstore(A.state_out, zl + (P.row_pos + k), pB[k] + dt * pd[k], is_root, P.n_rows);
-        ln.gstore(A.state_out, zl + (P.row_vlin + k), vWn[k], is_root, P.n_rows);
-        ln.gstore(A.state_out, zl + (P.row_vang + k), omn[k], is_root, P.n_rows);
+        pB[k] = pB[k] + dt * pd[k];
+        om[k] = omn[k];
+      }
+    }
+    }  // fused step loop
+
+    // ---- write the state back once ---------------------------------------------------------------
+    {
+      const VI zl = lane * 0;
+      ln.gstore(A.state_out, jrow + P.row_s, s, is_joint, P.n_rows);
+      ln.gstore(A.state_out, jrow + P.row_sd, sd, is_joint, P.n_rows);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) ln.gstore(A.state_out, zl + (P.row_quat + k), q[k], is_root, P.n_rows);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        ln.gstore(A.state_out, zl + (P.row_pos + k), pB[k], is_root, P.n_rows);
+        ln.gstore(A.state_out, zl + (P.row_vlin + k), vW[k], is_root, P.n_rows);
+        ln.gstore(A.state_out, zl + (P.row_vang + k), om[k], is_root, P.n_rows);
+      }
+      if (with_contacts) {
+        const VM valid = ps0.body >= 0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) ln.gstore(A.state_out, ps0.prow * 3 + (P.row_m + k), ps0.m[k], valid, P.n_rows);
       }
     }
     ln.stamp(A, 10);  // integrate + stores issued
@@ -940,12 +963,12 @@ struct Core {
     for (int k = 0; k < 3; ++k) ps.m[k] = ln.gload(A.state_in, ps.prow * 3 + (P.row_m + k), P.n_rows);
   }
 
-  JXS_HD void contacts(const VI& lane, const PointSlot& ps0, const V* R, const V* r, const V* vl, const V* va,
+  JXS_HD void contacts(const VI& lane, PointSlot& ps0, const V* R, const V* r, const V* vl, const V* va,
                        const V* pB, const V* doff, const V* vBc, const V* om, V* fl, V* fa) const {
     const V zero = V(T(0));
     for (int ch = 0; ch < P.n_chunks; ++ch) {
       PointSlot ps = ps0;
-      if (ch > 0) {
+      if (ch > 0) {  // further chunks go through memory every step (rollouts are not fused then)
         load_slot_tables(lane, ch, ps);
         load_slot_state(ps);
       }
@@ -1035,7 +1058,11 @@ struct Core {
       }
 #pragma unroll
       for (int k = 0; k < 3; ++k)
-        ln.gstore(A.state_out, prow * 3 + (P.row_m + k), m[k] + P.dt * md[k], valid, P.n_rows);
+      {
+        const V m_new = m[k] + P.dt * md[k];
+        if (ch == 0) ps0.m[k] = m_new;  // chunk 0 is carried in registers and stored by run()
+        else ln.gstore(A.state_out, prow * 3 + (P.row_m + k), m_new, valid, P.n_rows);
+      }
       // wrench in C: [f; r_C x f]  (W_f = [f; p x f], soft.py:377-388, moved to the C origin)
       V w6[6];
       w6[0] = vsel(valid, ft[0], zero);

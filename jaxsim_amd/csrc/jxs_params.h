@@ -89,7 +89,8 @@ enum Mode : int {
   MODE_STEP = 0,  // js.model.step                         api/model.py:2601-2681
   MODE_FD = 1,    // forward_dynamics_aba (no contacts)    api/model.py:1269-1406
   MODE_ID = 2,    // inverse_dynamics / RNEA               api/model.py:1746-1894
-  MODE_KIN = 3    // cached kinematics of JaxSimModelData  api/data.py:405-523
+  MODE_KIN = 3,   // cached kinematics of JaxSimModelData  api/data.py:405-523
+  MODE_ROLLOUT = 4  // MODE_STEP repeated KArgs::n_steps times in one launch (state in registers)
 };
 
 enum ForceRepr : int { REPR_INERTIAL = 0, REPR_BODY = 1, REPR_MIXED = 2 };  // api/common.py:39-47
@@ -144,6 +145,7 @@ struct KArgs {
   T* out_H;            // MODE_KIN: [nL*12][N] rows of [R|p] per link (row-major 3x4)
   T* out_V;            // MODE_KIN: [nL*6][N] inertial-fixed link velocities
   int N;               // batch size (leading dimension of every [row][N] array)
+  int n_steps;         // MODE_STEP: consecutive steps fused in this launch (state carried in registers)
   long long* dbg;      // developer builds (-DJXS_PHASE_TIMING): [blocks][16] cycle stamps, else null
 };
 

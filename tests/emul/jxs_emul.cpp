@@ -31,6 +31,7 @@ void run_group(const jxs::Packed<T>& pk, jxs::KArgs<T> a, int mode) {
       case jxs::MODE_STEP: core.template run<jxs::MODE_STEP>(); break;
       case jxs::MODE_FD: core.template run<jxs::MODE_FD>(); break;
       case jxs::MODE_ID: core.template run<jxs::MODE_ID>(); break;
+      case jxs::MODE_ROLLOUT: core.template run<jxs::MODE_ROLLOUT>(); break;
       default: core.template run<jxs::MODE_KIN>(); break;
     }
   }
@@ -39,7 +40,7 @@ void run_group(const jxs::Packed<T>& pk, jxs::KArgs<T> a, int mode) {
 template <typename T>
 int run_typed(const jxs_model_desc* d, int mode, const void* state_in, void* state_out, const void* tau,
               const void* link_f, int force_repr, const void* in_a, void* out_a, void* out_H, void* out_V,
-              int N) {
+              int N, int n_steps) {
   jxs::Packed<T> pk;
   const std::string err = jxs::pack_model<T>(*d, pk);
   if (!err.empty()) {
@@ -57,11 +58,20 @@ int run_typed(const jxs_model_desc* d, int mode, const void* state_in, void* sta
   a.out_H = static_cast<T*>(out_H);
   a.out_V = static_cast<T*>(out_V);
   a.N = N;
+  a.n_steps = n_steps;
   if (mode == jxs::MODE_STEP && state_out != state_in && pk.n_disabled > 0)
 {
     const int tile = 64 / pk.G;
     std::memcpy(state_out, state_in, sizeof(T) * (size_t)((N + tile - 1) / tile) * tile * pk.P.n_rows);
   }
+  int launches = 1;
+  if (mode == jxs::MODE_STEP && n_steps > 1 && pk.P.n_chunks > 1) {  // like jxs_rollout: not fused
+    launches = n_steps;
+    a.n_steps = 1;
+  }
+  if (mode == jxs::MODE_STEP && a.n_steps > 1) mode = jxs::MODE_ROLLOUT;
+  for (int it = 0; it < launches; ++it) {
+    if (it == 1) a.state_in = a.state_out;
   switch (pk.G) {
     case 4: run_group<T, 4>(pk, a, mode); break;
     case 8: run_group<T, 8>(pk, a, mode); break;
@@ -69,6 +79,7 @@ int run_typed(const jxs_model_desc* d, int mode, const void* state_in, void* sta
     case 32: run_group<T, 32>(pk, a, mode); break;
     case 64: run_group<T, 64>(pk, a, mode); break;
     default: g_err = "bad group size"; return JXS_EINVAL;
+  }
   }
   return JXS_OK;
 }
@@ -94,9 +105,9 @@ int jxs_emul_layout(const jxs_model_desc* d, jxs_layout* out) {
 
 int jxs_emul_run(const jxs_model_desc* d, int mode, const void* state_in, void* state_out, const void* tau,
                  const void* link_f, int force_repr, const void* in_a, void* out_a, void* out_H, void* out_V,
-                 int N) {
+                 int N, int n_steps) {
   if (d->dtype == JXS_F64)
-    return run_typed<double>(d, mode, state_in, state_out, tau, link_f, force_repr, in_a, out_a, out_H, out_V, N);
-  return run_typed<float>(d, mode, state_in, state_out, tau, link_f, force_repr, in_a, out_a, out_H, out_V, N);
+    return run_typed<double>(d, mode, state_in, state_out, tau, link_f, force_repr, in_a, out_a, out_H, out_V, N, n_steps);
+  return run_typed<float>(d, mode, state_in, state_out, tau, link_f, force_repr, in_a, out_a, out_H, out_V, N, n_steps);
 }
 }

@@ -42,7 +42,7 @@ def lib():
         _emul.jxs_emul_last_error.restype = C.c_char_p
         vp = C.c_void_p
         _emul.jxs_emul_run.restype = C.c_int
-        _emul.jxs_emul_run.argtypes = [C.POINTER(_lib.ModelDesc), C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, C.c_int]
+        _emul.jxs_emul_run.argtypes = [C.POINTER(_lib.ModelDesc), C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int]
         _emul.jxs_emul_layout.restype = C.c_int
         _emul.jxs_emul_layout.argtypes = [C.POINTER(_lib.ModelDesc), C.POINTER(_lib.Layout)]
     return _emul
@@ -61,7 +61,7 @@ def layout(model, dtype=np.float64) -> _lib.Layout:
     return out
 
 
-def run(model, mode, state, *, tau=None, link_forces=None, force_repr=0, in_acc=None, dtype=None):
+def run(model, mode, state, *, tau=None, link_forces=None, force_repr=0, in_acc=None, dtype=None, n_steps=1):
     """Run one emulated launch.  All arrays are [rows, N] C-contiguous of the model dtype."""
     dtype = np.dtype(dtype or state.dtype)
     d, keep = _lib.make_desc(model, dtype)
@@ -84,7 +84,7 @@ def run(model, mode, state, *, tau=None, link_forces=None, force_repr=0, in_acc=
     out_V = alloc(nL * 6) if mode == MODE_KIN else None
     rc = lib().jxs_emul_run(
         C.byref(d), mode, _p(st), _p(state_out), _p(tau), _p(link_forces), int(force_repr), _p(in_acc),
-        _p(out_a), _p(out_H), _p(out_V), N,
+        _p(out_a), _p(out_H), _p(out_V), N, int(n_steps),
     )  # fmt: skip
     if rc != 0:
         raise RuntimeError(lib().jxs_emul_last_error().decode())

@@ -185,3 +185,17 @@ def test_unsupported_models_are_rejected(models):
     big = ja.JaxSimModel.build_from_model_description(robots.chain_urdf(70, fixed_base=True, seed=0))
     with pytest.raises(RuntimeError, match="64 links"):
         eb.layout(big)
+
+
+@pytest.mark.parametrize("name", ["cartpole", "chain9f", "anymal", "icub"])
+def test_fused_rollout_equals_repeated_steps(models, name):
+    """n_steps fused in one launch (state carried in registers) == n_steps single-step launches."""
+    model = models(name)
+    d = models.random_data(name, 3, seed=14)
+    tau, f = helpers.random_inputs(model, 3, 15, np.float64)
+    blk = helpers.odata_to_block(model, d)
+    kw = dict(tau=tau.T, link_forces=f.reshape(3, -1).T, force_repr=2)
+    fused = eb.run(model, eb.MODE_STEP, blk, n_steps=7, **kw)
+    for _ in range(7):
+        blk = eb.run(model, eb.MODE_STEP, blk, **kw)
+    np.testing.assert_array_equal(fused, blk)
