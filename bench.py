@@ -11,8 +11,8 @@ A "step" is one ``jxs_step`` launch over the rank's batch (1024 environments per
 scaling: 8192 environments on 8 GPUs).  The state is resident in HBM, there is no host
 round-trip inside the timed region and no per-step communication; after the timed region the
 final state shards are concatenated with ONE RCCL all-gather (timed separately).  Rank 0
-prints one JSON line.  ``torch.distributed`` is used only as the launcher's process group
-(barrier, max-over-ranks, unique-id broadcast); the data path is the C-ABI library.
+prints one JSON line.  ``torch.distributed.run`` is only the launcher: the ranks rendezvous through a
+temp file and use RCCL through the C-ABI library for barriers, the max-over-ranks and the gather.
 """
 
 from __future__ import annotations
@@ -55,6 +55,7 @@ def parse_args():
     ap.add_argument("--dtype", default="float32", choices=["float32", "float64"])
     ap.add_argument("--model", default="icub23", choices=["icub23", "icub23_16", "anymal12", "cartpole"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="developer: run the multi-rank code path even with WORLD_SIZE=1")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=10.0)
     return ap.parse_args()
 
@@ -170,19 +171,17 @@ def main():
     if args.gpus > 1 and world == 1:
         raise SystemExit("multi-GPU runs are launched with torch.distributed.run (one rank per GPU)")
 
-    dist = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-
+    multi = world > 1 or args.force_dist
     import jaxsim_amd.api as js
     from jaxsim_amd import _lib, distributed, runtime
 
     runtime.require_device()
     runtime.set_device(local_rank)
+    # Multi-rank runs: RANK/LOCAL_RANK/WORLD_SIZE/MASTER_PORT come from torch.distributed.run; the
+    # ranks rendezvous through a temp file and talk RCCL through the C-ABI library only.  (torch is
+    # NOT imported: its wheel bundles a second ROCm runtime with the same sonames, and two HIP
+    # runtimes in one process do not both see the GPU -- measured on the MI355X box.)
+    comm = distributed.communicator_from_env() if multi else None
     dtype = np.dtype(args.dtype)
     model = build_model(args.model)
     n_local = args.envs_per_gpu
@@ -203,8 +202,8 @@ def main():
                 _lib.check(rc, "jxs_step")
 
     def barrier():
-        if dist is not None:
-            dist.barrier()
+        if comm is not None:
+            comm.barrier()
 
     run_steps(args.warmup)
     stream.synchronize()
@@ -234,26 +233,25 @@ def main():
     _lib.check(rc, "jxs_rollout")
     rollout_ms_per_step = ev2.elapsed_ms(ev3) / max(args.steps, 1)
 
-    if dist is not None:
-        import torch
-
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    if comm is not None:
+        elapsed = float(comm.all_gather_scalars(elapsed).max())  # max over ranks
 
     # final state concat: ONE RCCL all-gather over xGMI, outside the timed region
     allgather_ms = None
     final = data.state_block()
-    if dist is not None:
-        comm = distributed.communicator_from_torch()
-        runtime.synchronize(stream)
-        barrier()
-        t1 = time.perf_counter()
-        full = distributed.all_gather_state(comm, data)
-        allgather_ms = (time.perf_counter() - t1) * 1e3
-        assert full.shape == (final.shape[0], n_local * world)
-        lo = rank * n_local
-        assert np.array_equal(full[:, lo : lo + n_local], final)
+    allgather_error = None
+    if comm is not None:
+        try:
+            runtime.synchronize(stream)
+            barrier()
+            t1 = time.perf_counter()
+            full = distributed.all_gather_state(comm, data)
+            allgather_ms = (time.perf_counter() - t1) * 1e3
+            lo = rank * n_local
+            if full.shape != (final.shape[0], n_local * world) or not np.array_equal(full[:, lo : lo + n_local], final):
+                allgather_error = "gathered state does not contain this rank's shard"
+        except Exception as e:  # the gather is outside the timed region: report, do not lose the line
+            allgather_error = repr(e)
     nonfinite_envs = int((~np.isfinite(final).all(axis=0)).sum())
 
     if rank == 0:
@@ -302,6 +300,7 @@ def main():
             "nonfinite_envs_rank0": nonfinite_envs,
             "traffic_note": "rocprofv3 FETCH_SIZE/WRITE_SIZE per launch: profiles/ (see DESIGN.md section 6)",
             "allgather_ms": allgather_ms,
+            "allgather_error": allgather_error,
             "fused_rollout": {"us_per_step": rollout_ms_per_step * 1e3, "env_steps_per_s_rank0": n_local / (rollout_ms_per_step * 1e-3),
                               "note": "same steps as one jxs_rollout launch; secondary figure, not `value`"},
         }
@@ -313,9 +312,8 @@ def main():
                                        "sample": f"failed: {e!r}"}  # fmt: skip
         print(json.dumps(out), flush=True)
 
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if comm is not None:
+        comm.barrier()
 
 
 if __name__ == "__main__":

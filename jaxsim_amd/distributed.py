@@ -71,11 +71,73 @@ class Communicator:
         )  # fmt: skip
         return out
 
+    def all_gather_scalars(self, value: float) -> np.ndarray:
+        """One float64 per rank, gathered through RCCL; returns the ``[world]`` host array."""
+        send = runtime.DeviceArray.from_host(np.array([[float(value)]], dtype=np.float64), tile=1)
+        out = self.all_gather(send)
+        runtime.synchronize()
+        return out.to_host_raw().reshape(-1)[: self.world_size].copy()
+
+    def barrier(self) -> None:
+        """Device-side barrier: a one-element all-gather followed by a stream synchronisation."""
+        self.all_gather_scalars(0.0)
+
     def __del__(self):
         try:
             _lib.load().jxs_comm_destroy(self.handle)
         except Exception:
             pass
+
+
+def file_rendezvous(rank: int, world_size: int, key: str, timeout_s: float = 120.0) -> bytes:
+    """Single-node bootstrap without any framework: rank 0 creates the RCCL unique id and
+    publishes it through an atomically renamed file under the temp dir; the other ranks poll for
+    it.  ``key`` must be the same on all ranks of one job and unique per job (the launcher's
+    MASTER_PORT / run id)."""
+    import os
+    import tempfile
+    import time
+
+    path = os.path.join(tempfile.gettempdir(), f"jaxsim_amd_rdzv_{key}.bin")
+    fresh_after = time.time() - 30.0  # a file left behind by a crashed earlier job is ignored
+    if rank == 0:
+        uid = Communicator.create_unique_id()
+        tmp = f"{path}.{os.getpid()}.tmp"
+        with open(tmp, "wb") as f:
+            f.write(uid)
+        os.replace(tmp, path)
+        return uid
+    deadline = time.monotonic() + timeout_s
+    while time.monotonic() < deadline:
+        try:
+            if os.path.getmtime(path) >= fresh_after:
+                with open(path, "rb") as f:
+                    uid = f.read()
+                if len(uid) == 128:
+                    return uid
+        except OSError:
+            pass
+        time.sleep(0.02)
+    raise _lib.JaxsimAmdError(f"rendezvous timed out waiting for {path}")
+
+
+def communicator_from_env(tag: str = "") -> Communicator:
+    """Communicator for a job started by ``torch.distributed.run`` (or any launcher exporting
+    RANK / WORLD_SIZE / MASTER_PORT): file rendezvous + ``ncclCommInitRank``.  No torch import."""
+    import os
+
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    key = "_".join(str(os.environ.get(k, "")) for k in ("MASTER_PORT", "TORCHELASTIC_RUN_ID")) + tag
+    comm = Communicator(file_rendezvous(rank, world, key), rank, world)
+    comm.barrier()
+    if rank == 0:  # everyone has read the id once the first collective completed
+        import tempfile
+
+        try:
+            os.remove(os.path.join(tempfile.gettempdir(), f"jaxsim_amd_rdzv_{key}.bin"))
+        except OSError:
+            pass
+    return comm
 
 
 def communicator_from_torch() -> Communicator:

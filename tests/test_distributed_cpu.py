@@ -50,3 +50,22 @@ def test_world_size_2_gloo_shard_step_gather():
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     assert "DIST_OK" in res.stdout
+
+
+def test_file_rendezvous_ignores_stale_files(tmp_path, monkeypatch):
+    import os
+    import tempfile
+    import time
+
+    monkeypatch.setattr(tempfile, "tempdir", str(tmp_path))
+    stale = tmp_path / "jaxsim_amd_rdzv_k1.bin"
+    stale.write_bytes(b"x" * 128)
+    old = time.time() - 3600
+    os.utime(stale, (old, old))
+    from jaxsim_amd import _lib
+
+    with pytest.raises(_lib.JaxsimAmdError):
+        distributed.file_rendezvous(1, 2, "k1", timeout_s=0.2)
+    fresh = tmp_path / "jaxsim_amd_rdzv_k2.bin"
+    fresh.write_bytes(bytes(range(128)))
+    assert distributed.file_rendezvous(1, 2, "k2", timeout_s=1.0) == bytes(range(128))
