@@ -181,7 +181,14 @@ def main():
     # ranks rendezvous through a temp file and talk RCCL through the C-ABI library only.  (torch is
     # NOT imported: its wheel bundles a second ROCm runtime with the same sonames, and two HIP
     # runtimes in one process do not both see the GPU -- measured on the MI355X box.)
-    comm = distributed.communicator_from_env() if multi else None
+    comm, comm_error = None, None
+    if multi:
+        try:
+            comm = distributed.communicator_from_env()
+        except Exception as e:  # keep the bench line: fall back to a host-side file collective
+            comm_error = repr(e)
+            key = "_".join(str(os.environ.get(k, "")) for k in ("MASTER_PORT", "TORCHELASTIC_RUN_ID"))
+            comm = distributed.FileCollective(rank, world, key)
     dtype = np.dtype(args.dtype)
     model = build_model(args.model)
     n_local = args.envs_per_gpu
@@ -242,6 +249,8 @@ def main():
     allgather_error = None
     if comm is not None:
         try:
+            if comm_error is not None:
+                raise RuntimeError(f"RCCL communicator unavailable: {comm_error}")
             runtime.synchronize(stream)
             barrier()
             t1 = time.perf_counter()

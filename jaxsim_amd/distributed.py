@@ -140,6 +140,48 @@ def communicator_from_env(tag: str = "") -> Communicator:
     return comm
 
 
+class FileCollective:
+    """Last-resort host collective for a single node (used by bench.py only if the RCCL
+    communicator cannot be created): barriers and scalar gathers through files in the temp dir."""
+
+    def __init__(self, rank: int, world_size: int, key: str):
+        import os
+        import tempfile
+
+        self.rank, self.world_size = int(rank), int(world_size)
+        self.dir = os.path.join(tempfile.gettempdir(), f"jaxsim_amd_fc_{key}")
+        os.makedirs(self.dir, exist_ok=True)
+        self.seq = 0
+
+    def all_gather_scalars(self, value: float, timeout_s: float = 300.0) -> np.ndarray:
+        import os
+        import time
+
+        self.seq += 1
+        mine = os.path.join(self.dir, f"{self.seq}_{self.rank}")
+        with open(mine + ".tmp", "w") as f:
+            f.write(repr(float(value)))
+        os.replace(mine + ".tmp", mine)
+        out = np.zeros(self.world_size)
+        deadline = time.monotonic() + timeout_s
+        for r in range(self.world_size):
+            path = os.path.join(self.dir, f"{self.seq}_{r}")
+            while True:
+                try:
+                    with open(path) as f:
+                        out[r] = float(f.read())
+                    break
+                except (OSError, ValueError):
+                    if time.monotonic() > deadline:
+                        raise _lib.JaxsimAmdError(f"file collective timed out on {path}") from None
+                    time.sleep(0.0002)
+        return out
+
+    def barrier(self) -> None:
+        runtime.synchronize()
+        self.all_gather_scalars(0.0)
+
+
 def communicator_from_torch() -> Communicator:
     """Bootstrap a ``Communicator`` from an initialised ``torch.distributed`` process group:
     rank 0 creates the RCCL unique id, the launcher's group broadcasts it."""

@@ -69,3 +69,23 @@ def test_file_rendezvous_ignores_stale_files(tmp_path, monkeypatch):
     fresh = tmp_path / "jaxsim_amd_rdzv_k2.bin"
     fresh.write_bytes(bytes(range(128)))
     assert distributed.file_rendezvous(1, 2, "k2", timeout_s=1.0) == bytes(range(128))
+
+
+def test_file_collective_two_ranks(tmp_path, monkeypatch):
+    import tempfile
+    import threading
+
+    monkeypatch.setattr(tempfile, "tempdir", str(tmp_path))
+    monkeypatch.setattr(distributed.runtime, "synchronize", lambda *a, **k: None)
+    out = {}
+
+    def worker(r):
+        fc = distributed.FileCollective(r, 2, "t")
+        fc.barrier()
+        out[r] = fc.all_gather_scalars(10.0 + r)
+
+    ts = [threading.Thread(target=worker, args=(r,)) for r in range(2)]
+    [t.start() for t in ts]
+    [t.join(30) for t in ts]
+    np.testing.assert_array_equal(out[0], [10.0, 11.0])
+    np.testing.assert_array_equal(out[1], [10.0, 11.0])
