@@ -77,9 +77,10 @@ typedef struct jxs_model_desc {
   double time_step;               /* api/model.py:54-56                                     */
   double gravity;                 /* signed z acceleration (-9.81)                          */
   double K, D, mu, p, q;          /* SoftContactsParams, rbda/contacts/soft.py:24-46        */
-  double terrain_height;          /* FlatTerrain, terrain/terrain.py:65-124                 */
+  double terrain_height;          /* Flat/PlaneTerrain height over the origin, terrain/terrain.py:65-238 */
   double torque_max, omega_th, omega_max; /* ActuationParams, rbda/actuation/common.py:16-19 */
   int32_t enable_friction;
+  double terrain_normal[3];       /* PlaneTerrain unit normal (terrain/terrain.py:127-238); (0,0,1) = FlatTerrain */
 } jxs_model_desc;
 
 typedef struct jxs_model jxs_model; /* opaque, immutable after creation, shareable */

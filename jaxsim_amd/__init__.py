@@ -9,6 +9,7 @@ from .model import (  # noqa: F401
     FlatTerrain,
     IntegratorType,
     JaxSimModel,
+    PlaneTerrain,
     SoftContacts,
     SoftContactsParams,
     VelRepr,

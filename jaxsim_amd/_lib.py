@@ -59,6 +59,7 @@ class ModelDesc(C.Structure):
         ("omega_th", C.c_double),
         ("omega_max", C.c_double),
         ("enable_friction", C.c_int32),
+        ("terrain_normal", C.c_double * 3),
     ]
 
 
@@ -135,6 +136,8 @@ def make_desc(model, dtype) -> tuple[ModelDesc, list]:
     ap = model.actuation_params
     d.torque_max, d.omega_th, d.omega_max = float(ap.torque_max), float(ap.omega_th), float(ap.omega_max)
     d.enable_friction = int(bool(ap.enable_friction))
+    nrm = getattr(model.terrain, "_normal", (0.0, 0.0, 1.0))
+    d.terrain_normal = (C.c_double * 3)(*[float(x) for x in nrm])
     return d, keep
 
 
@@ -144,7 +147,7 @@ def model_signature(model, dtype) -> tuple:
     cp, ap = model.contact_params, model.actuation_params
     return (
         id(kdp), np.dtype(dtype).str, model.time_step, model.gravity, model.floating_base(),
-        cp.K, cp.D, cp.mu, cp.p, cp.q, model.terrain._height,
+        cp.K, cp.D, cp.mu, cp.p, cp.q, model.terrain._height, tuple(getattr(model.terrain, "_normal", (0.0, 0.0, 1.0))),
         ap.torque_max, ap.omega_th, ap.omega_max, ap.enable_friction,
     )  # fmt: skip
 

@@ -1014,10 +1014,25 @@ struct Core {
 #pragma unroll
         for (int k = 0; k < 3; ++k) pd[k] = pd[k] + t[k];
       }
-      // penetration data, flat terrain: n = +z, h = [0,0,height - p_z]
-      const V delta = vmax(zero, V(P.terrain_h) - pw[2]);
+      // penetration data (rbda/contacts/common.py:25-63): h = [0,0,height(x,y) - p_z],
+      // delta = max(0, h.n); FlatTerrain: n = +z; PlaneTerrain: constant unit normal,
+      // height(x,y) = h0 - (A x + B y) / C  (terrain/terrain.py:180-215)
+      V delta, pdn, mdn;  // penetration, pdot.n, m.n
+      V nh[3];
+      if (P.flat) {
+        nh[0] = zero, nh[1] = zero, nh[2] = V(T(1));
+        delta = vmax(zero, V(P.terrain_h) - pw[2]);
+        pdn = pd[2];
+        mdn = m[2];
+      } else {
+        nh[0] = V(P.nrm[0]), nh[1] = V(P.nrm[1]), nh[2] = V(P.nrm[2]);
+        const V height = V(P.terrain_h) - (P.nrm[0] * pw[0] + P.nrm[1] * pw[1]) * (T(1) / P.nrm[2]);
+        delta = vmax(zero, (height - pw[2]) * P.nrm[2]);
+        pdn = pd[0] * nh[0] + pd[1] * nh[1] + pd[2] * nh[2];
+        mdn = m[0] * nh[0] + m[1] * nh[1] + m[2] * nh[2];
+      }
       const VM in_contact = delta > zero;
-      const V ddelta = vsel(in_contact, -pd[2], zero);
+      const V ddelta = vsel(in_contact, -pdn, zero);
       V dp, dq;
       if (P.pq_half) {
         dp = vsqrt(delta + P.eps);
@@ -1028,10 +1043,14 @@ struct Core {
       }
       const V Kdp = P.K * dp, Ddq = P.D * dq;
       const V fn = vmax(zero, Kdp * delta + Ddq * ddelta);
-      // tangential quantities (normal = +z)
-      const V vt[3] = {pd[0], pd[1], zero};
-      const V mn[3] = {zero, zero, m[2]};
-      const V mt[3] = {m[0], m[1], zero};
+      // tangential / normal split of the point velocity and of the deformation
+      V vt[3], mn[3], mt[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        vt[k] = pd[k] - pdn * nh[k];
+        mn[k] = mdn * nh[k];
+        mt[k] = m[k] - mn[k];
+      }
       V ft[3];
 #pragma unroll
       for (int k = 0; k < 3; ++k) ft[k] = -(Kdp * mt[k] + Ddq * vt[k]);
@@ -1065,9 +1084,9 @@ struct Core {
       }
       // wrench in C: [f; r_C x f]  (W_f = [f; p x f], soft.py:377-388, moved to the C origin)
       V w6[6];
-      w6[0] = vsel(valid, ft[0], zero);
-      w6[1] = vsel(valid, ft[1], zero);
-      w6[2] = vsel(valid, fn + ft[2], zero);
+      w6[0] = vsel(valid, fn * nh[0] + ft[0], zero);
+      w6[1] = vsel(valid, fn * nh[1] + ft[1], zero);
+      w6[2] = vsel(valid, fn * nh[2] + ft[2], zero);
       cross(rc, w6, w6 + 3);
       // segmented suffix-sum over the slots of one link (slots are sorted by link); when every
       // segment lies inside a 16-lane row the partner lane+off is reached by a DPP row shift

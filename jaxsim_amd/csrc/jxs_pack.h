@@ -40,6 +40,12 @@ std::string pack_model(const jxs_model_desc& d, Packed<T>& out) {
   if (nL < 1) return "n_links must be >= 1";
   if (nL > 64) return "models with more than 64 links are not supported (one link per lane of a wave)";
   if (d.parent[0] != -1) return "parent[0] must be -1";
+  {
+    const double* nn = d.terrain_normal;
+    const double n2 = nn[0] * nn[0] + nn[1] * nn[1] + nn[2] * nn[2];
+    if (std::fabs(n2 - 1.0) > 1e-9) return "terrain_normal must be a unit vector";
+    if (std::fabs(nn[2]) < 1e-12) return "the z component of the terrain normal cannot be zero";  // terrain.py:197-200
+  }
   for (int i = 1; i < nL; ++i) {
     if (d.parent[i] < 0 || d.parent[i] >= i) return "parent array must be topologically ordered (BFS indices)";
     if (d.joint_type[i] != 1 && d.joint_type[i] != 2) return "joint types must be revolute(1) or prismatic(2)";
@@ -139,6 +145,8 @@ std::string pack_model(const jxs_model_desc& d, Packed<T>& out) {
   P.K_over_D = (T)d.K / (T)d.D;
   P.pq_half = (d.p == 0.5 && d.q == 0.5) ? 1 : 0;
   P.terrain_h = (T)d.terrain_height;
+  for (int k = 0; k < 3; ++k) P.nrm[k] = (T)d.terrain_normal[k];
+  P.flat = (d.terrain_normal[0] == 0.0 && d.terrain_normal[1] == 0.0 && d.terrain_normal[2] == 1.0) ? 1 : 0;
   P.tau_max = (T)d.torque_max;
   P.w_th = (T)d.omega_th;
   P.w_max = (T)d.omega_max;

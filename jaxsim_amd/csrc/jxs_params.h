@@ -117,7 +117,9 @@ struct KParams {
   T dt, g;                       // time_step, signed z gravity          api/model.py:54-60
   T K, D, mu, p, q, K_over_D;    // SoftContactsParams                   rbda/contacts/soft.py:24-46
   int pq_half;                   // p == q == 0.5 -> sqrt instead of pow
-  T terrain_h;                   // FlatTerrain height                   terrain/terrain.py:65-124
+  T terrain_h;                   // terrain height over the origin       terrain/terrain.py:65-238
+  T nrm[3];                      // PlaneTerrain unit normal (0,0,1 for FlatTerrain)
+  int flat;                      // normal == +z: specialised contact arithmetic
   T tau_max, w_th, w_max;        // ActuationParams                      rbda/actuation/common.py:16-19
   T inv_w_range;                 // 1 / (w_max - w_th)
   int enable_friction;

@@ -103,6 +103,33 @@ class FlatTerrain:
         return n
 
 
+@dataclasses.dataclass
+class PlaneTerrain(FlatTerrain):
+    """``PlaneTerrain`` (``src/jaxsim/terrain/terrain.py:127-238``): plane ``A x + B y + C z + D = 0``
+    with unit normal ``(A, B, C)`` and height ``-D / C`` over the origin."""
+
+    _normal: tuple = (0.0, 0.0, 1.0)
+
+    @staticmethod
+    def build(height: float = 0.0, *, normal) -> "PlaneTerrain":
+        n = np.asarray(normal, dtype=float)
+        if n.shape != (3,):
+            raise ValueError(f"Expected a 3D vector for the plane normal, got '{n.shape}'.")
+        n = n / np.linalg.norm(n)
+        return PlaneTerrain(_height=float(height), _normal=tuple(n.tolist()))
+
+    def normal(self, x=None, y=None):
+        shape = np.shape(x) if x is not None else ()
+        return np.broadcast_to(np.array(self._normal, dtype=float), shape + (3,)).copy()
+
+    def height(self, x, y):
+        A, B, Cc = self._normal
+        if np.allclose(Cc, 0.0):
+            raise ValueError("The z component of the normal cannot be zero.")
+        D = -Cc * self._height
+        return np.asarray(-(A * np.asarray(x) + B * np.asarray(y) + D) / Cc, dtype=float)
+
+
 class SoftContacts:
     """Marker for the Hunt-Crossley soft-contact model (``rbda/contacts/soft.py:126-444``)."""
 

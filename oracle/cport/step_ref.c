@@ -330,8 +330,10 @@ static void step_env(const ctx_t* c, const real* sin_, real* sout, const real* t
     cross3(Wv[b] + 3, pw, t); /* [I, -S(p)] v = v_lin + w x p (collidable_points.py:50-53) */
     for (int k = 0; k < 3; ++k) pd[k] = Wv[b][k] + t[k];
     /* penetration (contacts/common.py:25-63), flat terrain */
-    real nh[3] = {0, 0, 1};
-    real h = (real)d->terrain_height - pw[2];
+    real nh[3] = {(real)d->terrain_normal[0], (real)d->terrain_normal[1], (real)d->terrain_normal[2]};
+    /* PlaneTerrain.height (terrain/terrain.py:180-215); FlatTerrain is the normal (0,0,1) */
+    real height = (real)(-(d->terrain_normal[0] * pw[0] + d->terrain_normal[1] * pw[1] - d->terrain_normal[2] * d->terrain_height) / d->terrain_normal[2]);
+    real h = (height - pw[2]) * nh[2]; /* h . n with h = [0,0,height - p_z] */
     real delta = h > 0 ? h : 0;
     real ddot = delta > 0 ? -(pd[0] * nh[0] + pd[1] * nh[1] + pd[2] * nh[2]) : 0;
     real dp = (real)pow((double)(delta + eps), d->p), dq = (real)pow((double)(delta + eps), d->q);

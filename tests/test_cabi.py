@@ -54,7 +54,7 @@ def test_struct_layout_matches_header():
         names = decl.replace("*", " ").split()
         # "double K, D, mu, p, q" style declarations
         first = names.index(next(n for n in names if n not in ("const", "int32_t", "double", "uint8_t")))
-        fields += [n.strip(",") for n in names[first:]]
+        fields += [n.strip(",").split("[")[0] for n in names[first:]]
     assert fields == [f[0] for f in _lib.ModelDesc._fields_]
 
 

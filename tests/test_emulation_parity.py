@@ -199,3 +199,43 @@ def test_fused_rollout_equals_repeated_steps(models, name):
     for _ in range(7):
         blk = eb.run(model, eb.MODE_STEP, blk, **kw)
     np.testing.assert_array_equal(fused, blk)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_plane_terrain(models, dtype):
+    """PlaneTerrain: tilted ground plane through the soft-contact model."""
+    import jaxsim_amd as ja
+
+    terrain = ja.PlaneTerrain.build(height=0.02, normal=[0.15, -0.1, 1.0])
+    for name in ("box", "icub"):
+        model = helpers.with_params(models(name), terrain=terrain)
+        d = models.random_data(name, 8, seed=23, dtype=dtype)
+        ref = oracle.step(model, helpers.upcast(d))
+        out = eb.run(model, eb.MODE_STEP, helpers.odata_to_block(model, d))
+        assert helpers.rel_err(out, helpers.odata_to_block(model, ref)) < helpers.tol_of(dtype)
+        # the tilted plane really changes the answer
+        flat = eb.run(models(name), eb.MODE_STEP, helpers.odata_to_block(model, d))
+        assert helpers.rel_err(flat, helpers.odata_to_block(model, ref)) > 1e-6
+
+
+def test_plane_terrain_box_slides_downhill(models):
+    """Known answer: a box at rest on a frictionless 10-degree incline accelerates at g sin(a) along it."""
+    import jaxsim_amd as ja
+
+    a = np.deg2rad(10.0)
+    terrain = ja.PlaneTerrain.build(normal=[np.sin(a), 0.0, np.cos(a)])
+    params = ja.SoftContactsParams.build(K=2e4, D=300.0, mu=0.0)
+    model = helpers.enable_points(helpers.with_params(models("box"), terrain=terrain, contact_params=params), [0, 1, 2, 3])
+    # start resting on the plane: base tilted with the plane, bottom face 0.4 mm inside
+    q = np.array([np.cos(a / 2), 0.0, np.sin(a / 2), 0.0])  # rotation about +y by a: body z -> plane normal
+    n = np.array([np.sin(a), 0.0, np.cos(a)])
+    d = oracle.OracleData.build(model, base_position=n * (0.05 - 4e-4), base_quaternion=q)
+    blk = helpers.odata_to_block(model, d)
+    for _ in range(300):
+        blk = eb.run(model, eb.MODE_STEP, blk)
+        d = oracle.step(model, d)
+    assert helpers.rel_err(blk, helpers.odata_to_block(model, d)) < 1e-8
+    t = 0.3
+    downhill = np.array([np.cos(a), 0.0, -np.sin(a)])
+    travelled = float(blk[0:3, 0] @ downhill - (n * (0.05 - 4e-4)) @ downhill)
+    assert travelled == pytest.approx(0.5 * 9.81 * np.sin(a) * t * t, rel=0.03)

@@ -268,3 +268,31 @@ def test_gpu_golden(models, name, dtype):
     vd, sdd = js.model.forward_dynamics_aba(model, data, joint_forces=g["tau"], link_forces=g["link_forces"])
     assert helpers.rel_err(np.concatenate([vd, sdd], -1), g["fd"]) < helpers.tol_of(dtype)
     assert helpers.rel_err(data._link_transforms, g["link_transforms"]) < helpers.tol_of(dtype)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_plane_terrain_gpu(models, dtype):
+    terrain = ja.PlaneTerrain.build(height=0.02, normal=[0.15, -0.1, 1.0])
+    model = helpers.with_params(models("icub"), terrain=terrain)
+    d = models.random_data("icub", 40, seed=23, dtype=dtype)
+    ref = oracle.step(model, helpers.upcast(d))
+    out = js.model.step(model, to_gpu(model, d))
+    assert helpers.rel_err(out.state_block(), helpers.odata_to_block(model, ref)) < helpers.tol_of(dtype)
+
+
+def test_fused_rollout_equals_repeated_steps_gpu(models):
+    model = models("icub")
+    d = models.random_data("icub", 64, seed=14, dtype=np.float32)
+    g = to_gpu(model, d)
+    fused = js.model.rollout(model, g, 9).state_block()
+    for _ in range(9):
+        g = js.model.step(model, g)
+    np.testing.assert_array_equal(fused, g.state_block())
+    # more collidable points than lanes (sphere: 50 points, 2 chunks): rollout falls back to launches
+    sph = models("sphere")
+    ds = models.random_data("sphere", 16, seed=3)
+    gs = to_gpu(sph, ds)
+    fused = js.model.rollout(sph, gs, 5).state_block()
+    for _ in range(5):
+        ds = oracle.step(sph, ds)
+    assert helpers.rel_err(fused, helpers.odata_to_block(sph, ds)) < 1e-9
