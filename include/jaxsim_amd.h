@@ -47,6 +47,10 @@ extern "C" {
 #define JXS_REPR_BODY 1
 #define JXS_REPR_MIXED 2
 
+/* IntegratorType: src/jaxsim/api/model.py:32-40.  RungeKutta4Fast is not built. */
+#define JXS_INTEGRATOR_SEMI_IMPLICIT_EULER 0
+#define JXS_INTEGRATOR_RUNGE_KUTTA4 1
+
 /* Host description of one model: the static tables of `KinDynParameters`
  * (src/jaxsim/api/kin_dyn_parameters.py:86-284) plus the model-level constants of
  * `JaxSimModel` (src/jaxsim/api/model.py:52-82).  All arrays are host pointers, indexed by
@@ -81,6 +85,7 @@ typedef struct jxs_model_desc {
   double torque_max, omega_th, omega_max; /* ActuationParams, rbda/actuation/common.py:16-19 */
   int32_t enable_friction;
   double terrain_normal[3];       /* PlaneTerrain unit normal (terrain/terrain.py:127-238); (0,0,1) = FlatTerrain */
+  int32_t integrator;             /* JXS_INTEGRATOR_*: model.integrator, api/model.py:2665-2678 */
 } jxs_model_desc;
 
 typedef struct jxs_model jxs_model; /* opaque, immutable after creation, shareable */

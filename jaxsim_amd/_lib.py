@@ -60,6 +60,7 @@ class ModelDesc(C.Structure):
         ("omega_max", C.c_double),
         ("enable_friction", C.c_int32),
         ("terrain_normal", C.c_double * 3),
+        ("integrator", C.c_int32),
     ]
 
 
@@ -138,6 +139,7 @@ def make_desc(model, dtype) -> tuple[ModelDesc, list]:
     d.enable_friction = int(bool(ap.enable_friction))
     nrm = getattr(model.terrain, "_normal", (0.0, 0.0, 1.0))
     d.terrain_normal = (C.c_double * 3)(*[float(x) for x in nrm])
+    d.integrator = int(model.integrator)
     return d, keep
 
 
@@ -148,7 +150,7 @@ def model_signature(model, dtype) -> tuple:
     return (
         id(kdp), np.dtype(dtype).str, model.time_step, model.gravity, model.floating_base(),
         cp.K, cp.D, cp.mu, cp.p, cp.q, model.terrain._height, tuple(getattr(model.terrain, "_normal", (0.0, 0.0, 1.0))),
-        ap.torque_max, ap.omega_th, ap.omega_max, ap.enable_friction,
+        ap.torque_max, ap.omega_th, ap.omega_max, ap.enable_friction, int(model.integrator),
     )  # fmt: skip
 
 

@@ -59,7 +59,8 @@ template <typename T, int G, int MODE>
 hipError_t launch_one(const jxs::KParams<T>& P, const jxs::KArgs<T>& A, hipStream_t s) {
   const int envs_per_wave = 64 / G;  // = the tile of every batched array: block b owns tile b
   const int blocks = (A.N + envs_per_wave - 1) / envs_per_wave;
-  const bool rows = P.row_mode && (MODE == jxs::MODE_STEP || MODE == jxs::MODE_ROLLOUT || MODE == jxs::MODE_FD);
+  const bool rows = P.row_mode && (MODE == jxs::MODE_STEP || MODE == jxs::MODE_ROLLOUT || MODE == jxs::MODE_FD ||
+                                   MODE == jxs::MODE_STEP_RK4);
   const size_t lds_bytes = rows ? sizeof(T) * (size_t)envs_per_wave * jxs::lds_words_per_env(G) : 0;
   hipLaunchKernelGGL((jxs_kernel<T, G, MODE>), dim3(blocks), dim3(64), lds_bytes, s, P, A);
   return hipGetLastError();
@@ -83,6 +84,7 @@ hipError_t launch_mode(int mode, int G, const jxs::KParams<T>& P, const jxs::KAr
     case jxs::MODE_FD: return launch_g<T, jxs::MODE_FD>(G, P, A, s);
     case jxs::MODE_ID: return launch_g<T, jxs::MODE_ID>(G, P, A, s);
     case jxs::MODE_ROLLOUT: return launch_g<T, jxs::MODE_ROLLOUT>(G, P, A, s);
+    case jxs::MODE_STEP_RK4: return launch_g<T, jxs::MODE_STEP_RK4>(G, P, A, s);
     default: return launch_g<T, jxs::MODE_KIN>(G, P, A, s);
   }
 }
@@ -182,6 +184,9 @@ int run_typed(jxs_model* model, int mode, const void* state_in, void* state_out,
   }
   a.dbg = g_dbg;
   a.n_steps = 1;
+  if (mode == jxs::MODE_STEP && mt->pk.integrator == JXS_INTEGRATOR_RUNGE_KUTTA4) {
+    mode = jxs::MODE_STEP_RK4;  // four dynamics evaluations per launch; a rollout is one launch per step
+  }
   if (mode == jxs::MODE_STEP && repeat > 1 && mt->pk.P.n_chunks <= 1) {
     // fused rollout: one launch, the state stays in registers between the steps
     a.n_steps = repeat;

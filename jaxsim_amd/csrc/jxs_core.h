@@ -64,7 +64,8 @@ struct Core {
   // ==========================================================================================
   template <int MODE>
   JXS_HD void run() {
-    constexpr bool kStep = (MODE == MODE_STEP || MODE == MODE_ROLLOUT);
+    constexpr bool kRK4 = (MODE == MODE_STEP_RK4);
+    constexpr bool kStep = (MODE == MODE_STEP || MODE == MODE_ROLLOUT || kRK4);
     const VI lane = ln.lane();
     ln.stamp(A, 0);
 
@@ -172,6 +173,27 @@ struct Core {
       tau = vmax(vmin(tot, lim), -lim);  // clip(tot, -lim, lim)
     }
 
+    // Runge-Kutta 4 (api/integrators.py:91-167): the joint torques above are computed once from the
+    // initial state (api/model.py:2658), the stage loop below evaluates system_dynamics
+    // (api/ode.py:174-225) at x0, x0 + dt/2 k1, x0 + dt/2 k2, x0 + dt k3.  One stage for Euler.
+    constexpr int n_stages = kRK4 ? 4 : 1;
+    V x0s, x0sd, x0q[4], x0p[3], x0v[3], x0w[3], x0m[3];  // stage-0 state (quaternion normalised)
+    V ks, ksd, kq[4], kp[3], kv[3], kw[3], km[3];           // weighted sum of the stage derivatives
+    V xfl[3], xfa[3];                                       // external link wrench in the stage-0 frame C
+    if (kRK4) {
+      const V nrm0 = vsqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+      const V inv0 = vrcp(vsel(nrm0 == V(T(0)), V(T(1)), nrm0));
+      x0s = s, x0sd = sd, ks = V(T(0)), ksd = V(T(0));
+#pragma unroll
+      for (int k = 0; k < 4; ++k) q[k] = q[k] * inv0, x0q[k] = q[k], kq[k] = V(T(0));
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        x0p[k] = pB[k], x0v[k] = vW[k], x0w[k] = om[k], x0m[k] = ps0.m[k];
+        kp[k] = V(T(0)), kv[k] = V(T(0)), kw[k] = V(T(0)), km[k] = V(T(0));
+      }
+    }
+#pragma unroll
+    for (int stage = 0; stage < n_stages; ++stage) {
     // ---- base rotation: DCM of q/|q| (data.base_orientation, api/data.py:267-286) --------
     V R[9], r[3];
     {
@@ -324,7 +346,17 @@ struct Core {
 
     // ---- external link wrenches in C -----------------------------------------------------
     V fl[3] = {V(T(0)), V(T(0)), V(T(0))}, fa[3] = {V(T(0)), V(T(0)), V(T(0))};
-    if (A.link_f != nullptr) {
+    if (kRK4 && stage > 0) {
+      // The inertial wrench is converted once, with the link transforms of the initial state
+      // (api/model.py:2641-2646), and held over the stages: only its moment is re-referred to the
+      // origin of this stage's frame C,  mu_Cs = mu_C0 + (p_B0 - p_Bs) x f.
+      if (A.link_f != nullptr) {
+        V dp[3] = {x0p[0] - pB[0], x0p[1] - pB[1], x0p[2] - pB[2]}, t[3];
+        cross(dp, xfl, t);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) fl[k] = xfl[k], fa[k] = xfa[k] + t[k];
+      }
+    } else if (A.link_f != nullptr) {
       const VM is_link = level >= 0;
       V f6[6];
 #pragma unroll
@@ -360,6 +392,10 @@ struct Core {
           fl[k] = fw[k];
           fa[k] = mw[k] + t[k];
         }
+      }
+      if (kRK4) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) xfl[k] = fl[k], xfa[k] = fa[k];
       }
     }
 
@@ -618,8 +654,8 @@ struct Core {
       return;
     }
 
+    if (!kRK4) {
     // ---- C: semi-implicit Euler (api/integrators.py:14-88) ---------------------------------
-    {
       const V dt = V(P.dt);
       sd = sd + dt * sdd;
       s = s + dt * sd;
@@ -633,15 +669,11 @@ struct Core {
         vW[k] = vW[k] + dt * (acl[k] - t[k]);
       }
       // Qdot = 1/2 Q_inertial(q) [K |w| (1 - |q|); w]   (math/quaternion.py:68-132)
-      const V nw = vsqrt(omn[0] * omn[0] + omn[1] * omn[1] + omn[2] * omn[2]);
-      const V nq = vsqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-      const V h0 = P.quat_K * nw * (V(T(1)) - nq);
-      const V half = V(T(0.5));
+      V qd[4];
+      quat_derivative(q, omn, P.quat_K, qd);
       V qn[4];
-      qn[0] = q[0] + dt * half * (q[0] * h0 - q[1] * omn[0] - q[2] * omn[1] - q[3] * omn[2]);
-      qn[1] = q[1] + dt * half * (q[1] * h0 + q[0] * omn[0] + q[3] * omn[1] - q[2] * omn[2]);
-      qn[2] = q[2] + dt * half * (q[2] * h0 - q[3] * omn[0] + q[0] * omn[1] + q[1] * omn[2]);
-      qn[3] = q[3] + dt * half * (q[3] * h0 + q[2] * omn[0] - q[1] * omn[1] + q[0] * omn[2]);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) qn[k] = q[k] + dt * qd[k];
       const V nn = vsqrt(qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3]);
       const V invn = vrcp(vsel(nn == V(T(0)), V(T(1)), nn));
 #pragma unroll
@@ -650,8 +682,63 @@ struct Core {
       for (int k = 0; k < 3; ++k) {
         pB[k] = pB[k] + dt * pd[k];
         om[k] = omn[k];
+        if (with_contacts) ps0.m[k] = ps0.m[k] + dt * ps0.md[k];  // api/integrators.py:67-71
+      }
+    } else {
+      // ---- system_dynamics at this stage (api/ode.py:134-225): position derivatives use the stage
+      // velocity, the quaternion derivative the Baumgarte gain 1.0 ------------------------------------
+      V dq[4], dv[3], t[3];
+      quat_derivative(q, om, T(1), dq);
+      cross(aca, pB, t);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) dv[k] = acl[k] - t[k];  // inertial-fixed linear acceleration
+      const T wgt = (stage == 0 || stage == 3) ? T(1) : T(2);
+      ks = ks + wgt * sd, ksd = ksd + wgt * sdd;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) kq[k] = kq[k] + wgt * dq[k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        kp[k] = kp[k] + wgt * vBc[k];  // W_pdot_B = v_W + w x p_B
+        kv[k] = kv[k] + wgt * dv[k];
+        kw[k] = kw[k] + wgt * aca[k];
+        if (with_contacts) km[k] = km[k] + wgt * ps0.md[k];
+      }
+      if (stage < 3) {
+        const V h = V(stage == 2 ? P.dt : P.dt * T(0.5));  // euler_mid, euler_mid, euler_fin
+        const V sd_st = sd, sdd_st = sdd;
+        s = x0s + h * sd_st;
+        sd = x0sd + h * sdd_st;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) q[k] = x0q[k] + h * dq[k];  // re-normalised at the next stage start
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const V pdot = vBc[k];
+          pB[k] = x0p[k] + h * pdot;
+          vW[k] = x0v[k] + h * dv[k];
+          om[k] = x0w[k] + h * aca[k];
+          if (with_contacts) ps0.m[k] = x0m[k] + h * ps0.md[k];
+        }
+      } else {
+        const V h = V(P.dt * T(1.0 / 6.0));
+        s = x0s + h * ks;
+        sd = x0sd + h * ksd;
+        V qn[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) qn[k] = x0q[k] + h * kq[k];
+        const V nn = vsqrt(qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3]);
+        const V invn = vrcp(vsel(nn == V(T(0)), V(T(1)), nn));  // data.replace (api/data.py:434-440)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) q[k] = qn[k] * invn;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          pB[k] = x0p[k] + h * kp[k];
+          vW[k] = x0v[k] + h * kv[k];
+          om[k] = x0w[k] + h * kw[k];
+          if (with_contacts) ps0.m[k] = x0m[k] + h * km[k];
+        }
       }
     }
+    }  // integrator stages
     }  // fused step loop
 
     // ---- write the state back once ---------------------------------------------------------------
@@ -674,6 +761,18 @@ struct Core {
       }
     }
     ln.stamp(A, 10);  // integrate + stores issued
+  }
+
+  // Qdot = 1/2 Q_inertial(q) [K |w| (1 - |q|); w]   (math/quaternion.py:68-132), q normalised
+  static JXS_HD void quat_derivative(const V* q, const V* w, const T K, V* qd) {
+    const V nw = vsqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+    const V nq = vsqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    const V h0 = K * nw * (V(T(1)) - nq);
+    const V half = V(T(0.5));
+    qd[0] = half * (q[0] * h0 - q[1] * w[0] - q[2] * w[1] - q[3] * w[2]);
+    qd[1] = half * (q[1] * h0 + q[0] * w[0] + q[3] * w[1] - q[2] * w[2]);
+    qd[2] = half * (q[2] * h0 - q[3] * w[0] + q[0] * w[1] + q[1] * w[2]);
+    qd[3] = half * (q[3] * h0 + q[2] * w[0] - q[1] * w[1] + q[0] * w[2]);
   }
 
   // ==========================================================================================
@@ -946,7 +1045,7 @@ struct Core {
 
   struct PointSlot {
     VI body, prow, tail, hd;
-    V Lp[3], m[3];
+    V Lp[3], m[3], md[3];  // md: deformation rate of the last evaluation (chunk 0)
   };
   JXS_HD void load_slot_tables(const VI& lane, int ch, PointSlot& ps) const {
     const VI slot = lane + ch * G;
@@ -1078,9 +1177,8 @@ struct Core {
 #pragma unroll
       for (int k = 0; k < 3; ++k)
       {
-        const V m_new = m[k] + P.dt * md[k];
-        if (ch == 0) ps0.m[k] = m_new;  // chunk 0 is carried in registers and stored by run()
-        else ln.gstore(A.state_out, prow * 3 + (P.row_m + k), m_new, valid, P.n_rows);
+        if (ch == 0) ps0.md[k] = md[k];  // chunk 0 is carried in registers, integrated by run()
+        else ln.gstore(A.state_out, prow * 3 + (P.row_m + k), m[k] + P.dt * md[k], valid, P.n_rows);
       }
       // wrench in C: [f; r_C x f]  (W_f = [f; p x f], soft.py:377-388, moved to the C origin)
       V w6[6];

@@ -25,6 +25,7 @@ struct Packed {
   std::vector<int> head;
   std::vector<int> rti;
   int n_disabled = 0;
+  int integrator = 0;  // JXS_INTEGRATOR_*
 };
 
 inline int pow2ceil(int x) {
@@ -46,6 +47,9 @@ std::string pack_model(const jxs_model_desc& d, Packed<T>& out) {
     if (std::fabs(n2 - 1.0) > 1e-9) return "terrain_normal must be a unit vector";
     if (std::fabs(nn[2]) < 1e-12) return "the z component of the terrain normal cannot be zero";  // terrain.py:197-200
   }
+  if (d.integrator != JXS_INTEGRATOR_SEMI_IMPLICIT_EULER && d.integrator != JXS_INTEGRATOR_RUNGE_KUTTA4)
+    return "unsupported integrator (SemiImplicitEuler = 0 and RungeKutta4 = 1 are built)";
+  out.integrator = d.integrator;
   for (int i = 1; i < nL; ++i) {
     if (d.parent[i] < 0 || d.parent[i] >= i) return "parent array must be topologically ordered (BFS indices)";
     if (d.joint_type[i] != 1 && d.joint_type[i] != 2) return "joint types must be revolute(1) or prismatic(2)";
@@ -84,6 +88,8 @@ std::string pack_model(const jxs_model_desc& d, Packed<T>& out) {
   P.n_points = d.n_points;
   P.n_slots = n_slots;
   P.n_chunks = n_chunks;
+  if (d.integrator == JXS_INTEGRATOR_RUNGE_KUTTA4 && n_chunks > 1)
+    return "RungeKutta4 needs every enabled collidable point in one lane group (at most 64 points)";
   P.floating = d.floating_base ? 1 : 0;
 
   // tree structure

@@ -90,7 +90,8 @@ enum Mode : int {
   MODE_FD = 1,    // forward_dynamics_aba (no contacts)    api/model.py:1269-1406
   MODE_ID = 2,    // inverse_dynamics / RNEA               api/model.py:1746-1894
   MODE_KIN = 3,   // cached kinematics of JaxSimModelData  api/data.py:405-523
-  MODE_ROLLOUT = 4  // MODE_STEP repeated KArgs::n_steps times in one launch (state in registers)
+  MODE_ROLLOUT = 4,  // MODE_STEP repeated KArgs::n_steps times in one launch (state in registers)
+  MODE_STEP_RK4 = 5  // js.model.step with IntegratorType.RungeKutta4  api/integrators.py:91-167
 };
 
 enum ForceRepr : int { REPR_INERTIAL = 0, REPR_BODY = 1, REPR_MIXED = 2 };  // api/common.py:39-47

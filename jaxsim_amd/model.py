@@ -139,9 +139,11 @@ class SoftContacts:
 
 
 class IntegratorType(enum.IntEnum):
-    """``IntegratorType`` (``src/jaxsim/api/model.py:32-40``); only semi-implicit Euler is built."""
+    """``IntegratorType`` (``src/jaxsim/api/model.py:32-40``); values are the C-ABI enum.
+    ``RungeKutta4Fast`` (the reference's approximate variant) is not built."""
 
     SemiImplicitEuler = 0
+    RungeKutta4 = 1
 
 
 class JaxSimModel:

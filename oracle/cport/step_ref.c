@@ -501,6 +501,7 @@ static void step_env(const ctx_t* c, const real* sin_, real* sout, const real* t
 int FN(oracle_step)(const jxs_model_desc* d, const REAL* state_in, REAL* state_out, const REAL* tau,
                     const REAL* link_forces, int N, int n_steps, int n_threads) {
   if (d->n_links > MAXL) return -1;
+  if (d->integrator != 0) return -2; /* the C port restates the semi-implicit Euler step only */
   ctx_t* c = (ctx_t*)malloc(sizeof(ctx_t));
   build_ctx(d, c);
   if (state_out != state_in) memcpy(state_out, state_in, sizeof(REAL) * (size_t)c->rows * N);

@@ -736,8 +736,72 @@ def semi_implicit_euler_integration(model, data: OracleData, link_forces, joint_
     return new.update_caches(model)
 
 
+def system_position_dynamics(data: OracleData, baumgarte_quaternion_regularization=1.0):
+    """``system_position_dynamics`` (ode.py:134-171), inertial-fixed representation."""
+    W_w_WB = data.base_angular_velocity
+    W_pd_B = data.base_linear_velocity + np.cross(W_w_WB, data.base_position)
+    W_Qd_B = rm.quaternion_derivative(
+        data.base_orientation, W_w_WB, omega_in_body_fixed=False, K=baumgarte_quaternion_regularization
+    )
+    return W_pd_B, W_Qd_B, data.joint_velocities
+
+
+def system_dynamics(model, data: OracleData, *, link_forces=None, joint_torques=None) -> dict:
+    """``system_dynamics`` (ode.py:174-225): the state derivative as a dict keyed like the
+    integrator's state (quaternion Baumgarte gain 1.0)."""
+    W_vd_WB, sdd, md = system_acceleration(model, data, link_forces=link_forces, joint_torques=joint_torques)
+    W_pd_B, W_Qd_B, sd = system_position_dynamics(data, 1.0)
+    return dict(
+        base_position=W_pd_B,
+        base_quaternion=W_Qd_B,
+        joint_positions=sd,
+        base_linear_velocity=W_vd_WB[:, :3],
+        base_angular_velocity=W_vd_WB[:, 3:],
+        joint_velocities=sdd,
+        tangential_deformation=md,
+    )
+
+
+def rk4_integration(model, data: OracleData, link_forces, joint_torques) -> OracleData:
+    """``rk4_integration`` (integrators.py:91-167): classic RK4 on the dict state; every stage
+    state goes through ``data.replace`` (quaternion normalisation + cache refresh), the external
+    inertial link wrenches and the joint torques are those of the initial state."""
+    dtype = data.dtype
+    dt = dtype.type(model.time_step)
+
+    def f(x):
+        data_ti = dataclasses.replace(data, **x).update_caches(model)
+        return system_dynamics(model, data_ti, link_forces=link_forces, joint_torques=joint_torques)
+
+    nrm = rm.safe_norm(data.base_quaternion, keepdims=True)
+    x_t0 = dict(
+        base_position=data.base_position,
+        base_quaternion=data.base_quaternion / np.where(nrm == 0, 1.0, nrm).astype(dtype),
+        joint_positions=data.joint_positions,
+        base_linear_velocity=data.base_linear_velocity,
+        base_angular_velocity=data.base_angular_velocity,
+        joint_velocities=data.joint_velocities,
+        tangential_deformation=data.tangential_deformation,
+    )
+
+    def advance(x, dxdt, h):
+        return {k: (x[k] + h * dxdt[k]).astype(dtype) for k in x}
+
+    k1 = f(x_t0)
+    k2 = f(advance(x_t0, k1, dtype.type(0.5) * dt))
+    k3 = f(advance(x_t0, k2, dtype.type(0.5) * dt))
+    k4 = f(advance(x_t0, k3, dt))
+    dxdt = {k: (k1[k] + 2 * k2[k] + 2 * k3[k] + k4[k]) / 6 for k in x_t0}
+    x_tf = advance(x_t0, dxdt, dt)
+    return dataclasses.replace(data, **x_tf).update_caches(model)
+
+
+_INTEGRATORS = {0: semi_implicit_euler_integration, 1: rk4_integration}  # integrators.py:279-283
+
+
 def step(model, data: OracleData, *, link_forces=None, joint_force_references=None) -> OracleData:
-    """``js.model.step`` (model.py:2601-2681) for SoftContacts + semi-implicit Euler."""
+    """``js.model.step`` (model.py:2601-2681) for SoftContacts; the integrator is
+    ``model.integrator`` (SemiImplicitEuler or RungeKutta4)."""
     N, nL = data.batch_size, model.kin_dyn_parameters.number_of_links()
     dtype = data.dtype
     O_f_L = link_forces if link_forces is not None else np.zeros((N, nL, 6), dtype=dtype)
@@ -750,7 +814,7 @@ def step(model, data: OracleData, *, link_forces=None, joint_force_references=No
         else np.zeros_like(data.joint_positions)
     )
     tau_total = compute_resultant_torques(model, data, joint_force_references=tau_ref)
-    return semi_implicit_euler_integration(model, data, W_f_L, tau_total)
+    return _INTEGRATORS[int(getattr(model, "integrator", 0))](model, data, W_f_L, tau_total)
 
 
 # =============================================================================================

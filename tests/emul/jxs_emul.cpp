@@ -32,6 +32,7 @@ void run_group(const jxs::Packed<T>& pk, jxs::KArgs<T> a, int mode) {
       case jxs::MODE_FD: core.template run<jxs::MODE_FD>(); break;
       case jxs::MODE_ID: core.template run<jxs::MODE_ID>(); break;
       case jxs::MODE_ROLLOUT: core.template run<jxs::MODE_ROLLOUT>(); break;
+      case jxs::MODE_STEP_RK4: core.template run<jxs::MODE_STEP_RK4>(); break;
       default: core.template run<jxs::MODE_KIN>(); break;
     }
   }
@@ -65,6 +66,12 @@ int run_typed(const jxs_model_desc* d, int mode, const void* state_in, void* sta
     std::memcpy(state_out, state_in, sizeof(T) * (size_t)((N + tile - 1) / tile) * tile * pk.P.n_rows);
   }
   int launches = 1;
+  const bool rk4 = (mode == jxs::MODE_STEP && pk.integrator == JXS_INTEGRATOR_RUNGE_KUTTA4);
+  if (rk4) mode = jxs::MODE_STEP_RK4;
+  if (rk4 && n_steps > 1) {
+    launches = n_steps;
+    a.n_steps = 1;
+  }
   if (mode == jxs::MODE_STEP && n_steps > 1 && pk.P.n_chunks > 1) {  // like jxs_rollout: not fused
     launches = n_steps;
     a.n_steps = 1;

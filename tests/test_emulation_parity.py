@@ -239,3 +239,115 @@ def test_plane_terrain_box_slides_downhill(models):
     downhill = np.array([np.cos(a), 0.0, -np.sin(a)])
     travelled = float(blk[0:3, 0] @ downhill - (n * (0.05 - 4e-4)) @ downhill)
     assert travelled == pytest.approx(0.5 * 9.81 * np.sin(a) * t * t, rel=0.03)
+
+
+# ---- Runge-Kutta 4 (reference: api/integrators.py:91-167) -----------
+RK4_MODELS = ["box", "pendulum", "cartpole", "chain9f", "anymal", "icub16"]
+
+
+def _rk4(model):
+    import jaxsim_amd as ja
+
+    # Explicit RK4 leaves its stability region on the zoo's default contact stiffness (K = 1e6,
+    # D = 2000 at dt = 1 ms amplify light links by 1e7 per step, in the reference too), which
+    # would turn a parity check into a chaos check: the RK4 cases use a softer ground.
+    soft = ja.SoftContactsParams.build(K=2e4, D=60.0, mu=0.6)
+    return helpers.with_params(model, integrator=ja.IntegratorType.RungeKutta4, contact_params=soft)
+
+
+@pytest.mark.parametrize("name", RK4_MODELS)
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_rk4_step_matches_oracle(models, name, dtype):
+    model = _rk4(models(name))
+    N = 5
+    d = models.random_data(name, N, seed=31, dtype=dtype)
+    tau, f = helpers.random_inputs(model, N, 32, dtype)
+    ref = oracle.step(model, helpers.upcast(d), link_forces=f.astype(np.float64), joint_force_references=tau.astype(np.float64))
+    out = eb.run(model, eb.MODE_STEP, helpers.odata_to_block(model, d), tau=tau.T,
+                 link_forces=f.reshape(N, -1).T, force_repr=REPR_CODE[d.velocity_representation])  # fmt: skip
+    assert helpers.rel_err(out, helpers.odata_to_block(model, ref)) < helpers.tol_of(dtype)
+    # and it is not the Euler answer
+    euler = oracle.step(helpers.with_params(model, integrator=0), helpers.upcast(d), link_forces=f.astype(np.float64), joint_force_references=tau.astype(np.float64))
+    assert helpers.rel_err(helpers.odata_to_block(model, euler), helpers.odata_to_block(model, ref)) > 1e-7
+
+
+@pytest.mark.parametrize("rep", [VelRepr.Inertial, VelRepr.Body, VelRepr.Mixed])
+def test_rk4_link_forces_are_held_over_the_stages(models, rep):
+    """The external wrenches are converted to inertial once, with the link transforms of the
+    initial state (api/model.py:2641-2646), and held while the stages move the links."""
+    model = _rk4(models("chain9f"))
+    N = 4
+    d = models.random_data("chain9f", N, seed=33, rep=rep)
+    tau, f = helpers.random_inputs(model, N, 34, np.float64)
+    ref = oracle.step(model, d, link_forces=f, joint_force_references=tau)
+    out = eb.run(model, eb.MODE_STEP, helpers.odata_to_block(model, d), tau=tau.T,
+                 link_forces=f.reshape(N, -1).T, force_repr=REPR_CODE[rep])  # fmt: skip
+    assert helpers.rel_err(out, helpers.odata_to_block(model, ref)) < helpers.FP64_TOL
+
+
+def test_rk4_multi_step_rollout(models):
+    for name in ("cartpole", "icub16"):
+        model = _rk4(models(name))
+        d = models.random_data(name, 3, seed=35)
+        blk = helpers.odata_to_block(model, d)
+        for _ in range(10):
+            d = oracle.step(model, d)
+        out = eb.run(model, eb.MODE_STEP, blk, n_steps=10)  # one launch per step
+        assert helpers.rel_err(out, helpers.odata_to_block(model, d)) < 1e-8
+
+
+def test_rk4_free_fall_known_answer(models):
+    """Constant acceleration: RK4 integrates position exactly, p(t) = p0 + v0 t + g t^2 / 2
+    (semi-implicit Euler has an O(dt) position error on the same problem)."""
+    model = _rk4(models("box"))
+    v0 = np.array([0.3, -0.2, 1.0])
+    d = oracle.OracleData.build(model, base_position=[0.0, 0.0, 5.0], base_linear_velocity=v0)
+    blk = eb.run(model, eb.MODE_STEP, helpers.odata_to_block(model, d), n_steps=50)
+    t = 50 * model.time_step
+    expect = np.array([0.0, 0.0, 5.0]) + v0 * t + 0.5 * np.array([0.0, 0.0, model.gravity]) * t * t
+    np.testing.assert_allclose(blk[0:3, 0], expect, rtol=0, atol=1e-12)
+
+
+def test_rk4_pendulum_energy_drift_is_fourth_order(models):
+    """Undamped pendulum: the RK4 energy drift over 200 steps is orders of magnitude below
+    semi-implicit Euler's bounded oscillation at the same time step."""
+    import jaxsim_amd as ja
+
+    base = helpers.with_params(models("pendulum"), actuation_params=ja.ActuationParams(enable_friction=False))
+
+    def energy(model, blk):
+        dd = helpers.block_to_odata(model, blk)
+        M = oracle.free_floating_mass_matrix(model, dd)
+        v = dd.generalized_velocity(VelRepr.Inertial) if model.floating_base() else np.concatenate([np.zeros((1, 6)), dd.joint_velocities], -1)
+        T = 0.5 * np.einsum("ni,nij,nj->n", v, M, v)
+        H = dd.link_transforms
+        kdp = model.kin_dyn_parameters
+        com_w = np.einsum("nlij,lj->nli", H[:, :, :3, :3], kdp.link_com) + H[:, :, :3, 3]
+        U = -model.gravity * np.einsum("l,nl->n", kdp.link_mass, com_w[..., 2])
+        return (T + U)[0]
+
+    out = {}
+    for key, model in (("euler", base), ("rk4", _rk4(base))):
+        d = oracle.OracleData.build(model, joint_positions=[1.0])
+        blk = helpers.odata_to_block(model, d)
+        e0 = energy(model, blk)
+        drift = 0.0
+        for _ in range(4):
+            blk = eb.run(model, eb.MODE_STEP, blk, n_steps=50)
+            drift = max(drift, abs(energy(model, blk) - e0))
+        out[key] = drift / abs(e0) if e0 != 0 else drift
+    assert out["rk4"] < 1e-9 and out["rk4"] < 1e-3 * out["euler"], out
+
+
+def test_rk4_needs_one_chunk_of_points(models):
+    """More enabled points than lanes of a group would need a second contact pass per stage:
+    rejected at model creation (documented limit), not silently integrated with Euler."""
+    import jaxsim_amd as ja
+    from jaxsim_amd import robots
+
+    big = ja.JaxSimModel.build_from_model_description(robots.icub23_urdf(sole_boxes_per_foot=3))
+    assert eb.layout(big).n_points > eb.layout(big).group  # fine with the Euler integrator
+    with pytest.raises(RuntimeError, match="RungeKutta4"):
+        eb.layout(_rk4(big))
+    with pytest.raises(RuntimeError, match="unsupported integrator"):
+        eb.layout(helpers.with_params(models("box"), integrator=2))

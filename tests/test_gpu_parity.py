@@ -296,3 +296,49 @@ def test_fused_rollout_equals_repeated_steps_gpu(models):
     for _ in range(5):
         ds = oracle.step(sph, ds)
     assert helpers.rel_err(fused, helpers.odata_to_block(sph, ds)) < 1e-9
+
+
+# ---- Runge-Kutta 4 (api/integrators.py:91-167) --------------------------------------------------
+def _rk4(model):
+    # softer ground than the zoo default: explicit RK4 is outside its stability region at K = 1e6
+    soft = ja.SoftContactsParams.build(K=2e4, D=60.0, mu=0.6)
+    return helpers.with_params(model, integrator=ja.IntegratorType.RungeKutta4, contact_params=soft)
+
+
+@pytest.mark.parametrize("name", ["box", "cartpole", "chain9f", "anymal", "icub16", "icub"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_rk4_step_matches_oracle_gpu(models, name, dtype):
+    model = _rk4(models(name))
+    N = 70
+    d = models.random_data(name, N, seed=31, dtype=dtype)
+    tau, f = helpers.random_inputs(model, N, 32, dtype)
+    ref = oracle.step(model, helpers.upcast(d), link_forces=f.astype(np.float64), joint_force_references=tau.astype(np.float64))
+    out = js.model.step(model, to_gpu(model, d), link_forces=f, joint_force_references=tau)
+    assert helpers.rel_err(out.state_block(), helpers.odata_to_block(model, ref)) < helpers.tol_of(dtype)
+
+
+@pytest.mark.parametrize("rep", [VelRepr.Inertial, VelRepr.Body, VelRepr.Mixed])
+def test_rk4_link_force_representations_gpu(models, rep):
+    model = _rk4(models("icub"))
+    d = models.random_data("icub", 33, seed=33, rep=rep)
+    tau, f = helpers.random_inputs(model, 33, 34, np.float64)
+    ref = oracle.step(model, d, link_forces=f, joint_force_references=tau)
+    out = js.model.step(model, to_gpu(model, d), link_forces=f, joint_force_references=tau)
+    assert helpers.rel_err(out.state_block(), helpers.odata_to_block(model, ref)) < helpers.FP64_TOL
+
+
+def test_rk4_rollout_and_free_fall_gpu(models):
+    model = _rk4(models("icub"))
+    d = models.random_data("icub", 20, seed=35)
+    out = js.model.rollout(model, to_gpu(model, d), 10).state_block()
+    for _ in range(10):
+        d = oracle.step(model, d)
+    assert helpers.rel_err(out, helpers.odata_to_block(model, d)) < 1e-8
+    # constant acceleration is integrated exactly by RK4
+    box = _rk4(models("box"))
+    v0 = np.array([0.3, -0.2, 1.0])
+    d0 = oracle.OracleData.build(box, base_position=[0.0, 0.0, 5.0], base_linear_velocity=v0)
+    blk = js.model.rollout(box, to_gpu(box, d0), 50).state_block()
+    t = 50 * box.time_step
+    expect = np.array([0.0, 0.0, 5.0]) + v0 * t + 0.5 * np.array([0.0, 0.0, box.gravity]) * t * t
+    np.testing.assert_allclose(blk[0:3, 0], expect, rtol=0, atol=1e-12)
