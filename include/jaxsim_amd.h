@@ -51,6 +51,10 @@ extern "C" {
 #define JXS_INTEGRATOR_SEMI_IMPLICIT_EULER 0
 #define JXS_INTEGRATOR_RUNGE_KUTTA4 1
 
+/* Contact models: src/jaxsim/rbda/contacts/{soft,rigid}.py */
+#define JXS_CONTACT_SOFT 0
+#define JXS_CONTACT_RIGID 1
+
 /* Host description of one model: the static tables of `KinDynParameters`
  * (src/jaxsim/api/kin_dyn_parameters.py:86-284) plus the model-level constants of
  * `JaxSimModel` (src/jaxsim/api/model.py:52-82).  All arrays are host pointers, indexed by
@@ -86,6 +90,10 @@ typedef struct jxs_model_desc {
   int32_t enable_friction;
   double terrain_normal[3];       /* PlaneTerrain unit normal (terrain/terrain.py:127-238); (0,0,1) = FlatTerrain */
   int32_t integrator;             /* JXS_INTEGRATOR_*: model.integrator, api/model.py:2665-2678 */
+  int32_t contact_model;          /* JXS_CONTACT_*; with JXS_CONTACT_RIGID K, D, mu are RigidContactsParams
+                                     (rbda/contacts/rigid.py:28-42) and p, q are ignored */
+  double regularization_delassus; /* RigidContacts.regularization_delassus (rigid.py:99-101), 1e-6 */
+  double solver_tol;              /* RigidContacts solver_options["solver_tol"] (rigid.py:103-108), 1e-3 */
 } jxs_model_desc;
 
 typedef struct jxs_model jxs_model; /* opaque, immutable after creation, shareable */
@@ -154,6 +162,12 @@ int jxs_forward_dynamics_aba(jxs_model* model, const void* state, const void* jo
 int jxs_inverse_dynamics(jxs_model* model, const void* state, const void* in_acc,
                          const void* link_forces, int force_repr, void* out_forces, int N,
                          void* stream);
+
+/* Gravity compensation torques: the joint part of free_floating_gravity_forces
+ * (src/jaxsim/api/model.py:1897-1931: RNEA at zero velocity, zero acceleration, no external forces),
+ * written as [n][N] -- the layout jxs_step reads `tau` in, so a controller loop
+ * "tau = g(q); step(tau)" (BASELINE.json config 5) stays on the device.                     */
+int jxs_gravity_torques(jxs_model* model, const void* state, void* out_tau, int N, void* stream);
 
 /* The cached kinematics of JaxSimModelData.replace (src/jaxsim/api/data.py:405-523,
  * rbda/forward_kinematics.py:12-113): link transforms [nL*12][N] (rows of [R|p]) and

@@ -61,6 +61,9 @@ class ModelDesc(C.Structure):
         ("enable_friction", C.c_int32),
         ("terrain_normal", C.c_double * 3),
         ("integrator", C.c_int32),
+        ("contact_model", C.c_int32),
+        ("regularization_delassus", C.c_double),
+        ("solver_tol", C.c_double),
     ]
 
 
@@ -132,7 +135,8 @@ def make_desc(model, dtype) -> tuple[ModelDesc, list]:
     d.time_step = float(model.time_step)
     d.gravity = float(model.gravity)
     cp = model.contact_params
-    d.K, d.D, d.mu, d.p, d.q = float(cp.K), float(cp.D), float(cp.mu), float(cp.p), float(cp.q)
+    d.K, d.D, d.mu = float(cp.K), float(cp.D), float(cp.mu)
+    d.p, d.q = float(getattr(cp, "p", 0.5)), float(getattr(cp, "q", 0.5))  # RigidContactsParams has no exponents
     d.terrain_height = float(model.terrain._height)
     ap = model.actuation_params
     d.torque_max, d.omega_th, d.omega_max = float(ap.torque_max), float(ap.omega_th), float(ap.omega_max)
@@ -140,6 +144,10 @@ def make_desc(model, dtype) -> tuple[ModelDesc, list]:
     nrm = getattr(model.terrain, "_normal", (0.0, 0.0, 1.0))
     d.terrain_normal = (C.c_double * 3)(*[float(x) for x in nrm])
     d.integrator = int(model.integrator)
+    cm = model.contact_model
+    d.contact_model = 1 if type(cm).__name__ == "RigidContacts" else 0
+    d.regularization_delassus = float(getattr(cm, "regularization_delassus", 1e-6))
+    d.solver_tol = float(getattr(cm, "solver_tol", 1e-3))
     return d, keep
 
 
@@ -149,8 +157,10 @@ def model_signature(model, dtype) -> tuple:
     cp, ap = model.contact_params, model.actuation_params
     return (
         id(kdp), np.dtype(dtype).str, model.time_step, model.gravity, model.floating_base(),
-        cp.K, cp.D, cp.mu, cp.p, cp.q, model.terrain._height, tuple(getattr(model.terrain, "_normal", (0.0, 0.0, 1.0))),
+        cp.K, cp.D, cp.mu, getattr(cp, "p", 0.5), getattr(cp, "q", 0.5), model.terrain._height, tuple(getattr(model.terrain, "_normal", (0.0, 0.0, 1.0))),
         ap.torque_max, ap.omega_th, ap.omega_max, ap.enable_friction, int(model.integrator),
+        type(model.contact_model).__name__, getattr(model.contact_model, "regularization_delassus", None),
+        getattr(model.contact_model, "solver_tol", None),
     )  # fmt: skip
 
 
@@ -185,6 +195,7 @@ def _declare(lib):
         "jxs_rollout": [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp],
         "jxs_forward_dynamics_aba": [vp, vp, vp, vp, C.c_int, vp, C.c_int, vp],
         "jxs_inverse_dynamics": [vp, vp, vp, vp, C.c_int, vp, C.c_int, vp],
+        "jxs_gravity_torques": [vp, vp, vp, C.c_int, vp],
         "jxs_refresh_kinematics": [vp, vp, vp, vp, C.c_int, vp],
         "jxs_comm_unique_id": [C.c_char * 128],
         "jxs_comm_init": [C.POINTER(vp), C.c_char * 128, C.c_int, C.c_int],

@@ -179,6 +179,20 @@ def free_floating_gravity_forces(model: JaxSimModel, data: JaxSimModelData):
     return np.concatenate([fB, tau], axis=-1)
 
 
+def gravity_compensation_torques(model: JaxSimModel, data: JaxSimModelData, out: DeviceArray | None = None) -> DeviceArray:
+    """Joint part of ``free_floating_gravity_forces`` as a device array ``[n][N]`` that ``step``
+    accepts as ``joint_force_references`` without a host round trip (extension; the reference
+    idiom is ``tau = js.model.free_floating_gravity_forces(model, data)[6:]`` followed by ``step``)."""
+    dm = runtime.device_model(model, data.dtype)
+    N, n = data.batch_size, model.dofs()
+    out = out if out is not None else DeviceArray(n, N, data.dtype, tile=data._state.tile)
+    _lib.check(
+        _lib.load().jxs_gravity_torques(dm.handle, C.c_void_p(data._state.ptr), C.c_void_p(out.ptr), N, runtime._sp()),
+        "jxs_gravity_torques",
+    )
+    return out
+
+
 def free_floating_bias_forces(model: JaxSimModel, data: JaxSimModelData):
     """``h(q, nu)`` (``src/jaxsim/api/model.py:1934-1978``); fixed-base models drop the base
     velocity like the reference does."""

@@ -40,7 +40,9 @@ int hip_fail(hipError_t e, const char* what) {
 template <typename T, int G, int MODE>
 __global__ __launch_bounds__(64) void jxs_kernel(const jxs::KParams<T> P, const jxs::KArgs<T> A) {
   extern __shared__ __align__(16) unsigned char jxs_smem[];
-  const jxs::DeviceLanes<T, G> ln(A.N, reinterpret_cast<T*>(jxs_smem), jxs::lds_words_per_env(G));
+  const jxs::DeviceLanes<T, G> ln(A.N, reinterpret_cast<T*>(jxs_smem),
+                                  MODE == jxs::MODE_STEP_RIGID ? jxs::rigid_lds_words_per_env(P.n_cp)
+                                                               : jxs::lds_words_per_env(G));
   jxs::Core<jxs::DeviceLanes<T, G>> core(P, A, ln);
   core.template run<MODE>();
 }
@@ -61,7 +63,15 @@ hipError_t launch_one(const jxs::KParams<T>& P, const jxs::KArgs<T>& A, hipStrea
   const int blocks = (A.N + envs_per_wave - 1) / envs_per_wave;
   const bool rows = P.row_mode && (MODE == jxs::MODE_STEP || MODE == jxs::MODE_ROLLOUT || MODE == jxs::MODE_FD ||
                                    MODE == jxs::MODE_STEP_RK4);
-  const size_t lds_bytes = rows ? sizeof(T) * (size_t)envs_per_wave * jxs::lds_words_per_env(G) : 0;
+  size_t lds_bytes = rows ? sizeof(T) * (size_t)envs_per_wave * jxs::lds_words_per_env(G) : 0;
+  if (MODE == jxs::MODE_STEP_RIGID) {
+    lds_bytes = sizeof(T) * (size_t)envs_per_wave * jxs::rigid_lds_words_per_env(P.n_cp);
+    if (lds_bytes > 64 * 1024) {  // beyond the default dynamic-LDS window (gfx950 has 160 KiB per CU)
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&jxs_kernel<T, G, MODE>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+      if (e != hipSuccess) return e;
+    }
+  }
   hipLaunchKernelGGL((jxs_kernel<T, G, MODE>), dim3(blocks), dim3(64), lds_bytes, s, P, A);
   return hipGetLastError();
 }
@@ -85,6 +95,7 @@ hipError_t launch_mode(int mode, int G, const jxs::KParams<T>& P, const jxs::KAr
     case jxs::MODE_ID: return launch_g<T, jxs::MODE_ID>(G, P, A, s);
     case jxs::MODE_ROLLOUT: return launch_g<T, jxs::MODE_ROLLOUT>(G, P, A, s);
     case jxs::MODE_STEP_RK4: return launch_g<T, jxs::MODE_STEP_RK4>(G, P, A, s);
+    case jxs::MODE_STEP_RIGID: return launch_g<T, jxs::MODE_STEP_RIGID>(G, P, A, s);
     default: return launch_g<T, jxs::MODE_KIN>(G, P, A, s);
   }
 }
@@ -163,7 +174,7 @@ int create_typed(const jxs_model_desc* d, std::unique_ptr<ModelT<T>>& slot) {
 template <typename T>
 int run_typed(jxs_model* model, int mode, const void* state_in, void* state_out, const void* tau,
               const void* link_f, int force_repr, const void* in_a, void* out_a, void* out_H, void* out_V, int N,
-              int repeat, void* stream) {
+              int repeat, void* stream, void* out_tau) {
   ModelT<T>* mt = typed<T>(model);
   hipStream_t s = static_cast<hipStream_t>(stream);
   jxs::KArgs<T> a = mt->args(N);
@@ -183,10 +194,13 @@ int run_typed(jxs_model* model, int mode, const void* state_in, void* state_out,
     JXS_HIP(hipMemcpyAsync(state_out, state_in, sizeof(T) * elems, hipMemcpyDeviceToDevice, s));
   }
   a.dbg = g_dbg;
+  a.out_tau = static_cast<T*>(out_tau);  // jxs_gravity_torques: RNEA at zero velocity, joint torques only
+  a.id_zero_vel = out_tau != nullptr ? 1 : 0;
   a.n_steps = 1;
   if (mode == jxs::MODE_STEP && mt->pk.integrator == JXS_INTEGRATOR_RUNGE_KUTTA4) {
     mode = jxs::MODE_STEP_RK4;  // four dynamics evaluations per launch; a rollout is one launch per step
   }
+  if (mode == jxs::MODE_STEP && mt->pk.P.rigid) mode = jxs::MODE_STEP_RIGID;  // QP contacts + impact, one launch per step
   if (mode == jxs::MODE_STEP && repeat > 1 && mt->pk.P.n_chunks <= 1) {
     // fused rollout: one launch, the state stays in registers between the steps
     a.n_steps = repeat;
@@ -203,16 +217,16 @@ int run_typed(jxs_model* model, int mode, const void* state_in, void* state_out,
 
 int run_any(jxs_model* model, int mode, const void* state_in, void* state_out, const void* tau, const void* link_f,
             int force_repr, const void* in_a, void* out_a, void* out_H, void* out_V, int N, int repeat,
-            void* stream) {
+            void* stream, void* out_tau = nullptr) {
   if (model == nullptr) return fail(JXS_EINVAL, "null model");
   if (state_in == nullptr) return fail(JXS_EINVAL, "null state");
   if (N <= 0) return fail(JXS_EINVAL, "N must be positive");
   if (force_repr < 0 || force_repr > 2) return fail(JXS_EINVAL, "invalid force representation");
   if (model->dtype == JXS_F64)
     return run_typed<double>(model, mode, state_in, state_out, tau, link_f, force_repr, in_a, out_a, out_H, out_V, N,
-                             repeat, stream);
+                             repeat, stream, out_tau);
   return run_typed<float>(model, mode, state_in, state_out, tau, link_f, force_repr, in_a, out_a, out_H, out_V, N,
-                          repeat, stream);
+                          repeat, stream, out_tau);
 }
 
 // ---- RCCL, resolved lazily so that the library loads (and the CPU symbol test passes)
@@ -345,7 +359,8 @@ int jxs_event_elapsed_ms(void* start, void* stop, float* ms) {
 int jxs_model_create(const jxs_model_desc* desc, jxs_model** out) {
   if (desc == nullptr || out == nullptr) return fail(JXS_EINVAL, "null argument");
   if (desc->dtype != JXS_F32 && desc->dtype != JXS_F64) return fail(JXS_EINVAL, "dtype must be JXS_F32 or JXS_F64");
-  if (desc->D <= 0 && desc->n_points > 0) return fail(JXS_EINVAL, "soft-contact damping D must be positive");
+  if (desc->contact_model == JXS_CONTACT_SOFT && desc->D <= 0 && desc->n_points > 0)
+    return fail(JXS_EINVAL, "soft-contact damping D must be positive");
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count == 0)
     return fail(JXS_ENODEVICE, "no HIP device available (this library has no CPU fallback)");
@@ -394,6 +409,11 @@ int jxs_inverse_dynamics(jxs_model* model, const void* state, const void* in_acc
   if (out_forces == nullptr) return fail(JXS_EINVAL, "null out_forces");
   return run_any(model, jxs::MODE_ID, state, nullptr, nullptr, link_forces, force_repr, in_acc, out_forces, nullptr,
                  nullptr, N, 1, stream);
+}
+int jxs_gravity_torques(jxs_model* model, const void* state, void* out_tau, int N, void* stream) {
+  if (out_tau == nullptr) return fail(JXS_EINVAL, "null out_tau");
+  return run_any(model, jxs::MODE_ID, state, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, N, 1, stream,
+                 out_tau);
 }
 int jxs_refresh_kinematics(jxs_model* model, const void* state, void* out_link_transforms, void* out_link_velocities,
                            int N, void* stream) {

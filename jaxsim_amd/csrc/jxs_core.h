@@ -65,7 +65,8 @@ struct Core {
   template <int MODE>
   JXS_HD void run() {
     constexpr bool kRK4 = (MODE == MODE_STEP_RK4);
-    constexpr bool kStep = (MODE == MODE_STEP || MODE == MODE_ROLLOUT || kRK4);
+    constexpr bool kRigid = (MODE == MODE_STEP_RIGID);
+    constexpr bool kStep = (MODE == MODE_STEP || MODE == MODE_ROLLOUT || kRK4 || kRigid);
     const VI lane = ln.lane();
     ln.stamp(A, 0);
 
@@ -123,6 +124,11 @@ struct Core {
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) q[k] = ln.gload_u(A.state_in, P.row_quat + k, P.n_rows);
+    if (MODE == MODE_ID && A.id_zero_vel) {
+      sd = V(T(0));
+#pragma unroll
+      for (int k = 0; k < 3; ++k) vW[k] = V(T(0)), om[k] = V(T(0));
+    }
     V tau_in = (A.tau != nullptr) ? ln.gload(A.tau, jrow_c, P.n) : V(T(0));
     V f6in[6];
     if (A.link_f != nullptr) {
@@ -132,11 +138,11 @@ struct Core {
     }
     // collidable-point tables of chunk 0 (further chunks are loaded inside the contact loop)
     RowTabs rt;
-    const bool with_rows = P.row_mode && (kStep || MODE == MODE_FD);
+    const bool with_rows = P.row_mode && (kStep || MODE == MODE_FD) && !kRigid;
     if (with_rows) load_row_tabs(rt);
     PointSlot ps0;
-    const bool with_contacts = (kStep) && P.n_chunks > 0;
-    if (with_contacts) load_slot_tables(lane, 0, ps0);
+    const bool with_contacts = (kStep && !kRigid) && P.n_chunks > 0;  // soft contacts (state m)
+    if (with_contacts || (kRigid && P.n_chunks > 0)) load_slot_tables(lane, 0, ps0);
 
     const VM is_joint = jtype != 0;
     const VM is_rev = jtype == 1;
@@ -176,7 +182,9 @@ struct Core {
     // Runge-Kutta 4 (api/integrators.py:91-167): the joint torques above are computed once from the
     // initial state (api/model.py:2658), the stage loop below evaluates system_dynamics
     // (api/ode.py:174-225) at x0, x0 + dt/2 k1, x0 + dt/2 k2, x0 + dt k3.  One stage for Euler.
-    constexpr int n_stages = kRK4 ? 4 : 1;
+    // RigidContacts: stage 0 is the step with QP contact forces, stage 1 re-evaluates the kinematics
+    // and the articulated inertias at the new state for the impact (rbda/contacts/rigid.py:391-446).
+    constexpr int n_stages = kRK4 ? 4 : (kRigid ? 2 : 1);
     V x0s, x0sd, x0q[4], x0p[3], x0v[3], x0w[3], x0m[3];  // stage-0 state (quaternion normalised)
     V ks, ksd, kq[4], kp[3], kv[3], kw[3], km[3];           // weighted sum of the stage derivatives
     V xfl[3], xfa[3];                                       // external link wrench in the stage-0 frame C
@@ -489,7 +497,7 @@ struct Core {
 
     V sdd = V(T(0));
     V acl[3], aca[3];  // base spatial acceleration in C incl. gravity (valid in every lane)
-    if (P.row_mode && (kStep || MODE == MODE_FD)) {
+    if (P.row_mode && (kStep || MODE == MODE_FD) && !kRigid) {
       V a0[6];
       aba_rows(lane, rt, MA, pA, S6, c6, tau, sdd, a0);
 #pragma unroll
@@ -637,6 +645,48 @@ struct Core {
         }
         if (P.floating) acl[2] = acl[2] + P.g;
       }
+      if (kRigid && P.n_chunks > 0) {
+        TreeFac tf;
+  #pragma unroll
+        for (int k = 0; k < 6; ++k) tf.U[k] = U[k], tf.S6[k] = S6[k];
+        tf.inv_d = inv_d;
+        if (P.floating) ldl6_factor(MA, tf);
+        RigidPoints rp;
+        rigid_points(ps0, R, r, vl, va, pB, rp);
+        const VI zero_lane = lane * 0;
+        if (stage == 0) {
+          // contact forces of the QP, then nudot = nudot_free + M^-1 J^T f  (api/ode.py:57-131)
+          V fpt[3];
+          rigid_contact_forces(lane, level, parent, child, tf, ps0, rp, a6, fpt);
+          V w6[6], cfl[3] = {V(T(0)), V(T(0)), V(T(0))}, cfa[3] = {V(T(0)), V(T(0)), V(T(0))};
+  #pragma unroll
+          for (int k = 0; k < 3; ++k) w6[k] = fpt[k];
+          cross(rp.rc, w6, w6 + 3);
+          scatter_point_wrenches(lane, ps0, w6, cfl, cfa);
+          V pAr[1][6], ar[1][6], sddr[1];
+  #pragma unroll
+          for (int k = 0; k < 3; ++k) pAr[0][k] = -cfl[k], pAr[0][3 + k] = -cfa[k];
+          response<1>(lane, level, parent, child, tf, pAr, ar, sddr);
+          sdd = sdd + sddr[0];
+  #pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            acl[k] = acl[k] + (P.floating ? ln.shfl(ar[0][k], zero_lane) : V(T(0)));
+            aca[k] = aca[k] + (P.floating ? ln.shfl(ar[0][3 + k], zero_lane) : V(T(0)));
+          }
+        } else {
+          // velocity reset at impacts: nu+ = nu - M^-1 J^T lambda on the new configuration
+          V dv0[6], dsd;
+          rigid_impact(lane, level, parent, child, tf, ps0, rp, dv0, dsd);
+          sd = sd + vsel(is_joint, dsd, V(T(0)));
+          V t[3];
+          cross(dv0 + 3, pB, t);  // inertial-fixed linear velocity: v_W = v_C - w x p_B
+  #pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            vW[k] = vW[k] + dv0[k] - t[k];
+            om[k] = om[k] + dv0[3 + k];
+          }
+        }
+      }
     }
 
     ln.stamp(A, 9);  // pass 3
@@ -654,7 +704,9 @@ struct Core {
       return;
     }
 
-    if (!kRK4) {
+    if (kRigid && stage == 1) {
+      // impact stage: the velocities were reset above, nothing to integrate
+    } else if (!kRK4) {
     // ---- C: semi-implicit Euler (api/integrators.py:14-88) ---------------------------------
       const V dt = V(P.dt);
       sd = sd + dt * sdd;
@@ -1062,6 +1114,8 @@ struct Core {
     for (int k = 0; k < 3; ++k) ps.m[k] = ln.gload(A.state_in, ps.prow * 3 + (P.row_m + k), P.n_rows);
   }
 
+#include "jxs_rigid.inc"
+
   JXS_HD void contacts(const VI& lane, PointSlot& ps0, const V* R, const V* r, const V* vl, const V* va,
                        const V* pB, const V* doff, const V* vBc, const V* om, V* fl, V* fa) const {
     const V zero = V(T(0));
@@ -1301,6 +1355,8 @@ struct Core {
       }
     }
     V tq = Sl[0] * f6[0] + Sl[1] * f6[1] + Sl[2] * f6[2] + Sa[0] * f6[3] + Sa[1] * f6[4] + Sa[2] * f6[5];
+    if (A.out_tau != nullptr) ln.gstore(A.out_tau, jrow, tq, is_joint, P.n);
+    if (A.out_a == nullptr) return;
     ln.gstore(A.out_a, jrow + 6, tq, is_joint, 6 + P.n);
     // W_f0 = B_X_W^T f_0: move the base wrench from the C origin back to the world origin
     V t[3];

@@ -108,6 +108,9 @@ struct DeviceLanes {
   __device__ __forceinline__ float shfl(float x, int src) const {
     return __int_as_float(__builtin_amdgcn_ds_bpermute(src4(src), __float_as_int(x)));
   }
+  __device__ __forceinline__ int shfl(int x, int src) const { return __builtin_amdgcn_ds_bpermute(src4(src), x); }
+  // true if the predicate holds in any lane of the wave (all environments of this tile)
+  __device__ __forceinline__ bool any(bool m) const { return __builtin_amdgcn_ballot_w64(m) != 0ull; }
   __device__ __forceinline__ double shfl(double x, int src) const {
     const int a = src4(src);
     int lo = __double2loint(x), hi = __double2hiint(x);
@@ -191,6 +194,14 @@ struct DeviceLanes {
     if (mask) lds_[addr] = v;
   }
   __device__ __forceinline__ V lds_read(int addr) const { return lds_[addr]; }
+  // Between LDS writes and reads of ANOTHER lane's data: the hardware keeps the DS queue of a wave in
+  // order, but the compiler reasons per thread (it may forward a masked store to the following load, or
+  // order the two sides of a lane-divergent branch either way) -- this fence pins program order.
+  __device__ __forceinline__ void lds_sync() const { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); }
+  // developer dumps: out[env * stride + idx] = v
+  __device__ __forceinline__ void dbg_store(T* out, int stride, int idx, T v, bool mask) const {
+    if (mask && env_ok_) out[(size_t)env_ * stride + idx] = v;
+  }
 
   // per-lane model constants
   __device__ __forceinline__ V lconstf(const T* tbl, int field) const { return tbl[field * G + lane_]; }

@@ -90,6 +90,26 @@ std::string pack_model(const jxs_model_desc& d, Packed<T>& out) {
   P.n_chunks = n_chunks;
   if (d.integrator == JXS_INTEGRATOR_RUNGE_KUTTA4 && n_chunks > 1)
     return "RungeKutta4 needs every enabled collidable point in one lane group (at most 64 points)";
+  if (d.contact_model != JXS_CONTACT_SOFT && d.contact_model != JXS_CONTACT_RIGID) return "unknown contact model";
+  P.rigid = (d.contact_model == JXS_CONTACT_RIGID && n_en > 0) ? 1 : 0;
+  P.n_cp = n_en;
+  if (P.rigid) {
+    // one point per lane, three rows of the QP per point, both matrices in LDS (jxs_rigid.inc)
+    if (n_en > kRigidMaxPoints) return "RigidContacts: at most 16 enabled collidable points are supported";
+    if (n_chunks > 1) return "RigidContacts needs every enabled collidable point in one lane group";
+    if (!d.floating_base) return "RigidContacts on a fixed-base model is not supported";
+    if (d.integrator != JXS_INTEGRATOR_SEMI_IMPLICIT_EULER) return "RigidContacts is built for the SemiImplicitEuler integrator";
+    if (!(d.regularization_delassus >= 0.0) || !(d.solver_tol > 0.0)) return "invalid RigidContacts options";
+    if (d.suc_H_i[3] != 0.0 || d.suc_H_i[7] != 0.0 || d.suc_H_i[11] != 0.0)
+      return "RigidContacts: a base link pose offset (suc_H_i[0]) is not supported";
+  }
+  P.reg_delassus = (T)d.regularization_delassus;
+  P.qp_tol = (T)d.solver_tol;
+  // Pivots of the (semidefinite) impact system below the rounding floor of J M^-1 J^T count as zero:
+  // contact directions with sigma(J) / sigma_max below ~1e-5 (fp64) are treated as dependent.  The
+  // reference's SVD-based lstsq resolves them down to ~1e-14; both are noise-dominated there
+  // (DESIGN.md section 4d).
+  P.impact_rel_tol = sizeof(T) == 8 ? (T)1e-10 : (T)1e-4;
   P.floating = d.floating_base ? 1 : 0;
 
   // tree structure
@@ -277,7 +297,8 @@ std::string pack_model(const jxs_model_desc& d, Packed<T>& out) {
   {
     const int n_slots_row = G / 8;
     bool ok = G >= 8 && max_depth < kRowLevels && max_depth >= 1;
-    if (std::getenv("JXS_DISABLE_ROW_MODE") != nullptr) ok = false;  // developer knob: A/B the two ABA layouts
+    if (std::getenv("JXS_DISABLE_ROW_MODE") != nullptr) ok = false;
+    if (P.rigid) ok = false;  // the rigid modes use the LDS for the QP and the link-per-lane sweeps  // developer knob: A/B the two ABA layouts
     std::vector<int> width(kRowLevels, 0);
     for (int i = 0; ok && i < nL; ++i) {
       if (++width[level[i]] > n_slots_row) ok = false;

@@ -84,6 +84,10 @@ enum RowI : int {
 // exchange area after the G records: base rows 42 words, a0 6 words, sdd G words
 enum RowLds : int { RL_M = 0, RL_S = 36, RL_C = 42, RL_PA = 48, RL_TAU = 54, RL_SDD = 55 };
 JXS_HD constexpr int lds_words_per_env(int G) { return G * kRowRec + 48; }  // records + base rows (42) + pad
+// rigid modes: Q and H packed lower triangles of order 3 n_cp + one exchange vector (jxs_rigid.inc)
+JXS_HD constexpr int rigid_lds_words_per_env(int n_cp) { return 3 * n_cp * (3 * n_cp + 1) + 3 * n_cp + 8; }
+constexpr int kQpMaxIter = 30;    // interior-point iterations (oracle/refrigid.py QP_MAX_ITER)
+constexpr int kRigidMaxPoints = 16;
 
 enum Mode : int {
   MODE_STEP = 0,  // js.model.step                         api/model.py:2601-2681
@@ -91,7 +95,8 @@ enum Mode : int {
   MODE_ID = 2,    // inverse_dynamics / RNEA               api/model.py:1746-1894
   MODE_KIN = 3,   // cached kinematics of JaxSimModelData  api/data.py:405-523
   MODE_ROLLOUT = 4,  // MODE_STEP repeated KArgs::n_steps times in one launch (state in registers)
-  MODE_STEP_RK4 = 5  // js.model.step with IntegratorType.RungeKutta4  api/integrators.py:91-167
+  MODE_STEP_RK4 = 5,  // js.model.step with IntegratorType.RungeKutta4  api/integrators.py:91-167
+  MODE_STEP_RIGID = 6  // js.model.step with the RigidContacts model    rbda/contacts/rigid.py:176-539
 };
 
 enum ForceRepr : int { REPR_INERTIAL = 0, REPR_BODY = 1, REPR_MIXED = 2 };  // api/common.py:39-47
@@ -127,6 +132,12 @@ struct KParams {
   T base_off[3];                 // translation of suc_H_i[0] (quirk 12)
   T eps;                         // finfo(dtype).eps                     rbda/contacts/soft.py:246
   T quat_K;                      // Baumgarte gain of Quaternion.derivative (0.1)  math/quaternion.py:72
+  // RigidContacts (rbda/contacts/rigid.py:95-174); K, D, mu above are then RigidContactsParams
+  int rigid;                     // contact model: 0 SoftContacts, 1 RigidContacts
+  int n_cp;                      // enabled collidable points (= used slots of chunk 0 in the rigid modes)
+  T reg_delassus;                // regularization_delassus (1e-6)
+  T qp_tol;                      // solver_options["solver_tol"] (1e-3)
+  T impact_rel_tol;              // relative pivot threshold of the semidefinite impact solve
 };
 
 // Device/host pointers handed to the core for one launch.
@@ -149,6 +160,8 @@ struct KArgs {
   T* out_V;            // MODE_KIN: [nL*6][N] inertial-fixed link velocities
   int N;               // batch size (leading dimension of every [row][N] array)
   int n_steps;         // MODE_STEP: consecutive steps fused in this launch (state carried in registers)
+  T* out_tau;          // MODE_ID, optional: joint torques only, [n][N] (the layout `tau` is read in)
+  int id_zero_vel;     // MODE_ID: evaluate at zero velocity (gravity term g(q), api/model.py:1897-1931)
   long long* dbg;      // developer builds (-DJXS_PHASE_TIMING): [blocks][16] cycle stamps, else null
 };
 

@@ -133,9 +133,54 @@ class PlaneTerrain(FlatTerrain):
 class SoftContacts:
     """Marker for the Hunt-Crossley soft-contact model (``rbda/contacts/soft.py:126-444``)."""
 
+    _parameters_class = SoftContactsParams
+
     @classmethod
     def build(cls, **kwargs):
         return cls()
+
+
+@dataclasses.dataclass
+class RigidContactsParams:
+    """``RigidContactsParams`` (``src/jaxsim/rbda/contacts/rigid.py:28-98``): friction coefficient
+    and the Baumgarte gains of the contact constraint (both 0 by default)."""
+
+    mu: float = 0.5
+    K: float = 0.0
+    D: float = 0.0
+
+    @classmethod
+    def build(cls, *, mu=None, K=None, D=None, **kwargs):
+        return cls(mu=0.5 if mu is None else float(mu), K=0.0 if K is None else float(K), D=0.0 if D is None else float(D))
+
+    def valid(self) -> bool:
+        return self.mu >= 0.0 and self.K >= 0.0 and self.D >= 0.0
+
+
+@dataclasses.dataclass(frozen=True)
+class RigidContacts:
+    """``RigidContacts`` (``src/jaxsim/rbda/contacts/rigid.py:95-174``): contact forces from a QP
+    on the Delassus matrix, velocity reset at impacts.  ``solver_options`` accepts ``solver_tol``
+    (the reference forwards the dict to ``qpax.solve_qp``)."""
+
+    regularization_delassus: float = 1e-6
+    solver_tol: float = 1e-3
+    _parameters_class = RigidContactsParams
+
+    @classmethod
+    def build(cls, regularization_delassus=None, solver_options=None, **kwargs):
+        opts = {"solver_tol": 1e-3} | (dict(solver_options) if solver_options is not None else {})
+        unknown = set(opts) - {"solver_tol"}
+        if unknown:
+            raise ValueError(f"unsupported solver options: {sorted(unknown)}")
+        return cls(
+            regularization_delassus=1e-6 if regularization_delassus is None else float(regularization_delassus),
+            solver_tol=float(opts["solver_tol"]),
+        )
+
+    @property
+    def solver_options(self) -> dict:
+        return {"solver_tol": self.solver_tol}
 
 
 class IntegratorType(enum.IntEnum):
@@ -172,7 +217,8 @@ class JaxSimModel:
         self.gravity = float(gravity)
         self.terrain = terrain if terrain is not None else FlatTerrain.build()
         self.contact_model = contact_model if contact_model is not None else SoftContacts.build()
-        self.contact_params = contact_params if contact_params is not None else SoftContactsParams()
+        #: default parameters follow the contact model (``api/model.py:283-286``)
+        self.contact_params = contact_params if contact_params is not None else self.contact_model._parameters_class()
         self.actuation_params = actuation_params if actuation_params is not None else ActuationParams()
         self.integrator = integrator
         self._device = {}  # dtype name -> device handle (see _lib.DeviceModel)

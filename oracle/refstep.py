@@ -690,6 +690,10 @@ def forward_dynamics_aba(model, data: OracleData, *, joint_forces=None, link_for
     return C_vd_WB.astype(dtype), sdd
 
 
+def is_rigid_contact_model(model) -> bool:
+    return type(getattr(model, "contact_model", None)).__name__ == "RigidContacts"
+
+
 def system_acceleration(model, data: OracleData, *, link_forces=None, joint_torques=None):
     """``system_acceleration`` (ode.py:16-131) evaluated in inertial representation, as the
     semi-implicit Euler integrator does (integrators.py:22)."""
@@ -700,7 +704,13 @@ def system_acceleration(model, data: OracleData, *, link_forces=None, joint_torq
     W_f_L_terrain = np.zeros_like(f_L)
     md = np.zeros_like(data.tangential_deformation)
     if kdp.number_of_collidable_points() > 0:  # ode.py:57
-        W_f_L_terrain, md = link_contact_forces(model, data)
+        if is_rigid_contact_model(model):  # contact.py:538-546: rigid models see the applied forces
+            from . import refrigid
+
+            data_in = dataclasses.replace(data, velocity_representation=VelRepr.Inertial)  # integrators.py:22
+            W_f_L_terrain, _ = refrigid.link_contact_forces(model, data_in, link_forces=f_L, joint_torques=joint_torques)
+        else:
+            W_f_L_terrain, md = link_contact_forces(model, data)
     W_f_L_total = f_L + W_f_L_terrain
     data_in = dataclasses.replace(data, velocity_representation=VelRepr.Inertial)
     W_vd_WB, sdd = forward_dynamics_aba(model, data_in, joint_forces=joint_torques, link_forces=W_f_L_total)
@@ -814,7 +824,12 @@ def step(model, data: OracleData, *, link_forces=None, joint_force_references=No
         else np.zeros_like(data.joint_positions)
     )
     tau_total = compute_resultant_torques(model, data, joint_force_references=tau_ref)
-    return _INTEGRATORS[int(getattr(model, "integrator", 0))](model, data, W_f_L, tau_total)
+    data_tf = _INTEGRATORS[int(getattr(model, "integrator", 0))](model, data, W_f_L, tau_total)
+    if is_rigid_contact_model(model):  # model.py:2677-2679
+        from . import refrigid
+
+        data_tf = refrigid.update_velocity_after_impact(model, data_tf)
+    return data_tf
 
 
 # =============================================================================================

@@ -15,6 +15,7 @@
 namespace {
 
 thread_local std::string g_err;
+void* g_dbg_ptr = nullptr;
 
 template <typename T, int G>
 void run_group(const jxs::Packed<T>& pk, jxs::KArgs<T> a, int mode) {
@@ -25,7 +26,7 @@ void run_group(const jxs::Packed<T>& pk, jxs::KArgs<T> a, int mode) {
   a.head = pk.head.data();
   a.rti = pk.rti.data();
   for (int env = 0; env < a.N; ++env) {
-    jxs::HostLanes<T, G> ln(a.N, env);
+    jxs::HostLanes<T, G> ln(a.N, env, (size_t)jxs::rigid_lds_words_per_env(pk.P.n_cp));
     jxs::Core<jxs::HostLanes<T, G>> core(pk.P, a, ln);
     switch (mode) {
       case jxs::MODE_STEP: core.template run<jxs::MODE_STEP>(); break;
@@ -33,6 +34,7 @@ void run_group(const jxs::Packed<T>& pk, jxs::KArgs<T> a, int mode) {
       case jxs::MODE_ID: core.template run<jxs::MODE_ID>(); break;
       case jxs::MODE_ROLLOUT: core.template run<jxs::MODE_ROLLOUT>(); break;
       case jxs::MODE_STEP_RK4: core.template run<jxs::MODE_STEP_RK4>(); break;
+      case jxs::MODE_STEP_RIGID: core.template run<jxs::MODE_STEP_RIGID>(); break;
       default: core.template run<jxs::MODE_KIN>(); break;
     }
   }
@@ -60,6 +62,7 @@ int run_typed(const jxs_model_desc* d, int mode, const void* state_in, void* sta
   a.out_V = static_cast<T*>(out_V);
   a.N = N;
   a.n_steps = n_steps;
+  a.dbg = static_cast<long long*>(g_dbg_ptr);
   if (mode == jxs::MODE_STEP && state_out != state_in && pk.n_disabled > 0)
 {
     const int tile = 64 / pk.G;
@@ -68,7 +71,9 @@ int run_typed(const jxs_model_desc* d, int mode, const void* state_in, void* sta
   int launches = 1;
   const bool rk4 = (mode == jxs::MODE_STEP && pk.integrator == JXS_INTEGRATOR_RUNGE_KUTTA4);
   if (rk4) mode = jxs::MODE_STEP_RK4;
-  if (rk4 && n_steps > 1) {
+  const bool rigid = (mode == jxs::MODE_STEP && pk.P.rigid);
+  if (rigid) mode = jxs::MODE_STEP_RIGID;
+  if ((rk4 || rigid) && n_steps > 1) {
     launches = n_steps;
     a.n_steps = 1;
   }
@@ -96,6 +101,7 @@ int run_typed(const jxs_model_desc* d, int mode, const void* state_in, void* sta
 extern "C" {
 
 const char* jxs_emul_last_error(void) { return g_err.c_str(); }
+void jxs_emul_set_debug(void* p) { g_dbg_ptr = p; }
 
 int jxs_emul_layout(const jxs_model_desc* d, jxs_layout* out) {
   jxs::Packed<double> pk;

@@ -6,6 +6,7 @@
 // lanes of the group.  This is what lets the CPU test-suite (-m "not gpu") check the kernel
 // logic against the oracle without a GPU.  It is never shipped or benchmarked.
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <cstddef>
 #include <vector>
@@ -29,7 +30,7 @@ struct Vec {
     for (int i = 0; i < G; ++i) r.v[i] = a.v[i] op b.v[i];    \
     return r;                                                 \
   }
-  JXS_BIN(+) JXS_BIN(-) JXS_BIN(*) JXS_BIN(/) JXS_BIN(&) JXS_BIN(>>)
+  JXS_BIN(+) JXS_BIN(-) JXS_BIN(*) JXS_BIN(/) JXS_BIN(&) JXS_BIN(>>) JXS_BIN(^)
 #undef JXS_BIN
 #define JXS_CMP(op)                                              \
   friend Vec<bool, G> operator op(const Vec& a, const Vec& b) {  \
@@ -131,7 +132,18 @@ struct HostLanes {
   int env_;
   int N_;
   mutable std::vector<T_> lds_;
-  HostLanes(int N, int env) : env_(env), N_(N), lds_((size_t)G_ * kRowRec + 64 + G_, T_(0)) {}
+  HostLanes(int N, int env, size_t lds_words = 0)
+      : env_(env), N_(N), lds_(std::max((size_t)G_ * kRowRec + 64 + G_, lds_words), T_(0)) {}
+  void dbg_store(T* out, int stride, int idx, const V& v, const VM& mask) const {
+    for (int i = 0; i < G; ++i)
+      if (mask.v[i]) out[(size_t)env_ * stride + idx] = v.v[i];
+  }
+  void lds_sync() const {}
+  bool any(const VM& m) const {
+    for (int i = 0; i < G; ++i)
+      if (m.v[i]) return true;
+    return false;
+  }
 
   VI lane() const {
     VI r;

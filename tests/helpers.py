@@ -130,3 +130,15 @@ def upcast(d: oracle.OracleData) -> oracle.OracleData:
         v = getattr(d, fld.name)
         kw[fld.name] = v.astype(np.float64) if isinstance(v, np.ndarray) else v
     return oracle.OracleData(**kw)
+
+
+def rigid_model(model, idx, *, build=None, **params):
+    """Host model with the RigidContacts model on the enabled points ``idx`` (reference idiom:
+    ``tests/test_simulations.py:245-270``)."""
+    cm = ja.RigidContacts.build(**(build or {}))
+    return enable_points(with_params(model, contact_model=cm, contact_params=ja.RigidContactsParams(**params)), idx)
+
+
+#: bottom corners of the four foot boxes of the synthetic quadruped (16 points), one corner per foot (4)
+ANYMAL_FEET_16 = [0, 1, 2, 3, 8, 9, 10, 11, 16, 17, 18, 19, 24, 25, 26, 27]
+ANYMAL_FEET_4 = [0, 8, 16, 24]

@@ -342,3 +342,101 @@ def test_rk4_rollout_and_free_fall_gpu(models):
     t = 50 * box.time_step
     expect = np.array([0.0, 0.0, 5.0]) + v0 * t + 0.5 * np.array([0.0, 0.0, box.gravity]) * t * t
     np.testing.assert_allclose(blk[0:3, 0], expect, rtol=0, atol=1e-12)
+
+
+# ---- RigidContacts (rbda/contacts/rigid.py:176-539; BASELINE.json config 5) ----------------------
+RIGID_CASES = {
+    "box4": ("box", [0, 1, 2, 3], dict(K=1e5)),
+    "anymal16": ("anymal", helpers.ANYMAL_FEET_16, dict(K=1e4, D=1e2)),
+    "anymal4": ("anymal", helpers.ANYMAL_FEET_4, dict()),
+    "chain9f6": ("chain9f", [0, 1, 2, 3, 8, 9], dict(K=1e3, mu=0.8)),
+    "icub8": ("icub16", [0, 1, 2, 3, 8, 9, 10, 11], dict(K=1e4)),
+}
+
+
+@pytest.fixture()
+def reduced_qp():
+    """The kernel solves the reduced statement of the reference's QP (oracle/refrigid.py)."""
+    from oracle import refrigid
+
+    refrigid.REDUCED_QP = True
+    yield refrigid
+    refrigid.REDUCED_QP = False
+
+
+@pytest.mark.parametrize("key", list(RIGID_CASES))
+def test_rigid_step_matches_oracle_gpu(models, reduced_qp, key):
+    name, idx, params = RIGID_CASES[key]
+    model = helpers.rigid_model(models(name), idx, **params)
+    N = 21  # not a multiple of the environments per wave
+    d = models.random_data(name, N, seed=5)
+    tau, f = helpers.random_inputs(model, N, 7, np.float64)
+    ref = oracle.step(model, d, link_forces=f, joint_force_references=tau)
+    out = js.model.step(model, to_gpu(model, d), link_forces=f, joint_force_references=tau)
+    # 1e-7: with several points on one rigid body the QP Hessian is singular up to the 1e-6 shift
+    # (condition ~1e7), rounding differences between the two implementations are amplified by it
+    assert helpers.rel_err(out.state_block(), helpers.odata_to_block(model, ref)) < 1e-7
+
+
+@pytest.mark.parametrize("key,tol", [("anymal4", 3e-3), ("icub8", 3e-3), ("anymal16", 3e-3), ("box4", 2e-2)])
+def test_rigid_step_fp32_gpu(models, reduced_qp, key, tol):
+    """fp32 against the fp64 oracle on the same inputs: 3e-3 like the soft-contact path (measured
+    3e-6 .. 6e-5 on the articulated models).  The box case (1 kg, K = 1e5 with centimetres of
+    penetration, i.e. contact forces of 1e3 N on four coplanar points whose 12x12 Delassus matrix has
+    rank 6 plus the 1e-6 shift) is the stress case: 6e-3 measured, 2e-2 allowed."""
+    name, idx, params = RIGID_CASES[key]
+    model = helpers.rigid_model(models(name), idx, **params)
+    d = models.random_data(name, 40, seed=5, dtype=np.float32)
+    ref = oracle.step(model, helpers.upcast(d))
+    out = js.model.step(model, to_gpu(model, d))
+    blk = out.state_block()
+    assert blk.dtype == np.float32 and np.isfinite(blk).all()
+    assert helpers.rel_err(blk, helpers.odata_to_block(model, ref)) < tol
+
+
+@pytest.mark.parametrize("dtype,atol", [(np.float64, 1e-4), (np.float32, 2e-4)])
+def test_rigid_box_settles_known_answer_gpu(models, dtype, atol):
+    """reference tests/test_simulations.py:245-292."""
+    model = helpers.rigid_model(models("box"), [0, 1, 2, 3], build=dict(solver_options={"solver_tol": 1e-3}), K=1e5)
+    d = oracle.OracleData.build(model, base_position=[0.0, 0.0, 0.2], velocity_representation=VelRepr.Inertial, dtype=dtype)
+    out = js.model.rollout(model, to_gpu(model, d), 1000).state_block()
+    assert abs(out[0, 0]) < 1e-6 and abs(out[1, 0]) < 1e-6
+    assert out[2, 0] == pytest.approx(0.05, abs=atol)
+
+
+def test_rigid_tumbling_box_rollout_gpu(models, reduced_qp):
+    model = helpers.rigid_model(models("box"), [0, 1, 2, 3], K=1e5)
+    q = oracle.refmath.quaternion_from_euler_xyz(np.array([[0.3, 0.2, 0.1]]))
+    d = oracle.OracleData.build(model, base_position=[0, 0, 0.3], base_quaternion=q, base_linear_velocity=[0.5, 0, 0])
+    out = js.model.rollout(model, to_gpu(model, d), 300).state_block()
+    for _ in range(300):
+        d = oracle.step(model, d)
+    assert helpers.rel_err(out, helpers.odata_to_block(model, d)) < 1e-7
+
+
+def test_config5_quadruped_rigid_contacts_with_gravity_compensation(models, reduced_qp):
+    """BASELINE.json config 5: quadruped, RigidContacts, tau = RNEA gravity term, fp32, batch 4096.
+    Oracle parity on a slice of the batch (fp64 truth), device-resident controller loop, finiteness
+    and batch independence at the full size."""
+    model = helpers.rigid_model(models("anymal"), helpers.ANYMAL_FEET_4, K=1e4, D=2e2)
+    N = 4096
+    d32 = models.random_data("anymal", N, seed=11, dtype=np.float32)
+    g = to_gpu(model, d32)
+    tau = js.model.gravity_compensation_torques(model, g)
+    runtime.synchronize()
+    # the device torque block equals the joint part of free_floating_gravity_forces
+    gq = js.model.free_floating_gravity_forces(model, g)[:, 6:]
+    np.testing.assert_allclose(tau.to_host().T, gq, rtol=1e-5, atol=1e-4)
+    sub = dataclasses.replace(helpers.upcast(d32), **{
+        f.name: getattr(helpers.upcast(d32), f.name)[:24] for f in dataclasses.fields(d32)
+        if isinstance(getattr(d32, f.name), np.ndarray)})  # fmt: skip
+    ref_tau = oracle.free_floating_gravity_forces(model, sub)[:, 6:]
+    np.testing.assert_allclose(gq[:24], ref_tau, rtol=1e-4, atol=1e-3)
+    out = js.model.step(model, g, joint_force_references=tau).state_block()
+    assert np.isfinite(out).all()
+    ref = oracle.step(model, sub, joint_force_references=ref_tau)
+    assert helpers.rel_err(out[:, :24], helpers.odata_to_block(model, ref)) < 3e-3
+    # batch independence: the first 24 environments alone give the same bits
+    g24 = js.data.JaxSimModelData.from_state_block(model, helpers.odata_to_block(model, d32)[:, :24], ja.VelRepr.Mixed)
+    out24 = js.model.step(model, g24, joint_force_references=tau.to_host()[:, :24].T).state_block()
+    np.testing.assert_array_equal(out24, out[:, :24])

@@ -1,0 +1,71 @@
+"""Developer tool: time BASELINE.json config 5 on one GPU -- synthetic ANYmal-like quadruped
+(13 links, 12 DoF), RigidContacts, tau = RNEA gravity term recomputed every step on the device,
+fp32, batch 4096.  Not the headline benchmark (bench.py measures config 3); the numbers feed
+DESIGN.md section 6.
+
+    python tools/bench_c5.py [--points 4|16] [--envs 4096] [--steps 200]
+"""
+
+import argparse
+import ctypes as C
+import json
+import pathlib
+import sys
+
+import numpy as np
+
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--points", type=int, default=4, choices=[4, 16])
+    ap.add_argument("--envs", type=int, default=4096)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--dtype", default="float32")
+    args = ap.parse_args()
+
+    import helpers  # tests/helpers.py: model zoo + rigid_model
+    import jaxsim_amd.api as js
+    from jaxsim_amd import _lib, runtime
+
+    runtime.require_device()
+    zoo = helpers.ModelZoo()
+    idx = helpers.ANYMAL_FEET_4 if args.points == 4 else helpers.ANYMAL_FEET_16
+    model = helpers.rigid_model(zoo("anymal"), idx, K=1e4, D=2e2)
+    dtype = np.dtype(args.dtype)
+    d = zoo.random_data("anymal", args.envs, seed=0, dtype=dtype)
+    data = js.data.JaxSimModelData.from_state_block(model, helpers.odata_to_block(model, d), 2)
+    dm = runtime.device_model(model, dtype)
+    lib = _lib.load()
+    stream = runtime.Stream()
+    runtime.set_stream(stream)
+    tau = runtime.DeviceArray(model.dofs(), args.envs, dtype, tile=data._state.tile, zero=True)
+    st, tp = C.c_void_p(data._state.ptr), C.c_void_p(tau.ptr)
+
+    def run(k):
+        for _ in range(k):
+            _lib.check(lib.jxs_gravity_torques(dm.handle, st, tp, args.envs, stream.handle), "jxs_gravity_torques")
+            _lib.check(lib.jxs_step(dm.handle, st, st, tp, None, 2, args.envs, stream.handle), "jxs_step")
+
+    run(args.warmup)
+    stream.synchronize()
+    e0, e1 = runtime.Event(), runtime.Event()
+    e0.record(stream)
+    run(args.steps)
+    e1.record(stream)
+    stream.synchronize()
+    ms = e0.elapsed_ms(e1) / args.steps
+    blk = data.state_block()
+    print(json.dumps({
+        "workload": f"config 5: anymal12 synthetic, RigidContacts ({args.points} points), gravity compensation, {args.dtype}",
+        "envs": args.envs, "steps": args.steps, "ms_per_step": ms, "env_steps_per_s": args.envs / (ms * 1e-3),
+        "finite_envs": float(np.isfinite(blk).all(axis=0).mean()), "lanes_per_env": int(dm.layout.group),
+    }))  # fmt: skip
+
+
+if __name__ == "__main__":
+    main()
