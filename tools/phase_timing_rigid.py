@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Developer tool: cycle breakdown of the RigidContacts step (library built with -DJXS_PHASE_TIMING,
+JAXSIM_AMD_LIB=.../libjaxsim_amd_timing.so).  python tools/phase_timing_rigid.py [points] [N]"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import helpers  # noqa: E402
+import jaxsim_amd.api as js  # noqa: E402
+from jaxsim_amd import _lib, runtime  # noqa: E402
+
+pts = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+zoo = helpers.ModelZoo()
+model = helpers.rigid_model(zoo("anymal"), helpers.ANYMAL_FEET_4 if pts == 4 else helpers.ANYMAL_FEET_16, K=1e4, D=2e2)
+d = zoo.random_data("anymal", N, seed=0, dtype=np.float32)
+data = js.data.JaxSimModelData.from_state_block(model, helpers.odata_to_block(model, d), 2)
+lib = _lib.load()
+dm = runtime.device_model(model, np.float32)
+blocks = (N + dm.layout.tile - 1) // dm.layout.tile
+buf = C.c_void_p()
+lib.jxs_malloc(C.byref(buf), blocks * 16 * 8)
+lib.jxs_debug_set_stamp_buffer.argtypes = [C.c_void_p]
+ptr = C.c_void_p(data._state.ptr)
+for _ in range(60):
+    lib.jxs_step(dm.handle, ptr, ptr, None, None, 2, N, None)
+lib.jxs_memset(buf, 0, blocks * 16 * 8, None)
+lib.jxs_debug_set_stamp_buffer(buf)
+lib.jxs_step(dm.handle, ptr, ptr, None, None, 2, N, None)
+runtime.synchronize()
+out = np.zeros((blocks, 16), dtype=np.int64)
+lib.jxs_memcpy_d2h(out.ctypes.data_as(C.c_void_p), buf, out.nbytes, None)
+has = (out[:, 11] > 0) & (out[:, 14] > 0)
+print(f"points={pts} N={N}: {blocks} waves, {has.sum()} with contacts in both stages")
+o = out[has]
+tot = o[:, 10] - o[:, 0]
+print("  total                 %9.0f (max %d)" % (tot.mean(), tot.max()))
+print("  stage0 delassus       %9.0f" % (o[:, 12] - o[:, 11]).mean())
+print("  stage0 QP             %9.0f (max %d)" % ((o[:, 13] - o[:, 12]).mean(), (o[:, 13] - o[:, 12]).max()))
+print("  stage1 delassus+impact%9.0f" % (o[:, 15] - o[:, 14]).mean())
+print("  everything else       %9.0f" % (tot - (o[:, 13] - o[:, 11]) - (o[:, 15] - o[:, 14])).mean())
+free = out[~has & (out[:, 10] > 0)]
+if len(free):
+    print("  waves without contact: total %9.0f" % (free[:, 10] - free[:, 0]).mean())
