@@ -178,6 +178,42 @@ struct DeviceLanes {
 #pragma unroll
     for (int k = 0; k < 7; ++k) x[k] = x[k] + dpp<0x141>(x[k]);
   }
+  // Reductions over the G lanes of one environment, result in every lane: DPP butterflies inside a
+  // 16-lane row (quad_perm, row_half_mirror, row_mirror), ds_bpermute only across rows (G = 32, 64).
+  template <class Op>
+  __device__ __forceinline__ V env_reduce(V x, Op op) const {
+    if (G >= 2) x = op(x, dpp<0xB1>(x));   // quad_perm:[1,0,3,2]
+    if (G >= 4) x = op(x, dpp<0x4E>(x));   // quad_perm:[2,3,0,1]
+    if (G >= 8) x = op(x, dpp<0x141>(x));  // row_half_mirror
+    if (G >= 16) x = op(x, dpp<0x140>(x)); // row_mirror
+    if (G >= 32) x = op(x, shfl(x, lane_ ^ 16));
+    if (G >= 64) x = op(x, shfl(x, lane_ ^ 32));
+    return x;
+  }
+  __device__ __forceinline__ V env_sum(V x) const { return env_reduce(x, [](V a, V b) { return a + b; }); }
+  __device__ __forceinline__ V env_max(V x) const { return env_reduce(x, [](V a, V b) { return vmax(a, b); }); }
+  __device__ __forceinline__ V env_min(V x) const { return env_reduce(x, [](V a, V b) { return vmin(a, b); }); }
+  // Value of lane `src` (wave-uniform) of this environment in all its lanes.  G >= 8: one v_readlane
+  // per environment of the wave (scalar lane select, no LDS crossbar round trip, no branch) and a
+  // select on the environment index; G = 4 (16 environments per wave): ds_bpermute.
+  __device__ __forceinline__ int env_bcast_bits(int v, int src) const {
+    if (G < 8) return __builtin_amdgcn_ds_bpermute(src4(src), v);
+    constexpr int E = 64 / G;  // environments per wave: 1, 2, 4 or 8
+    int r[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) r[e] = __builtin_amdgcn_readlane(v, e * G + src);
+    int out = r[0];
+#pragma unroll
+    for (int e = 1; e < E; ++e) out = (sub_ == e) ? r[e] : out;
+    return out;
+  }
+  __device__ __forceinline__ float env_bcast16(float x, int src) const {
+    return __int_as_float(env_bcast_bits(__float_as_int(x), src));
+  }
+  __device__ __forceinline__ double env_bcast16(double x, int src) const {
+    const int lo = env_bcast_bits(__double2loint(x), src), hi = env_bcast_bits(__double2hiint(x), src);
+    return __hiloint2double(hi, lo);
+  }
   // keep a wave-uniform kernel-argument value in an SGPR from here on
   static __device__ __forceinline__ unsigned pin(unsigned x) {
     asm volatile("" : "+s"(x));

@@ -139,6 +139,22 @@ struct HostLanes {
       if (mask.v[i]) out[(size_t)env_ * stride + idx] = v.v[i];
   }
   void lds_sync() const {}
+  V env_sum(const V& x) const {
+    T acc = T(0);
+    for (int i = 0; i < G; ++i) acc += x.v[i];
+    return V(acc);
+  }
+  V env_max(const V& x) const {
+    T acc = x.v[0];
+    for (int i = 1; i < G; ++i) acc = std::fmax(acc, x.v[i]);
+    return V(acc);
+  }
+  V env_min(const V& x) const {
+    T acc = x.v[0];
+    for (int i = 1; i < G; ++i) acc = std::fmin(acc, x.v[i]);
+    return V(acc);
+  }
+  V env_bcast16(const V& x, int src) const { return V(x.v[src]); }
   bool any(const VM& m) const {
     for (int i = 0; i < G; ++i)
       if (m.v[i]) return true;
