@@ -37,6 +37,30 @@ def main():
             id=np.concatenate([fB, tid], -1), link_transforms=d.link_transforms, link_velocities=d.link_velocities,
         )  # fmt: skip
         print("wrote", name)
+    # other integrator / contact model: one step each (inputs + expected next state)
+    import jaxsim_amd as ja
+
+    soft = ja.SoftContactsParams.build(K=2e4, D=60.0, mu=0.6)
+    for name in ("cartpole", "chain9f", "icub"):
+        model = helpers.with_params(zoo(name), integrator=ja.IntegratorType.RungeKutta4, contact_params=soft)
+        d = zoo.random_data(name, 4, seed=2027, rep=oracle.VelRepr.Mixed)
+        tau, f = helpers.random_inputs(model, 4, 2028, np.float64)
+        nxt = oracle.step(model, d, link_forces=f, joint_force_references=tau)
+        np.savez_compressed(OUT / f"rk4_{name}.npz", state=helpers.odata_to_block(model, d), tau=tau, link_forces=f,
+                            step=helpers.odata_to_block(model, nxt))  # fmt: skip
+        print("wrote rk4", name)
+    # RigidContacts, default solver_tol, the reduced statement of the QP (the one the kernel solves)
+    from oracle import refrigid
+
+    refrigid.REDUCED_QP = True
+    for name, idx, params in (("box", [0, 1, 2, 3], dict(K=1e5)), ("anymal", helpers.ANYMAL_FEET_4, dict(K=1e4, D=2e2))):
+        model = helpers.rigid_model(zoo(name), idx, **params)
+        d = zoo.random_data(name, 6, seed=5, rep=oracle.VelRepr.Mixed)
+        tau, f = helpers.random_inputs(model, 6, 2029, np.float64)
+        nxt = oracle.step(model, d, link_forces=f, joint_force_references=tau)
+        np.savez_compressed(OUT / f"rigid_{name}.npz", state=helpers.odata_to_block(model, d), tau=tau, link_forces=f,
+                            step=helpers.odata_to_block(model, nxt), enabled=np.array(idx), K=params["K"], D=params.get("D", 0.0))  # fmt: skip
+        print("wrote rigid", name)
 
 
 if __name__ == "__main__":

@@ -440,3 +440,29 @@ def test_config5_quadruped_rigid_contacts_with_gravity_compensation(models, redu
     g24 = js.data.JaxSimModelData.from_state_block(model, helpers.odata_to_block(model, d32)[:, :24], ja.VelRepr.Mixed)
     out24 = js.model.step(model, g24, joint_force_references=tau.to_host()[:, :24].T).state_block()
     np.testing.assert_array_equal(out24, out[:, :24])
+
+
+@pytest.mark.parametrize("name", ["cartpole", "chain9f", "icub"])
+def test_gpu_golden_rk4(models, name):
+    import test_golden as tg
+
+    g, model = tg.load(f"rk4_{name}"), tg._rk4_model(models, name)
+    N = g["state"].shape[1]
+    data = js.data.JaxSimModelData.from_state_block(model, g["state"], ja.VelRepr.Mixed)
+    out = js.model.step(model, data, link_forces=g["link_forces"], joint_force_references=g["tau"])
+    assert helpers.rel_err(out.state_block(), g["step"]) < helpers.FP64_TOL
+    out32 = js.model.step(model, js.data.JaxSimModelData.from_state_block(model, g["state"].astype(np.float32), ja.VelRepr.Mixed),
+                          link_forces=g["link_forces"], joint_force_references=g["tau"])  # fmt: skip
+    assert helpers.rel_err(out32.state_block(), g["step"]) < helpers.FP32_TOL
+    assert N == 4
+
+
+@pytest.mark.parametrize("name", ["box", "anymal"])
+def test_gpu_golden_rigid(models, name):
+    import test_golden as tg
+
+    g = tg.load(f"rigid_{name}")
+    model = tg._rigid_model(models, name, g)
+    data = js.data.JaxSimModelData.from_state_block(model, g["state"], ja.VelRepr.Mixed)
+    out = js.model.step(model, data, link_forces=g["link_forces"], joint_force_references=g["tau"])
+    assert helpers.rel_err(out.state_block(), g["step"]) < 1e-7
