@@ -77,6 +77,9 @@ std::string pack_model(const jxs_model_desc& d, Packed<T>& out) {
   const int n_en = (int)en.size();
   int G = pow2ceil(std::max(nL, std::min(n_en, 32)));
   G = std::max(G, 4);
+  // RungeKutta4 keeps the tangential deformation of every point in registers across its stages: one
+  // point chunk, so up to 64 points get a lane each (semi-implicit Euler prefers 32 lanes + 2 chunks)
+  if (d.integrator == JXS_INTEGRATOR_RUNGE_KUTTA4 && n_en > 32 && n_en <= 64) G = 64;
   out.G = G;
   const int n_chunks = (n_en + G - 1) / G;
   const int n_slots = n_chunks * G;

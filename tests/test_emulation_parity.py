@@ -242,7 +242,7 @@ def test_plane_terrain_box_slides_downhill(models):
 
 
 # ---- Runge-Kutta 4 (reference: api/integrators.py:91-167) -----------
-RK4_MODELS = ["box", "pendulum", "cartpole", "chain9f", "anymal", "icub16"]
+RK4_MODELS = ["box", "sphere", "pendulum", "cartpole", "chain9f", "anymal", "icub16"]  # sphere: 50 points -> 64 lanes
 
 
 def _rk4(model):
@@ -345,8 +345,10 @@ def test_rk4_needs_one_chunk_of_points(models):
     import jaxsim_amd as ja
     from jaxsim_amd import robots
 
-    big = ja.JaxSimModel.build_from_model_description(robots.icub23_urdf(sole_boxes_per_foot=3))
-    assert eb.layout(big).n_points > eb.layout(big).group  # fine with the Euler integrator
+    mid = ja.JaxSimModel.build_from_model_description(robots.icub23_urdf(sole_boxes_per_foot=3))  # 48 points
+    assert eb.layout(mid).group == 32 and eb.layout(_rk4(mid)).group == 64  # RK4: one lane per point
+    big = ja.JaxSimModel.build_from_model_description(robots.icub23_urdf(sole_boxes_per_foot=5))  # 80 points
+    assert eb.layout(big).n_points > 64  # fine with the Euler integrator
     with pytest.raises(RuntimeError, match="RungeKutta4"):
         eb.layout(_rk4(big))
     with pytest.raises(RuntimeError, match="unsupported integrator"):

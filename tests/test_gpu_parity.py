@@ -305,7 +305,7 @@ def _rk4(model):
     return helpers.with_params(model, integrator=ja.IntegratorType.RungeKutta4, contact_params=soft)
 
 
-@pytest.mark.parametrize("name", ["box", "cartpole", "chain9f", "anymal", "icub16", "icub"])
+@pytest.mark.parametrize("name", ["box", "sphere", "cartpole", "chain9f", "anymal", "icub16", "icub"])
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_rk4_step_matches_oracle_gpu(models, name, dtype):
     model = _rk4(models(name))
