@@ -39,6 +39,30 @@ def _ptr(d: DeviceArray | None):
     return None if d is None else C.c_void_p(d.ptr)
 
 
+def reduce(model: JaxSimModel, considered_joints, locked_joint_positions: dict | None = None) -> JaxSimModel:
+    """``js.model.reduce`` (``src/jaxsim/api/model.py:807-878``): lump the links connected by the
+    joints that are not in ``considered_joints``, locked at ``locked_joint_positions`` (default 0).
+    The reduced model keeps the time step, terrain, contact model / parameters, actuation parameters,
+    gravity and integrator of ``model``."""
+    src = model.__dict__.get("built_from")
+    if src is None:
+        raise ValueError("the model was not built from a model description: nothing to reduce")
+    locked = dict(locked_joint_positions or {})
+    return JaxSimModel.build_from_model_description(
+        src,
+        model_name=model.name(),
+        time_step=model.time_step,
+        terrain=model.terrain,
+        contact_model=model.contact_model,
+        contact_params=model.contact_params,
+        actuation_params=model.actuation_params,
+        integrator=model.integrator,
+        gravity=-model.gravity,
+        considered_joints=tuple(considered_joints),
+        locked_joint_positions=locked,
+    )
+
+
 def step(
     model: JaxSimModel,
     data: JaxSimModelData,

@@ -236,14 +236,20 @@ class JaxSimModel:
         actuation_params: ActuationParams | None = None,
         integrator: IntegratorType | None = None,
         gravity: float = STANDARD_GRAVITY,
+        considered_joints=None,
+        locked_joint_positions: dict | None = None,
     ) -> "JaxSimModel":
         """Build from a URDF path or string (``src/jaxsim/api/model.py:128-223``).
 
         ``gravity`` is the positive magnitude; the stored value is ``-gravity``.
+        ``considered_joints`` keeps only the listed joints, the others are locked (at
+        ``locked_joint_positions``, default 0) and their links lumped (``:807-878``).
         """
-        desc = urdf_parser.parse_urdf(str(model_description))
+        desc = urdf_parser.parse_urdf(
+            str(model_description), considered_joints=considered_joints, locked_joint_positions=locked_joint_positions
+        )
         kdp = KinDynParameters.build(desc)
-        return JaxSimModel(
+        model = JaxSimModel(
             model_name or desc.name,
             kdp,
             floating_base=not desc.fixed_base,
@@ -255,6 +261,8 @@ class JaxSimModel:
             actuation_params=actuation_params,
             integrator=IntegratorType.SemiImplicitEuler if integrator is None else integrator,
         )
+        model.__dict__["built_from"] = str(model_description)  # origin, for `js.model.reduce`
+        return model
 
     # -- reference accessors (``src/jaxsim/api/model.py:674-799``) ---------------------------
     def name(self) -> str:

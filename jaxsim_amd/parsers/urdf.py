@@ -151,8 +151,29 @@ def _sphere_points(radius, H) -> np.ndarray:
     return (H[:3, :3] @ pts.T).T + H[:3, 3]
 
 
-def parse_urdf(urdf: str, *, is_path: bool | None = None) -> ModelDescription:
-    """Parse a URDF string or path into a reduced (fixed joints lumped) description."""
+def _joint_motion(jtype: int, axis: np.ndarray, q: float) -> np.ndarray:
+    """``pre_H_suc`` of a 1-DoF joint at position ``q`` (``math/joint_model.py:146-200``)."""
+    H = np.eye(4)
+    if jtype == REVOLUTE:
+        K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+        H[:3, :3] = np.eye(3) + np.sin(q) * K + (1 - np.cos(q)) * (K @ K)
+    elif jtype == PRISMATIC:
+        H[:3, 3] = q * axis
+    return H
+
+
+def parse_urdf(
+    urdf: str,
+    *,
+    is_path: bool | None = None,
+    considered_joints: list[str] | tuple[str, ...] | None = None,
+    locked_joint_positions: dict[str, float] | None = None,
+) -> ModelDescription:
+    """Parse a URDF string or path into a reduced (fixed joints lumped) description.
+
+    ``considered_joints`` (``api/model.py:128-223,807-878``): the 1-DoF joints to keep; every other
+    joint is locked at ``locked_joint_positions.get(name, 0.0)`` and removed by lumping its child into
+    the parent, exactly like a fixed joint (``parsers/kinematic_graph.py:379-611``)."""
     if is_path is None:
         is_path = not urdf.lstrip().startswith("<")
     root = ET.parse(urdf).getroot() if is_path else ET.fromstring(urdf)
@@ -216,6 +237,20 @@ def parse_urdf(urdf: str, *, is_path: bool | None = None) -> ModelDescription:
                 position_limit_spring=float(os.environ.get("JAXSIM_JOINT_POSITION_LIMIT_SPRING", 0.0)),
             )
         )
+
+    # ---- model reduction: lock the joints that are not considered --------------------------
+    if considered_joints is not None:
+        movable = {j.name for j in raw_joints if j.jtype != FIXED}
+        unknown = set(considered_joints) - {j.name for j in raw_joints}
+        if unknown:
+            raise ValueError(f"considered joints not existing in the model: {sorted(unknown)}")
+        locked = locked_joint_positions or {}
+        if not set(locked).issubset({j.name for j in raw_joints}):
+            raise ValueError(f"Passed joints not existing in the model: {sorted(set(locked) - movable)}")
+        for j in raw_joints:
+            if j.jtype != FIXED and j.name not in set(considered_joints):
+                j.pose = j.pose @ _joint_motion(j.jtype, j.axis, float(locked.get(j.name, 0.0)))
+                j.jtype = FIXED
 
     # ---- fixed base: fold the world->base fixed joint into the base pose ---------
     fixed_base = False

@@ -175,3 +175,36 @@ def test_tile_interleaved_layout_round_trip(tile, N):
     for row, env in ((0, 0), (3, N - 1), (rows - 1, N // 2)):
         assert flat[((env // tile) * rows + row) * tile + env % tile] == blk[row, env]
     np.testing.assert_array_equal(st.untile_block(flat, rows, N, tile), blk)
+
+
+def test_model_reduction_locks_joints_and_lumps_links(models):
+    """``js.model.reduce`` / ``considered_joints`` (reference api/model.py:807-878): the reduced model is
+    the full one with the removed joints held at their locked positions -- same total mass, and its
+    mass matrix is the full one without the locked rows / columns."""
+    import jaxsim_amd.api as js
+
+    full = models("anymal")
+    names = list(full.joint_names())
+    locked = {"LF_KFE": -0.7, "RH_HAA": 0.3, "RH_HFE": 0.0}
+    keep = [n for n in names if n not in locked]
+    red = js.model.reduce(full, considered_joints=keep, locked_joint_positions={k: v for k, v in locked.items() if v != 0.0})
+    assert red.number_of_joints() == len(keep) and set(red.joint_names()) == set(keep)
+    assert red.number_of_links() == full.number_of_links() - len(locked)
+    assert red.total_mass() == pytest.approx(full.total_mass(), rel=1e-12)
+    assert red.time_step == full.time_step and red.gravity == full.gravity
+    rng = np.random.default_rng(0)
+    s_red = rng.uniform(-0.8, 0.8, size=(3, len(keep)))
+    s_full = np.zeros((3, len(names)))
+    for k, n in enumerate(names):
+        s_full[:, k] = locked[n] if n in locked else s_red[:, list(red.joint_names()).index(n)]
+    M_full = oracle.crba(full, joint_positions=s_full)
+    M_red = oracle.crba(red, joint_positions=s_red)
+    idx = [0, 1, 2, 3, 4, 5] + [6 + names.index(n) for n in red.joint_names()]
+    np.testing.assert_allclose(M_red, M_full[:, idx][:, :, idx], rtol=1e-10, atol=1e-10)
+    # the collidable points follow their lumped links
+    assert red.kin_dyn_parameters.number_of_collidable_points() == full.kin_dyn_parameters.number_of_collidable_points()
+    # all joints considered: identical tables
+    same = js.model.reduce(full, considered_joints=names)
+    np.testing.assert_array_equal(same.kin_dyn_parameters.parent_array, full.kin_dyn_parameters.parent_array)
+    with pytest.raises(ValueError, match="not existing"):
+        js.model.reduce(full, considered_joints=names + ["nope"])
