@@ -217,6 +217,37 @@ def gravity_compensation_torques(model: JaxSimModel, data: JaxSimModelData, out:
     return out
 
 
+def free_floating_mass_matrix(model: JaxSimModel, data: JaxSimModelData):
+    """``M(q)`` in the active velocity representation (``src/jaxsim/api/model.py:1553-1590``).
+
+    The reference runs CRBA; here the columns come from ONE inverse-dynamics launch over a virtual
+    batch of ``N * (7 + n)`` environments at zero velocity: ``M e_i = ID(q, 0, e_i) - ID(q, 0, 0)``
+    (the RNEA kernel is the only device code involved)."""
+    N, n = data.batch_size, model.dofs()
+    nv = 6 + n
+    blk = data.state_block().astype(np.float64)  # [rows][N]
+    from ..state import StateLayout
+
+    L = StateLayout.of(model)
+    blk[L.row_vlin : L.row_vlin + 3] = 0
+    blk[L.row_vang : L.row_vang + 3] = 0
+    blk[L.row_sd : L.row_sd + n] = 0
+    rep_blk = np.tile(blk, (1, nv + 1))  # environment e of replica k sits at column k * N + e
+    z = JaxSimModelData.from_state_block(model, rep_blk.astype(data.dtype), data.velocity_representation)
+    acc = np.zeros((nv + 1, N, nv))
+    for k in range(nv):
+        acc[k, :, k] = 1.0
+    acc = acc.reshape((nv + 1) * N, nv)
+    fB, tau = inverse_dynamics(model, z, joint_accelerations=acc[:, 6:], base_acceleration=acc[:, :6])
+    cols = np.concatenate([np.asarray(fB, dtype=np.float64), np.asarray(tau, dtype=np.float64).reshape((nv + 1) * N, n)], axis=-1)
+    cols = cols.reshape(nv + 1, N, nv)
+    M = np.transpose(cols[:nv] - cols[nv:], (1, 2, 0))  # [N, row, column]
+    M = 0.5 * (M + np.transpose(M, (0, 2, 1)))
+    if not model.floating_base():
+        pass  # the reference returns the full (6+n) matrix for fixed-base models too
+    return data._out(M.astype(data.dtype))
+
+
 def free_floating_bias_forces(model: JaxSimModel, data: JaxSimModelData):
     """``h(q, nu)`` (``src/jaxsim/api/model.py:1934-1978``); fixed-base models drop the base
     velocity like the reference does."""

@@ -466,3 +466,18 @@ def test_gpu_golden_rigid(models, name):
     data = js.data.JaxSimModelData.from_state_block(model, g["state"], ja.VelRepr.Mixed)
     out = js.model.step(model, data, link_forces=g["link_forces"], joint_force_references=g["tau"])
     assert helpers.rel_err(out.state_block(), g["step"]) < 1e-7
+
+
+@pytest.mark.parametrize("name", ["chain9f", "anymal", "icub"])
+def test_free_floating_mass_matrix(models, name):
+    """``js.model.free_floating_mass_matrix`` (reference: CRBA, api/model.py:1553-1590; README usage) --
+    here RNEA columns over a virtual batch -- against the oracle's CRBA in Body and Mixed representation."""
+    from oracle import refrigid
+
+    model = models(name)
+    for rep in (VelRepr.Body, VelRepr.Mixed):
+        d = models.random_data(name, 5, seed=41, rep=rep)
+        M = js.model.free_floating_mass_matrix(model, to_gpu(model, d))
+        ref = oracle.crba(model, joint_positions=d.joint_positions) if rep == VelRepr.Body else refrigid.free_floating_mass_matrix_mixed(model, d)
+        assert M.shape == ref.shape
+        assert helpers.rel_err(M, ref) < 1e-9
