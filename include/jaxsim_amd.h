@@ -143,6 +143,12 @@ int jxs_model_layout(const jxs_model* model, jxs_layout* out);
 int jxs_step(jxs_model* model, const void* state_in, void* state_out, const void* tau,
              const void* link_forces, int force_repr, int N, void* stream);
 
+/* `n_launches` back-to-back in-place jxs_step launches enqueued from one call (no fusion: one kernel
+ * launch per step, exactly what a host loop over jxs_step enqueues, without the per-call cost of the
+ * host language).                                                                            */
+int jxs_step_repeat(jxs_model* model, void* state, const void* tau, const void* link_forces,
+                    int force_repr, int N, int n_launches, void* stream);
+
 /* `n_steps` consecutive steps with constant inputs in ONE launch sequence (what a
  * `jax.lax.fori_loop` over `step` does in the reference's notebooks); in place.           */
 int jxs_rollout(jxs_model* model, void* state, const void* tau, const void* link_forces,

@@ -174,7 +174,7 @@ int create_typed(const jxs_model_desc* d, std::unique_ptr<ModelT<T>>& slot) {
 template <typename T>
 int run_typed(jxs_model* model, int mode, const void* state_in, void* state_out, const void* tau,
               const void* link_f, int force_repr, const void* in_a, void* out_a, void* out_H, void* out_V, int N,
-              int repeat, void* stream, void* out_tau) {
+              int repeat, void* stream, void* out_tau, bool fuse) {
   ModelT<T>* mt = typed<T>(model);
   hipStream_t s = static_cast<hipStream_t>(stream);
   jxs::KArgs<T> a = mt->args(N);
@@ -201,7 +201,7 @@ int run_typed(jxs_model* model, int mode, const void* state_in, void* state_out,
     mode = jxs::MODE_STEP_RK4;  // four dynamics evaluations per launch; a rollout is one launch per step
   }
   if (mode == jxs::MODE_STEP && mt->pk.P.rigid) mode = jxs::MODE_STEP_RIGID;  // QP contacts + impact, one launch per step
-  if (mode == jxs::MODE_STEP && repeat > 1 && mt->pk.P.n_chunks <= 1) {
+  if (fuse && mode == jxs::MODE_STEP && repeat > 1 && mt->pk.P.n_chunks <= 1) {
     // fused rollout: one launch, the state stays in registers between the steps
     a.n_steps = repeat;
     repeat = 1;
@@ -217,16 +217,16 @@ int run_typed(jxs_model* model, int mode, const void* state_in, void* state_out,
 
 int run_any(jxs_model* model, int mode, const void* state_in, void* state_out, const void* tau, const void* link_f,
             int force_repr, const void* in_a, void* out_a, void* out_H, void* out_V, int N, int repeat,
-            void* stream, void* out_tau = nullptr) {
+            void* stream, void* out_tau = nullptr, bool fuse = true) {
   if (model == nullptr) return fail(JXS_EINVAL, "null model");
   if (state_in == nullptr) return fail(JXS_EINVAL, "null state");
   if (N <= 0) return fail(JXS_EINVAL, "N must be positive");
   if (force_repr < 0 || force_repr > 2) return fail(JXS_EINVAL, "invalid force representation");
   if (model->dtype == JXS_F64)
     return run_typed<double>(model, mode, state_in, state_out, tau, link_f, force_repr, in_a, out_a, out_H, out_V, N,
-                             repeat, stream, out_tau);
+                             repeat, stream, out_tau, fuse);
   return run_typed<float>(model, mode, state_in, state_out, tau, link_f, force_repr, in_a, out_a, out_H, out_V, N,
-                          repeat, stream, out_tau);
+                          repeat, stream, out_tau, fuse);
 }
 
 // ---- RCCL, resolved lazily so that the library loads (and the CPU symbol test passes)
@@ -397,6 +397,13 @@ int jxs_rollout(jxs_model* model, void* state, const void* tau, const void* link
   if (n_steps < 0) return fail(JXS_EINVAL, "n_steps must be >= 0");
   return run_any(model, jxs::MODE_STEP, state, state, tau, link_forces, force_repr, nullptr, nullptr, nullptr, nullptr,
                  N, n_steps, stream);
+}
+int jxs_step_repeat(jxs_model* model, void* state, const void* tau, const void* link_forces, int force_repr, int N,
+                    int n_launches, void* stream) {
+  if (n_launches < 0) return fail(JXS_EINVAL, "n_launches must be >= 0");
+  if (n_launches == 0) return JXS_OK;
+  return run_any(model, jxs::MODE_STEP, state, state, tau, link_forces, force_repr, nullptr, nullptr, nullptr, nullptr,
+                 N, n_launches, stream, nullptr, /*fuse=*/false);
 }
 int jxs_forward_dynamics_aba(jxs_model* model, const void* state, const void* joint_forces, const void* link_forces,
                              int force_repr, void* out_acc, int N, void* stream) {
