@@ -226,10 +226,11 @@ def anymal12_urdf(points_per_foot_box: bool = True, joint_limit: float = 1.0) ->
     return "".join(out)
 
 
-def chain_urdf(n_links: int = 5, fixed_base: bool = True, seed: int = 0) -> str:
+def chain_urdf(n_links: int = 5, fixed_base: bool = True, seed: int = 0, max_back: int = 3) -> str:
     """Random serial/branching chain with mixed revolute/prismatic joints, skewed axes and
     rotated joint frames: a stress model for parity tests (cf. the reference's scalable
-    "garpez" fixture, ``tests/conftest.py:479-707``)."""
+    "garpez" fixture, ``tests/conftest.py:479-707``).  The parent of link i is one of the ``max_back``
+    previous links (1: a serial chain of depth n_links - 1)."""
     rng = np.random.default_rng(seed)
     out = ['<robot name="chain">']
     if fixed_base:
@@ -244,7 +245,7 @@ def chain_urdf(n_links: int = 5, fixed_base: bool = True, seed: int = 0) -> str:
     if fixed_base:
         out.append(_joint("world_to_base", "fixed", "world", "link00", (0.1, -0.2, 0.5), (0, 0, 0)))
     for i in range(1, n_links):
-        parent = int(rng.integers(max(0, i - 3), i))
+        parent = int(rng.integers(max(0, i - max_back), i))
         jt = "prismatic" if rng.uniform() < 0.25 else "revolute"
         axis = rng.normal(size=3)
         axis = tuple(float(v) for v in axis / np.linalg.norm(axis))

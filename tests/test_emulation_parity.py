@@ -462,3 +462,35 @@ def test_rigid_unsupported_configurations_are_rejected(models):
         eb.layout(helpers.rigid_model(fixed, [0, 1, 2, 3]))
     with pytest.raises(RuntimeError, match="SemiImplicitEuler"):
         eb.layout(helpers.with_params(helpers.rigid_model(models("box"), [0, 1, 2, 3]), integrator=ja.IntegratorType.RungeKutta4))
+
+
+@pytest.mark.parametrize("fixed_base,max_back", [(True, 1), (False, 1), (False, 3)])
+def test_maximum_size_models(models, fixed_base, max_back):
+    """The largest supported model: 64 links, one per lane of a full wave; a serial chain makes the tree
+    63 levels deep (six pointer-jumping rounds, the link-per-lane ABA sweeps)."""
+    import jaxsim_amd as ja
+    from jaxsim_amd import robots
+
+    model = ja.JaxSimModel.build_from_model_description(robots.chain_urdf(64, fixed_base=fixed_base, seed=3, max_back=max_back))
+    assert eb.layout(model).group == 64
+    assert int(model.kin_dyn_parameters.tree_depths().max()) == (63 if max_back == 1 else 31)
+    d = oracle.random_model_data(model, batch_size=3, seed=1)
+    tau, f = helpers.random_inputs(model, 3, 2, np.float64)
+    blk, kw = helpers.odata_to_block(model, d), dict(tau=tau.T, link_forces=f.reshape(3, -1).T, force_repr=2)
+    ref = oracle.step(model, d, link_forces=f, joint_force_references=tau)
+    assert helpers.rel_err(eb.run(model, eb.MODE_STEP, blk, **kw), helpers.odata_to_block(model, ref)) < 1e-9
+    di = dataclasses_replace_inertial(d)  # the kernel entry points speak the inertial-fixed representation
+    vd, sdd = oracle.forward_dynamics_aba(model, di, joint_forces=tau, link_forces=f)
+    kwi = dict(tau=tau.T, link_forces=f.reshape(3, -1).T, force_repr=0)
+    assert helpers.rel_err(eb.run(model, eb.MODE_FD, blk, **kwi).T, np.concatenate([vd, sdd], -1)) < 1e-9
+    acc = np.random.default_rng(4).uniform(-1, 1, size=(3, 6 + model.dofs()))
+    fB, tq = oracle.inverse_dynamics(model, dataclasses_replace_inertial(d), joint_accelerations=acc[:, 6:], base_acceleration=acc[:, :6])
+    idn = eb.run(model, eb.MODE_ID, blk, in_acc=acc.T).T
+    ref_id = np.concatenate([fB if model.floating_base() else np.zeros_like(fB), tq], -1)
+    assert float(np.abs(idn - ref_id).max()) / max(1.0, float(np.abs(ref_id).max())) < 1e-9
+
+
+def dataclasses_replace_inertial(d):
+    import dataclasses
+
+    return dataclasses.replace(d, velocity_representation=VelRepr.Inertial)

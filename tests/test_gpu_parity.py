@@ -507,3 +507,30 @@ def test_reference_readme_flow(models):
     # free fall so far: z = 1 - g t^2 / 2 up to the semi-implicit Euler offset
     t = len(T) * model.time_step
     assert data.base_position[2] == pytest.approx(1.0 - 0.5 * 9.81 * t * (t + model.time_step), abs=1e-9)
+
+
+@pytest.mark.parametrize("fixed_base,max_back", [(True, 1), (False, 1)])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_maximum_size_models_gpu(fixed_base, max_back, dtype):
+    """64 links (one per lane of a full wave), serial chain: 63 tree levels."""
+    from jaxsim_amd import robots
+
+    model = ja.JaxSimModel.build_from_model_description(robots.chain_urdf(64, fixed_base=fixed_base, seed=3, max_back=max_back))
+    d = oracle.random_model_data(model, batch_size=5, seed=1, dtype=dtype)
+    tau, f = helpers.random_inputs(model, 5, 2, dtype)
+    ref = oracle.step(model, helpers.upcast(d), link_forces=f.astype(np.float64), joint_force_references=tau.astype(np.float64))
+    out = js.model.step(model, to_gpu(model, d), link_forces=f, joint_force_references=tau)
+    assert helpers.rel_err(out.state_block(), helpers.odata_to_block(model, ref)) < (1e-9 if dtype == np.float64 else helpers.FP32_TOL)
+
+
+@pytest.mark.parametrize("name", ["box", "anymal", "icub"])
+@pytest.mark.parametrize("N", [1, 2, 3, 17, 63, 65])
+def test_ragged_batch_sizes(models, name, N):
+    """Batch sizes around the tile boundaries (tile = 16 / 4 / 2 environments per wave): the padded tail of
+    the last tile is neither read as data nor written back."""
+    model = models(name)
+    d = models.random_data(name, N, seed=50 + N)
+    ref = oracle.step(model, d)
+    out = js.model.step(model, to_gpu(model, d)).state_block()
+    assert out.shape[1] == N
+    assert helpers.rel_err(out, helpers.odata_to_block(model, ref)) < helpers.FP64_TOL
