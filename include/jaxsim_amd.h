@@ -169,6 +169,12 @@ int jxs_inverse_dynamics(jxs_model* model, const void* state, const void* in_acc
                          const void* link_forces, int force_repr, void* out_forces, int N,
                          void* stream);
 
+/* Value checks of a state block, the counterpart of the host callbacks the reference enables with
+ * JAXSIM_ENABLE_EXCEPTIONS (src/jaxsim/exceptions.py:6-60, rbda/utils.py:135-146).  Synchronous.
+ * counts3[0] = environments whose base quaternion contains NaN, [1] = environments whose quaternion is
+ * not normalised (jnp.allclose(q.q, 1)), [2] = environments with any non-finite state entry.      */
+int jxs_validate_state(jxs_model* model, const void* state, int N, int* counts3, void* stream);
+
 /* Gravity compensation torques: the joint part of free_floating_gravity_forces
  * (src/jaxsim/api/model.py:1897-1931: RNEA at zero velocity, zero acceleration, no external forces),
  * written as [n][N] -- the layout jxs_step reads `tau` in, so a controller loop

@@ -35,6 +35,29 @@ def _as_device(x, rows: int, N: int, dtype, trailing_shape, tile: int) -> Device
     return DeviceArray.from_host(np.ascontiguousarray(a.reshape(N, rows).T), tile=tile, dtype=dtype)
 
 
+def _exceptions_enabled() -> bool:
+    """``JAXSIM_ENABLE_EXCEPTIONS`` (``src/jaxsim/exceptions.py:26-29``), same variable, same default."""
+    import os
+
+    return os.environ.get("JAXSIM_ENABLE_EXCEPTIONS", "0").lower() in ("1", "true", "on", "yes")
+
+
+def _check_quaternion(model, data: JaxSimModelData, *, normalized: bool) -> None:
+    """The value checks of ``rbda/utils.py:135-146`` on the device state (only when exceptions are on)."""
+    if not _exceptions_enabled():
+        return
+    dm = runtime.device_model(model, data.dtype)
+    counts = (C.c_int * 3)()
+    _lib.check(
+        _lib.load().jxs_validate_state(dm.handle, C.c_void_p(data._state.ptr), data.batch_size, counts, runtime._sp()),
+        "jxs_validate_state",
+    )
+    if counts[0]:
+        raise ValueError("A RBDA received a quaternion that contains NaN values.")
+    if normalized and counts[1]:
+        raise ValueError("A RBDA received a quaternion that is not normalized.")
+
+
 def _ptr(d: DeviceArray | None):
     return None if d is None else C.c_void_p(d.ptr)
 
@@ -79,6 +102,7 @@ def step(
     buffer instead and returns a data object sharing it.
     """
     dm = runtime.device_model(model, data.dtype)
+    _check_quaternion(model, data, normalized=False)  # ABA receives data.base_orientation (normalised)
     N, nL, n = data.batch_size, model.number_of_links(), model.dofs()
     f = _as_device(link_forces, nL * 6, N, data.dtype, (nL, 6), data._state.tile)
     tau = _as_device(joint_force_references, n, N, data.dtype, (n,), data._state.tile)
@@ -165,6 +189,7 @@ def inverse_dynamics(model: JaxSimModel, data: JaxSimModelData, *, joint_acceler
     """``inverse_dynamics`` (``src/jaxsim/api/model.py:1746-1894``): base wrench in the active
     representation and joint torques."""
     dm = runtime.device_model(model, data.dtype)
+    _check_quaternion(model, data, normalized=True)  # RNEA receives the raw quaternion (api/model.py:1856)
     N, nL, n = data.batch_size, model.number_of_links(), model.dofs()
     sdd = np.zeros((N, n)) if joint_accelerations is None else np.broadcast_to(
         np.asarray(joint_accelerations, dtype=np.float64).reshape(-1, n), (N, n))  # fmt: skip

@@ -264,6 +264,31 @@ int rccl_fail(ncclResult_t r, const char* what) {
 
 }  // namespace
 
+// ---- value checks standing in for JAXSIM_ENABLE_EXCEPTIONS (src/jaxsim/rbda/utils.py:135-146) ----
+template <typename T>
+__global__ void jxs_validate_kernel(const T* state, int n_rows, int row_quat, int tile, int N, int* counts) {
+  const int env = blockIdx.x * blockDim.x + threadIdx.x;
+  if (env >= N) return;
+  const size_t base = (size_t)(env / tile) * n_rows * tile + env % tile;
+  T q2 = 0;
+  bool nan_q = false;
+  for (int k = 0; k < 4; ++k) {
+    const T v = state[base + (size_t)(row_quat + k) * tile];
+    nan_q = nan_q || (v != v);
+    q2 += v * v;
+  }
+  bool bad = false;
+  for (int r = 0; r < n_rows; ++r) {
+    const T v = state[base + (size_t)r * tile];
+    bad = bad || !(v - v == T(0));  // NaN or infinity
+  }
+  const T d = q2 > T(1) ? q2 - T(1) : T(1) - q2;
+  if (nan_q) atomicAdd(&counts[0], 1);
+  if (!nan_q && !(d <= T(1e-8) + T(1e-5))) atomicAdd(&counts[1], 1);  // jnp.allclose(q.q, 1.0)
+  if (bad) atomicAdd(&counts[2], 1);
+}
+
+
 extern "C" {
 
 // Not part of the public ABI: phase-stamp buffer of the -DJXS_PHASE_TIMING developer build.
@@ -383,6 +408,30 @@ int jxs_model_layout(const jxs_model* model, jxs_layout* out) {
                       P.row_vlin, P.row_vang, P.row_sd, P.row_m, pk.G, 64 / pk.G, model->dtype, P.row_mode};
   };
   if (model->dtype == JXS_F64) fill(model->f64->pk); else fill(model->f32->pk);
+  return JXS_OK;
+}
+
+int jxs_validate_state(jxs_model* model, const void* state, int N, int* counts3, void* stream) {
+  if (model == nullptr || state == nullptr || counts3 == nullptr) return fail(JXS_EINVAL, "null argument");
+  if (N <= 0) return fail(JXS_EINVAL, "N must be positive");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int* d = nullptr;
+  JXS_HIP(hipMalloc(&d, 3 * sizeof(int)));
+  JXS_HIP(hipMemsetAsync(d, 0, 3 * sizeof(int), s));
+  jxs_layout lay;
+  jxs_model_layout(model, &lay);
+  const int threads = 256, blocks = (N + threads - 1) / threads;
+  if (model->dtype == JXS_F64)
+    hipLaunchKernelGGL(jxs_validate_kernel<double>, dim3(blocks), dim3(threads), 0, s, static_cast<const double*>(state),
+                       lay.n_rows, lay.row_quat, lay.tile, N, d);
+  else
+    hipLaunchKernelGGL(jxs_validate_kernel<float>, dim3(blocks), dim3(threads), 0, s, static_cast<const float*>(state),
+                       lay.n_rows, lay.row_quat, lay.tile, N, d);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(counts3, d, 3 * sizeof(int), hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  hipFree(d);
+  if (e != hipSuccess) return hip_fail(e, "jxs_validate_state");
   return JXS_OK;
 }
 

@@ -534,3 +534,33 @@ def test_ragged_batch_sizes(models, name, N):
     out = js.model.step(model, to_gpu(model, d)).state_block()
     assert out.shape[1] == N
     assert helpers.rel_err(out, helpers.odata_to_block(model, ref)) < helpers.FP64_TOL
+
+
+def test_value_checks_like_jaxsim_enable_exceptions(models, monkeypatch):
+    """``JAXSIM_ENABLE_EXCEPTIONS`` (reference exceptions.py:26-29, rbda/utils.py:135-146): NaN / non-unit
+    base quaternions raise ValueError from the RBDA entry points; off by default."""
+    import ctypes as C
+
+    from jaxsim_amd import _lib
+
+    model = models("anymal")
+    d = models.random_data("anymal", 9, seed=60)
+    blk = helpers.odata_to_block(model, d)
+    blk[3:7, 2] *= 1.5  # not normalised
+    blk[3, 5] = np.nan
+    blk[20, 7] = np.inf
+    bad = js.data.JaxSimModelData.from_state_block(model, blk, ja.VelRepr.Mixed)
+    counts = (C.c_int * 3)()
+    dm = runtime.device_model(model, np.float64)
+    _lib.check(_lib.load().jxs_validate_state(dm.handle, C.c_void_p(bad._state.ptr), 9, counts, None), "validate")
+    assert list(counts) == [1, 1, 2]
+    js.model.inverse_dynamics(model, bad)  # exceptions off: no check, garbage in -> garbage out
+    monkeypatch.setenv("JAXSIM_ENABLE_EXCEPTIONS", "1")
+    with pytest.raises(ValueError, match="contains NaN"):
+        js.model.step(model, bad)
+    blk[3, 5] = 0.5
+    unnorm = js.data.JaxSimModelData.from_state_block(model, blk, ja.VelRepr.Mixed)
+    js.model.forward_dynamics_aba(model, unnorm)  # ABA normalises its quaternion: accepted
+    with pytest.raises(ValueError, match="not normalized"):
+        js.model.inverse_dynamics(model, unnorm)
+    js.model.inverse_dynamics(model, to_gpu(model, d))  # a valid state passes
