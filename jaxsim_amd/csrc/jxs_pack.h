@@ -108,8 +108,8 @@ std::string pack_model(const jxs_model_desc& d, Packed<T>& out) {
   }
   P.reg_delassus = (T)d.regularization_delassus;
   P.qp_tol = (T)d.solver_tol;
-  // Pivots of the (semidefinite) impact system below the rounding floor of J M^-1 J^T count as zero:
-  // contact directions with sigma(J) / sigma_max below ~1e-5 (fp64) are treated as dependent.  The
+  // Relative Tikhonov shift of the (semidefinite) impact system, refined away by iterative refinement:
+  // contact directions with sigma(J M^-1 J') / sigma_max below it are enforced only partially -- the
   // reference's SVD-based lstsq resolves them down to ~1e-14; both are noise-dominated there
   // (DESIGN.md section 4d).
   P.impact_rel_tol = sizeof(T) == 8 ? (T)1e-10 : (T)1e-4;

@@ -88,6 +88,7 @@ JXS_HD constexpr int lds_words_per_env(int G) { return G * kRowRec + 48; }  // r
 JXS_HD constexpr int rigid_lds_words_per_env(int n_cp) { return 3 * n_cp * (3 * n_cp + 1) + 3 * n_cp + 8; }
 constexpr int kQpMaxIter = 30;    // interior-point iterations (oracle/refrigid.py QP_MAX_ITER)
 constexpr int kRigidMaxPoints = 16;
+constexpr int kImpactCgIters = 5;  // preconditioned CG iterations of the impact solve (jxs_rigid.inc)
 
 enum Mode : int {
   MODE_STEP = 0,  // js.model.step                         api/model.py:2601-2681
@@ -137,7 +138,7 @@ struct KParams {
   int n_cp;                      // enabled collidable points (= used slots of chunk 0 in the rigid modes)
   T reg_delassus;                // regularization_delassus (1e-6)
   T qp_tol;                      // solver_options["solver_tol"] (1e-3)
-  T impact_rel_tol;              // relative pivot threshold of the semidefinite impact solve
+  T impact_rel_tol;              // relative Tikhonov shift of the impact preconditioner
 };
 
 // Device/host pointers handed to the core for one launch.
