@@ -193,8 +193,7 @@ def main():
             comm = distributed.communicator_from_env()
         except Exception as e:  # keep the bench line: fall back to a host-side file collective
             comm_error = repr(e)
-            key = "_".join(str(os.environ.get(k, "")) for k in ("MASTER_PORT", "TORCHELASTIC_RUN_ID"))
-            comm = distributed.FileCollective(rank, world, key)
+            comm = distributed.FileCollective(rank, world, distributed.job_key())
     dtype = np.dtype(args.dtype)
     model = build_model(args.model)
     n_local = args.envs_per_gpu

@@ -99,7 +99,9 @@ def file_rendezvous(rank: int, world_size: int, key: str, timeout_s: float = 120
     import time
 
     path = os.path.join(tempfile.gettempdir(), f"jaxsim_amd_rdzv_{key}.bin")
-    fresh_after = time.time() - 30.0  # a file left behind by a crashed earlier job is ignored
+    # A file left behind by a crashed earlier job with the same key is ignored.  The window is wide:
+    # ranks of one job can start minutes apart (the first import on a fresh box pages the image in).
+    fresh_after = time.time() - 900.0
     if rank == 0:
         uid = Communicator.create_unique_id()
         tmp = f"{path}.{os.getpid()}.tmp"
@@ -121,13 +123,24 @@ def file_rendezvous(rank: int, world_size: int, key: str, timeout_s: float = 120
     raise _lib.JaxsimAmdError(f"rendezvous timed out waiting for {path}")
 
 
+def job_key() -> str:
+    """Identifier shared by the ranks of ONE launch and by no other: the launcher's rendezvous port and
+    run id plus the pid of the launcher process itself (every rank is its child)."""
+    import os
+
+    parts = [str(os.environ.get(k, "")) for k in ("MASTER_PORT", "TORCHELASTIC_RUN_ID")]
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        parts.append(str(os.getppid()))
+    return "_".join(parts)
+
+
 def communicator_from_env(tag: str = "") -> Communicator:
     """Communicator for a job started by ``torch.distributed.run`` (or any launcher exporting
     RANK / WORLD_SIZE / MASTER_PORT): file rendezvous + ``ncclCommInitRank``.  No torch import."""
     import os
 
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
-    key = "_".join(str(os.environ.get(k, "")) for k in ("MASTER_PORT", "TORCHELASTIC_RUN_ID")) + tag
+    key = job_key() + tag
     comm = Communicator(file_rendezvous(rank, world, key), rank, world)
     comm.barrier()
     if rank == 0:  # everyone has read the id once the first collective completed

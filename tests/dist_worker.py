@@ -33,6 +33,14 @@ def main():
     for _ in range(3):
         local = eb.run(model, eb.MODE_STEP, local)
     gathered = distributed.all_gather_state_blocks_host(local)
+    # the torch-free bootstrap of bench.py: every rank of this launch derives the same job key, and the
+    # host-side file collective (the fallback when RCCL is unavailable) gathers one scalar per rank
+    keys = [None] * world
+    dist.all_gather_object(keys, distributed.job_key())
+    assert len(set(keys)) == 1 and keys[0].endswith(str(os.getppid())), keys
+    fc = distributed.FileCollective(rank, world, "test_" + keys[0])
+    got = fc.all_gather_scalars(10.0 + rank)
+    assert got.tolist() == [10.0 + r for r in range(world)], got
     if rank == 0:
         ref = full
         for _ in range(3):
