@@ -189,6 +189,9 @@ def main():
     # runtimes in one process do not both see the GPU -- measured on the MI355X box.)
     comm, comm_error = None, None
     if multi:
+        # one node by contract: RCCL's out-of-band bootstrap can always use the loopback interface (a
+        # container without any other interface would otherwise fail to pick one)
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
         try:
             comm = distributed.communicator_from_env()
         except Exception as e:  # keep the bench line: fall back to a host-side file collective
