@@ -37,8 +37,22 @@ int hip_fail(hipError_t e, const char* what) {
     if (e_ != hipSuccess) return hip_fail(e_, #call);  \
   } while (0)
 
+// The first 16 dwords of the kernel arguments are PRELOADED into SGPRs by the command processor
+// (-mllvm -amdgpu-kernarg-preload-count=16; gfx940+): the pointers and row counts every first-batch
+// load address needs arrive with the wave instead of after a scalar-load round trip.  The structs that
+// follow carry the same values (and everything else); the preloaded copies simply replace them.
 template <typename T, int G, int MODE>
-__global__ __launch_bounds__(64) void jxs_kernel(const jxs::KParams<T> P, const jxs::KArgs<T> A) {
+__global__ __launch_bounds__(64) void jxs_kernel(const T* pre_state_in, const T* pre_ltf, const int* pre_lti,
+                                                 const T* pre_ptf, const int* pre_pti, const int* pre_head,
+                                                 int pre_n_rows, int pre_n, int pre_n_slots, int pre_N,
+                                                 const jxs::KParams<T> P_, const jxs::KArgs<T> A_) {
+  jxs::KParams<T> P = P_;
+  jxs::KArgs<T> A = A_;
+  A.state_in = pre_state_in, A.ltf = pre_ltf, A.lti = pre_lti, A.ptf = pre_ptf, A.pti = pre_pti, A.head = pre_head;
+  A.N = pre_N;
+  P.n_rows = pre_n_rows, P.n = pre_n, P.n_slots = pre_n_slots;
+  P.row_pos = 0, P.row_quat = 3, P.row_s = 7, P.row_vlin = 7 + pre_n, P.row_vang = 10 + pre_n, P.row_sd = 13 + pre_n;
+  P.row_m = 13 + 2 * pre_n;  // the state-block rows of SURVEY section 8(a) row D, derived instead of loaded
   extern __shared__ __align__(16) unsigned char jxs_smem[];
   const jxs::DeviceLanes<T, G> ln(A.N, reinterpret_cast<T*>(jxs_smem),
                                   MODE == jxs::MODE_STEP_RIGID ? jxs::rigid_lds_words_per_env(P.n_cp)
@@ -72,7 +86,8 @@ hipError_t launch_one(const jxs::KParams<T>& P, const jxs::KArgs<T>& A, hipStrea
       if (e != hipSuccess) return e;
     }
   }
-  hipLaunchKernelGGL((jxs_kernel<T, G, MODE>), dim3(blocks), dim3(64), lds_bytes, s, P, A);
+  hipLaunchKernelGGL((jxs_kernel<T, G, MODE>), dim3(blocks), dim3(64), lds_bytes, s, A.state_in, A.ltf, A.lti, A.ptf, A.pti,
+                     A.head, P.n_rows, P.n, P.n_slots, A.N, P, A);
   return hipGetLastError();
 }
 
