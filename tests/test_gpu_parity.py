@@ -564,3 +564,26 @@ def test_value_checks_like_jaxsim_enable_exceptions(models, monkeypatch):
     with pytest.raises(ValueError, match="not normalized"):
         js.model.inverse_dynamics(model, unnorm)
     js.model.inverse_dynamics(model, to_gpu(model, d))  # a valid state passes
+
+
+def test_step_repeat_graph_equals_single_launches(models):
+    """``jxs_step_repeat`` (hipGraph replay of n single-step launches on a created stream) gives the
+    bits of n ``jxs_step`` calls, also when replayed and when the arguments change."""
+    import ctypes as C
+
+    from jaxsim_amd import _lib
+
+    model = models("icub")
+    d = models.random_data("icub", 50, seed=70, dtype=np.float32)
+    ref = to_gpu(model, d)
+    for _ in range(12):
+        ref = js.model.step(model, ref)
+    lib, dm = _lib.load(), runtime.device_model(model, np.float32)
+    stream = runtime.Stream()
+    for trial in range(2):  # second trial: a new state buffer -> the graph is re-captured
+        g = to_gpu(model, d)
+        runtime.synchronize()
+        for _ in range(3):  # 3 replays of a 4-launch graph
+            _lib.check(lib.jxs_step_repeat(dm.handle, C.c_void_p(g._state.ptr), None, None, 2, 50, 4, stream.handle), "repeat")
+        stream.synchronize()
+        np.testing.assert_array_equal(g.state_block(), ref.state_block())
