@@ -29,7 +29,7 @@ for d in sorted(run.glob("pmc_*")):
     agg = collections.defaultdict(list)
     waves = None
     for r in csv.DictReader(open(f[0])):
-        if "jxs_kernel" in r["Kernel_Name"]:
+        if "jxs_kernel<float, 32, 0>" in r["Kernel_Name"]:  # the step kernel only (not the fused rollout / kinematics)
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
             waves = int(r["Grid_Size"]) // 64
     for k, v in agg.items():
