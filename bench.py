@@ -57,6 +57,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="developer: run the multi-rank code path even with WORLD_SIZE=1")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=10.0)
+    ap.add_argument("--saturated-envs", type=int, default=65536, help="secondary figure: batch that saturates one GPU (0 = skip)")
     return ap.parse_args()
 
 
@@ -251,6 +252,29 @@ def main():
     _lib.check(rc, "jxs_rollout")
     rollout_ms_per_step = ev2.elapsed_ms(ev3) / max(args.steps, 1)
 
+    # secondary figure: the same kernel with the chip saturated (64 Ki environments on this GPU) -- what
+    # the step costs once enough waves hide each other's latencies.  Not the headline configuration.
+    saturated = None
+    if world == 1 and args.saturated_envs > 0:
+        try:
+            n_sat = args.saturated_envs
+            reps = -(-n_sat // n_local)
+            big = js.data.JaxSimModelData.from_state_block(
+                model, np.tile(initial_block, (1, reps))[:, :n_sat].astype(dtype), data.velocity_representation
+            )
+            bp = C.c_void_p(big._state.ptr)
+            _lib.check(lib.jxs_step_repeat(dm.handle, bp, None, None, 2, n_sat, 20, stream.handle), "jxs_step_repeat")
+            ev4, ev5 = runtime.Event(), runtime.Event()
+            ev4.record(stream)
+            _lib.check(lib.jxs_step_repeat(dm.handle, bp, None, None, 2, n_sat, 200, stream.handle), "jxs_step_repeat")
+            ev5.record(stream)
+            runtime.synchronize(stream)
+            us = ev4.elapsed_ms(ev5) / 200 * 1e3
+            saturated = {"envs": n_sat, "us_per_step": us, "env_steps_per_s": n_sat / (us * 1e-6)}
+            del big
+        except Exception as e:  # secondary: never lose the headline for it
+            saturated = {"error": repr(e)}
+
     if comm is not None:
         elapsed = float(comm.all_gather_scalars(elapsed).max())  # max over ranks
 
@@ -324,6 +348,12 @@ def main():
             "fused_rollout": {"us_per_step": rollout_ms_per_step * 1e3, "env_steps_per_s_rank0": n_local / (rollout_ms_per_step * 1e-3),
                               "note": "same steps as one jxs_rollout launch; secondary figure, not `value`"},
         }
+        if saturated is not None:
+            if "env_steps_per_s" in saturated:
+                saturated["hbm_frac"] = alg_bytes_per_env * saturated["env_steps_per_s"] / 1e9 / HBM_PEAK_GBS
+                saturated["fp32_frac_of_vector_peak"] = FLOPS_PER_ENV_STEP * saturated["env_steps_per_s"] / 1e12 / FP32_PEAK_TFLOPS
+                saturated["note"] = "same step kernel, one GPU filled; secondary figure, not `value`"
+            out["saturated"] = saturated
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(model, initial_block, args.cpu_baseline_seconds)
