@@ -250,15 +250,7 @@ def free_floating_mass_matrix(model: JaxSimModel, data: JaxSimModelData):
     (the RNEA kernel is the only device code involved)."""
     N, n = data.batch_size, model.dofs()
     nv = 6 + n
-    blk = data.state_block().astype(np.float64)  # [rows][N]
-    from ..state import StateLayout
-
-    L = StateLayout.of(model)
-    blk[L.row_vlin : L.row_vlin + 3] = 0
-    blk[L.row_vang : L.row_vang + 3] = 0
-    blk[L.row_sd : L.row_sd + n] = 0
-    rep_blk = np.tile(blk, (1, nv + 1))  # environment e of replica k sits at column k * N + e
-    z = JaxSimModelData.from_state_block(model, rep_blk.astype(data.dtype), data.velocity_representation)
+    z = _zero_velocity_replicas(model, data, nv + 1)
     acc = np.zeros((nv + 1, N, nv))
     for k in range(nv):
         acc[k, :, k] = 1.0
@@ -271,6 +263,74 @@ def free_floating_mass_matrix(model: JaxSimModel, data: JaxSimModelData):
     if not model.floating_base():
         pass  # the reference returns the full (6+n) matrix for fixed-base models too
     return data._out(M.astype(data.dtype))
+
+
+def _zero_velocity_replicas(model: JaxSimModel, data: JaxSimModelData, copies: int) -> JaxSimModelData:
+    """``copies`` replicas of the batch at zero velocity: environment e of replica k sits at k * N + e."""
+    from ..state import StateLayout
+
+    n = model.dofs()
+    blk = data.state_block().astype(np.float64)
+    L = StateLayout.of(model)
+    blk[L.row_vlin : L.row_vlin + 3] = 0
+    blk[L.row_vang : L.row_vang + 3] = 0
+    blk[L.row_sd : L.row_sd + n] = 0
+    return JaxSimModelData.from_state_block(model, np.tile(blk, (1, copies)).astype(data.dtype), data.velocity_representation)
+
+
+def free_floating_mass_matrix_inverse(model: JaxSimModel, data: JaxSimModelData):
+    """``M(q)^-1`` in the active velocity representation (``src/jaxsim/api/model.py:1593-1631``; the
+    reference runs its ``mass_inverse`` recursion).  Columns from ONE forward-dynamics launch over a
+    virtual batch at zero velocity: ``M^-1 e_i = FD(q, 0, e_i) - FD(q, 0, 0)`` with the unit generalized
+    forces applied as a base-link wrench (active representation) or a joint torque."""
+    N, n, nL = data.batch_size, model.dofs(), model.number_of_links()
+    nv = 6 + n
+    z = _zero_velocity_replicas(model, data, nv + 1)
+    tau = np.zeros((nv + 1, N, n))
+    f = np.zeros((nv + 1, N, nL, 6))
+    for k in range(6):
+        f[k, :, 0, k] = 1.0
+    for k in range(n):
+        tau[6 + k, :, k] = 1.0
+    vd, sdd = forward_dynamics_aba(model, z, joint_forces=tau.reshape(-1, n), link_forces=f.reshape(-1, nL, 6))
+    acc = np.concatenate([np.asarray(vd, np.float64), np.asarray(sdd, np.float64).reshape((nv + 1) * N, n)], -1)
+    acc = acc.reshape(nv + 1, N, nv)
+    Mi = np.transpose(acc[:nv] - acc[nv:], (1, 2, 0))
+    Mi = 0.5 * (Mi + np.transpose(Mi, (0, 2, 1)))
+    return data._out(Mi.astype(data.dtype))
+
+
+def generalized_free_floating_jacobian(model: JaxSimModel, data: JaxSimModelData, *, output_vel_repr=None):
+    """Free-floating Jacobians of all links, ``[nL, 6, 6+n]`` (``src/jaxsim/api/model.py:925-1045``): the
+    generalized velocity is expressed in ``data.velocity_representation``, the link velocity in
+    ``output_vel_repr`` (default: the same).  Column i is the link velocity field of the unit generalized
+    velocity e_i, evaluated by the cached-kinematics kernel over a virtual batch of 6+n replicas."""
+    from ..state import StateLayout
+
+    out_rep = data.velocity_representation if output_vel_repr is None else VelRepr(output_vel_repr)
+    N, n, nL = data.batch_size, model.dofs(), model.number_of_links()
+    nv = 6 + n
+    L = StateLayout.of(model)
+    z = _zero_velocity_replicas(model, data, nv)
+    # unit generalized velocities in the active representation -> the inertial-fixed state rows
+    nu = np.zeros((nv, N, nv))
+    for k in range(nv):
+        nu[k, :, k] = 1.0
+    H_B = np.tile(data._base_transform_batched(), (nv, 1, 1))
+    W_v = _other_to_inertial(nu.reshape(-1, nv)[:, :6], data.velocity_representation, H_B, False)
+    blk = z.state_block().astype(np.float64)
+    blk[L.row_vlin : L.row_vlin + 3] = W_v[:, :3].T
+    blk[L.row_vang : L.row_vang + 3] = W_v[:, 3:].T
+    blk[L.row_sd : L.row_sd + n] = nu.reshape(-1, nv)[:, 6:].T
+    z = JaxSimModelData.from_state_block(model, blk.astype(data.dtype), data.velocity_representation)
+    W_v_WL = np.asarray(z._link_velocities, np.float64).reshape(nv, N, nL, 6)
+    W_H_L = np.asarray(z._link_transforms, np.float64).reshape(nv, N, nL, 4, 4)[0]
+    cols = W_v_WL
+    if out_rep != VelRepr.Inertial:
+        H = np.broadcast_to(W_H_L, (nv,) + W_H_L.shape).reshape(-1, 4, 4)
+        cols = _inertial_to_other(W_v_WL.reshape(-1, 6), out_rep, H, False).reshape(nv, N, nL, 6)
+    J = np.transpose(cols, (1, 2, 3, 0))  # [N, nL, 6, nv]
+    return data._out(J.astype(data.dtype))
 
 
 def free_floating_bias_forces(model: JaxSimModel, data: JaxSimModelData):

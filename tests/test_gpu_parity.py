@@ -587,3 +587,33 @@ def test_step_repeat_graph_equals_single_launches(models):
             _lib.check(lib.jxs_step_repeat(dm.handle, C.c_void_p(g._state.ptr), None, None, 2, 50, 4, stream.handle), "repeat")
         stream.synchronize()
         np.testing.assert_array_equal(g.state_block(), ref.state_block())
+
+
+@pytest.mark.parametrize("name", ["chain9f", "anymal"])
+def test_mass_matrix_inverse_and_link_jacobians(models, name):
+    """``free_floating_mass_matrix_inverse`` (api/model.py:1593-1631) and
+    ``generalized_free_floating_jacobian`` (:925-1045) evaluated through virtual batches of the FD / cached
+    kinematics kernels, against the oracle's dense restatement."""
+    from oracle import refmath as rm
+    from oracle import refrigid
+
+    model = models(name)
+    d = models.random_data(name, 4, seed=43, rep=VelRepr.Mixed)
+    g = to_gpu(model, d)
+    Mi = js.model.free_floating_mass_matrix_inverse(model, g)
+    assert helpers.rel_err(Mi, refrigid.free_floating_mass_matrix_inverse_mixed(model, d)) < 1e-9
+    M = js.model.free_floating_mass_matrix(model, g)
+    np.testing.assert_allclose(M @ Mi, np.broadcast_to(np.eye(M.shape[-1]), M.shape), atol=1e-8)
+    # mixed input, inertial output
+    W_J = refrigid.generalized_free_floating_jacobian_inertial_output(model, d, VelRepr.Mixed)
+    J_in = js.model.generalized_free_floating_jacobian(model, g, output_vel_repr=ja.VelRepr.Inertial)
+    assert J_in.shape == W_J.shape and helpers.rel_err(J_in, W_J) < 1e-9
+    # mixed input, mixed output: LW_X_W W_J  (api/model.py:1021-1040)
+    H = d.link_transforms.copy()
+    H[..., :3, :3] = np.eye(3)
+    LW_J = rm.adjoint_from_transform(H, inverse=True) @ W_J
+    assert helpers.rel_err(js.model.generalized_free_floating_jacobian(model, g), LW_J) < 1e-9
+    # J nu = link velocity in the output representation
+    nu = d.generalized_velocity(VelRepr.Mixed)
+    v = np.einsum("nlij,nj->nli", js.model.generalized_free_floating_jacobian(model, g, output_vel_repr=ja.VelRepr.Inertial), nu)
+    np.testing.assert_allclose(v, d.link_velocities, atol=1e-9)
