@@ -50,3 +50,80 @@ def estimate_good_contact_parameters(
         number_of_active_collidable_points_steady_state=number_of_active_collidable_points_steady_state,
         damping_ratio=damping_ratio,
     )
+
+
+# ---- queries on the cached kinematics (src/jaxsim/api/contact.py:18-145,214-350) ------------------
+# The kernels of the step keep the contact phase on the device; these are the reference's read-only
+# helpers, evaluated on the host from the cached link transforms / velocities of the data object
+# (``jxs_refresh_kinematics``).  Enabled collidable points only, like the reference.
+
+
+def _enabled(model: JaxSimModel):
+    kdp = model.kin_dyn_parameters
+    idx = kdp.indices_of_enabled_collidable_points
+    return kdp.contact_body[idx], kdp.contact_point[idx]
+
+
+def collidable_point_kinematics(model: JaxSimModel, data):
+    """Position and velocity of the enabled collidable points in the world frame
+    (``api/contact.py:18-45``, ``rbda/collidable_points.py:9-65``): ``p = W_H_L L_p``,
+    ``pdot = v_lin + w x p`` of the inertial-fixed link velocity."""
+    body, L_p = _enabled(model)
+    H = np.asarray(data._kinematics()[0], dtype=np.float64)[:, body]  # [N, n_cp, 4, 4]
+    V = np.asarray(data._kinematics()[1], dtype=np.float64)[:, body]
+    p = np.einsum("ncij,cj->nci", H[..., :3, :3], L_p) + H[..., :3, 3]
+    pd = V[..., :3] + np.cross(V[..., 3:], p)
+    return data._out(p.astype(data.dtype)), data._out(pd.astype(data.dtype))
+
+
+def collidable_point_positions(model: JaxSimModel, data):
+    return collidable_point_kinematics(model, data)[0]
+
+
+def collidable_point_velocities(model: JaxSimModel, data):
+    return collidable_point_kinematics(model, data)[1]
+
+
+def in_contact(model: JaxSimModel, data, *, link_names=None):
+    """Boolean per link: some enabled collidable point of the link is at or below the terrain
+    (``api/contact.py:92-145``)."""
+    names = model.link_names()
+    if link_names is not None and set(link_names).difference(names):
+        raise ValueError("One or more link names are not part of the model")
+    body, _ = _enabled(model)
+    p, _ = collidable_point_kinematics(model, data)
+    p = np.asarray(p, dtype=np.float64).reshape(-1, len(body), 3)
+    below = p[..., 2] <= model.terrain.height(p[..., 0], p[..., 1])
+    idxs = [names.index(n) for n in link_names] if link_names is not None else list(range(model.number_of_links()))
+    out = np.stack([(below & (body == i)[None, :]).any(axis=1) for i in idxs], axis=1)
+    return data._out(out)
+
+
+def transforms(model: JaxSimModel, data):
+    """``W_H_C`` of the implicit frames ``C = (W_p_C, [L])`` of the enabled points (``api/contact.py:214-257``)."""
+    body, L_p = _enabled(model)
+    H = np.asarray(data._kinematics()[0], dtype=np.float64)[:, body].copy()
+    H[..., :3, 3] += np.einsum("ncij,cj->nci", H[..., :3, :3], L_p)
+    return data._out(H.astype(data.dtype))
+
+
+def jacobian(model: JaxSimModel, data, *, output_vel_repr=None):
+    """Free-floating Jacobians of the frames of the enabled collidable points, ``[n_cp, 6, 6+n]``
+    (``api/contact.py:260-350``): the Jacobian of the parent link in inertial-fixed output representation,
+    re-expressed in the frame ``C`` (Body) or ``C[W]`` (Mixed)."""
+    from ..data import _inertial_to_other
+    from ..model import VelRepr
+    from . import model as _m
+
+    out_rep = data.velocity_representation if output_vel_repr is None else VelRepr(output_vel_repr)
+    body, _ = _enabled(model)
+    W_J = np.asarray(_m.generalized_free_floating_jacobian(model, data, output_vel_repr=VelRepr.Inertial), np.float64)
+    W_J = W_J.reshape((-1,) + W_J.shape[-3:])[:, body]  # [N, n_cp, 6, nv]
+    if out_rep == VelRepr.Inertial:
+        return data._out(W_J.astype(data.dtype))
+    W_H_C = np.asarray(transforms(model, data), np.float64).reshape((-1, len(body), 4, 4))
+    nv = W_J.shape[-1]
+    cols = np.moveaxis(W_J, -1, 2)  # [N, n_cp, nv, 6]
+    H = np.broadcast_to(W_H_C[:, :, None], cols.shape[:3] + (4, 4))
+    O = _inertial_to_other(cols.reshape(-1, 6), out_rep, H.reshape(-1, 4, 4), False).reshape(cols.shape)
+    return data._out(np.moveaxis(O, 2, -1).astype(data.dtype).reshape(W_J.shape[:2] + (6, nv)))

@@ -617,3 +617,36 @@ def test_mass_matrix_inverse_and_link_jacobians(models, name):
     nu = d.generalized_velocity(VelRepr.Mixed)
     v = np.einsum("nlij,nj->nli", js.model.generalized_free_floating_jacobian(model, g, output_vel_repr=ja.VelRepr.Inertial), nu)
     np.testing.assert_allclose(v, d.link_velocities, atol=1e-9)
+
+
+def test_contact_query_api(models):
+    """``js.contact``: point kinematics, ``in_contact``, frame transforms and Jacobians
+    (reference api/contact.py:18-145,214-350; identity checked by its tests: J nu = point velocity)."""
+    from oracle import refrigid
+
+    model = helpers.enable_points(models("anymal"), helpers.ANYMAL_FEET_16)
+    d = models.random_data("anymal", 6, seed=5)
+    g = to_gpu(model, d)
+    p_ref, v_ref = oracle.collidable_points_pos_vel(model, link_transforms=d.link_transforms, link_velocities=d.link_velocities)
+    p, v = js.contact.collidable_point_kinematics(model, g)
+    np.testing.assert_allclose(p, p_ref, atol=1e-12)
+    np.testing.assert_allclose(v, v_ref, atol=1e-12)
+    np.testing.assert_allclose(js.contact.collidable_point_positions(model, g), p_ref, atol=1e-12)
+    J = js.contact.jacobian(model, g)  # mixed in, mixed out
+    np.testing.assert_allclose(J, refrigid.contact_jacobian_mixed(model, d), atol=1e-9)
+    np.testing.assert_allclose(np.einsum("ncij,nj->nci", J, d.generalized_velocity(VelRepr.Mixed))[..., :3], v_ref, atol=1e-9)
+    np.testing.assert_allclose(js.contact.transforms(model, g), refrigid.contact_transforms(model, d), atol=1e-12)
+    touching = js.contact.in_contact(model, g)
+    assert touching.shape == (6, model.number_of_links())
+    body = model.kin_dyn_parameters.contact_body[model.kin_dyn_parameters.indices_of_enabled_collidable_points]
+    expect = np.stack([((p_ref[..., 2] <= 0) & (body == i)[None]).any(axis=1) for i in range(model.number_of_links())], 1)
+    np.testing.assert_array_equal(touching, expect)
+    assert touching.any() and not touching.all()
+    with pytest.raises(ValueError, match="not part of the model"):
+        js.contact.in_contact(model, g, link_names=["nope"])
+    feet = js.contact.in_contact(model, g, link_names=["LF_SHANK", "RH_SHANK"])
+    assert feet.shape == (6, 2)
+    # unbatched data: the leading axis disappears like in the reference
+    one = js.data.JaxSimModelData.build(model=model, base_position=np.array([0.0, 0.0, 0.5]))
+    assert js.contact.collidable_point_positions(model, one).shape == (16, 3)
+    assert js.contact.in_contact(model, one).shape == (model.number_of_links(),)
