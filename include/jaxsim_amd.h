@@ -170,6 +170,13 @@ int jxs_inverse_dynamics(jxs_model* model, const void* state, const void* in_acc
                          const void* link_forces, int force_repr, void* out_forces, int N,
                          void* stream);
 
+/* Layout conversion on the device between an environment-major array `[N][rows]` (row-major, what the
+ * reference's vmapped arrays, a NumPy upload or a DLPack / __cuda_array_interface__ buffer of another
+ * framework hold) and the tile-interleaved storage every batched argument of this library uses
+ * (`jxs_layout.tile`).  The tiled buffer must hold ceil(N / tile) * rows * tile elements.      */
+int jxs_tile_from_env_major(const void* src, void* dst, int rows, int N, int tile, int dtype, void* stream);
+int jxs_tile_to_env_major(const void* src, void* dst, int rows, int N, int tile, int dtype, void* stream);
+
 /* Value checks of a state block, the counterpart of the host callbacks the reference enables with
  * JAXSIM_ENABLE_EXCEPTIONS (src/jaxsim/exceptions.py:6-60, rbda/utils.py:135-146).  Synchronous.
  * counts3[0] = environments whose base quaternion contains NaN, [1] = environments whose quaternion is

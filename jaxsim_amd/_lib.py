@@ -196,6 +196,8 @@ def _declare(lib):
         "jxs_forward_dynamics_aba": [vp, vp, vp, vp, C.c_int, vp, C.c_int, vp],
         "jxs_inverse_dynamics": [vp, vp, vp, vp, C.c_int, vp, C.c_int, vp],
         "jxs_gravity_torques": [vp, vp, vp, C.c_int, vp],
+        "jxs_tile_from_env_major": [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp],
+        "jxs_tile_to_env_major": [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp],
         "jxs_validate_state": [vp, vp, C.c_int, C.POINTER(C.c_int), vp],
         "jxs_step_repeat": [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp],
         "jxs_refresh_kinematics": [vp, vp, vp, vp, C.c_int, vp],

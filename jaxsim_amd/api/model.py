@@ -19,13 +19,23 @@ from ..runtime import DeviceArray
 
 
 def _as_device(x, rows: int, N: int, dtype, trailing_shape, tile: int) -> DeviceArray | None:
-    """Accept None | DeviceArray ([rows][N]) | host array ([N, *trailing] or [*trailing])."""
+    """Accept None | DeviceArray ([rows][N]) | an object with ``__cuda_array_interface__`` holding a
+    contiguous device array ``[N, *trailing]`` | host array ([N, *trailing] or [*trailing])."""
     if x is None:
         return None
     if isinstance(x, DeviceArray):
         if x.shape != (rows, N) or x.dtype != np.dtype(dtype):
             raise ValueError((x.shape, (rows, N)))
         return x
+    cai = getattr(x, "__cuda_array_interface__", None)
+    if cai is not None:
+        # a device array of another framework (DLPack / CUDA array interface): contiguous [N, *trailing]
+        # of the data's dtype; tiled on the device, no host round trip
+        if tuple(cai["shape"]) != (N,) + tuple(trailing_shape) or np.dtype(cai["typestr"]) != np.dtype(dtype):
+            raise ValueError((tuple(cai["shape"]), cai["typestr"], (N,) + tuple(trailing_shape), np.dtype(dtype).str))
+        if cai.get("strides") is not None:
+            raise ValueError("device arrays must be C-contiguous")
+        return DeviceArray.from_device_env_major(cai["data"][0], N, rows, dtype, tile=tile)
     a = np.asarray(x, dtype=np.float64)
     a = a.squeeze() if a.ndim > len(trailing_shape) + 1 else a
     if a.shape == tuple(trailing_shape):

@@ -304,6 +304,18 @@ __global__ void jxs_validate_kernel(const T* state, int n_rows, int row_quat, in
 }
 
 
+// ---- layout conversion at the boundary: environment-major [N][rows] (what a host array, a DLPack /
+// __cuda_array_interface__ buffer of another framework holds) <-> the tile-interleaved storage ------
+template <typename T, bool TO_TILED>
+__global__ void jxs_retile_kernel(const T* src, T* dst, int rows, int N, int tile) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)rows * N) return;
+  const int env = (int)(i / rows), row = (int)(i % rows);
+  const size_t tiled = ((size_t)(env / tile) * rows + row) * tile + env % tile;
+  if (TO_TILED) dst[tiled] = src[i];
+  else dst[i] = src[tiled];
+}
+
 extern "C" {
 
 // Not part of the public ABI: phase-stamp buffer of the -DJXS_PHASE_TIMING developer build.
@@ -448,6 +460,32 @@ int jxs_validate_state(jxs_model* model, const void* state, int N, int* counts3,
   hipFree(d);
   if (e != hipSuccess) return hip_fail(e, "jxs_validate_state");
   return JXS_OK;
+}
+
+static int retile(const void* src, void* dst, int rows, int N, int tile, int dtype, void* stream, bool to_tiled) {
+  if (src == nullptr || dst == nullptr) return fail(JXS_EINVAL, "null argument");
+  if (rows <= 0 || N <= 0 || tile <= 0) return fail(JXS_EINVAL, "rows, N and tile must be positive");
+  if (dtype != JXS_F32 && dtype != JXS_F64) return fail(JXS_EINVAL, "dtype must be JXS_F32 or JXS_F64");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const long long total = (long long)rows * N;
+  const int threads = 256;
+  const int blocks = (int)((total + threads - 1) / threads);
+  if (dtype == JXS_F64) {
+    if (to_tiled) hipLaunchKernelGGL((jxs_retile_kernel<double, true>), dim3(blocks), dim3(threads), 0, s, (const double*)src, (double*)dst, rows, N, tile);
+    else hipLaunchKernelGGL((jxs_retile_kernel<double, false>), dim3(blocks), dim3(threads), 0, s, (const double*)src, (double*)dst, rows, N, tile);
+  } else {
+    if (to_tiled) hipLaunchKernelGGL((jxs_retile_kernel<float, true>), dim3(blocks), dim3(threads), 0, s, (const float*)src, (float*)dst, rows, N, tile);
+    else hipLaunchKernelGGL((jxs_retile_kernel<float, false>), dim3(blocks), dim3(threads), 0, s, (const float*)src, (float*)dst, rows, N, tile);
+  }
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "jxs_retile");
+  return JXS_OK;
+}
+int jxs_tile_from_env_major(const void* src, void* dst, int rows, int N, int tile, int dtype, void* stream) {
+  return retile(src, dst, rows, N, tile, dtype, stream, true);
+}
+int jxs_tile_to_env_major(const void* src, void* dst, int rows, int N, int tile, int dtype, void* stream) {
+  return retile(src, dst, rows, N, tile, dtype, stream, false);
 }
 
 int jxs_step(jxs_model* model, const void* state_in, void* state_out, const void* tau, const void* link_forces,

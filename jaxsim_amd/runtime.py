@@ -147,6 +147,38 @@ class DeviceArray:
         )
         return out
 
+    @staticmethod
+    def from_device_env_major(ptr: int, n_envs: int, rows: int, dtype, *, tile: int) -> "DeviceArray":
+        """Tile a device buffer ``[N][rows]`` (row-major, e.g. the ``data_ptr`` of another framework's
+        contiguous ``(N, rows)`` array) into a new ``DeviceArray``; stays on the device."""
+        out = DeviceArray(rows, n_envs, dtype, tile=tile, zero=n_envs % tile != 0)
+        _lib.check(
+            _lib.load().jxs_tile_from_env_major(
+                C.c_void_p(int(ptr)), C.c_void_p(out.ptr), out.rows, out.cols, out.tile, _lib.dtype_code(out.dtype), _sp()
+            ),
+            "jxs_tile_from_env_major",
+        )
+        return out
+
+    def to_device_env_major(self, ptr: int) -> None:
+        """Write this array as ``[N][rows]`` (row-major) into the device buffer at ``ptr``."""
+        _lib.check(
+            _lib.load().jxs_tile_to_env_major(
+                C.c_void_p(self.ptr), C.c_void_p(int(ptr)), self.rows, self.cols, self.tile, _lib.dtype_code(self.dtype), _sp()
+            ),
+            "jxs_tile_to_env_major",
+        )
+
+    @property
+    def __cuda_array_interface__(self) -> dict:
+        """Raw view of the tiled storage (1-D) for frameworks that speak the CUDA array interface."""
+        return {
+            "shape": (self.n_tiles * self.rows * self.tile,),
+            "typestr": self.dtype.str,
+            "data": (int(self.ptr), False),
+            "version": 3,
+        }
+
     def to_host_raw(self) -> np.ndarray:
         """Download the storage as is: ``[n_tiles, rows, tile]``."""
         out = np.empty((self.n_tiles, self.rows, self.tile), dtype=self.dtype)

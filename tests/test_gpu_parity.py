@@ -650,3 +650,46 @@ def test_contact_query_api(models):
     one = js.data.JaxSimModelData.build(model=model, base_position=np.array([0.0, 0.0, 0.5]))
     assert js.contact.collidable_point_positions(model, one).shape == (16, 3)
     assert js.contact.in_contact(model, one).shape == (model.number_of_links(),)
+
+
+def test_device_side_layout_conversion_and_array_interface(models):
+    """Environment-major device buffers (another framework's ``(N, n)`` array) are tiled / untiled on the
+    device (``jxs_tile_from_env_major`` / ``jxs_tile_to_env_major``) and accepted by ``step`` through the
+    CUDA array interface without a host round trip."""
+    import ctypes as C
+
+    from jaxsim_amd import _lib
+    from jaxsim_amd.runtime import DeviceArray
+
+    model = models("icub")
+    N, n = 37, model.dofs()
+    rng = np.random.default_rng(3)
+    tau = rng.uniform(-3, 3, size=(N, n)).astype(np.float32)
+    lib = _lib.load()
+    raw = C.c_void_p()
+    _lib.check(lib.jxs_malloc(C.byref(raw), tau.nbytes), "malloc")
+    _lib.check(lib.jxs_memcpy_h2d(raw, tau.ctypes.data_as(C.c_void_p), tau.nbytes, None), "h2d")
+    runtime.synchronize()
+    tile = runtime.device_model(model, np.float32).layout.tile
+    tiled = DeviceArray.from_device_env_major(raw.value, N, n, np.float32, tile=tile)
+    np.testing.assert_array_equal(tiled.to_host(), tau.T)
+    back = C.c_void_p()
+    _lib.check(lib.jxs_malloc(C.byref(back), tau.nbytes), "malloc")
+    tiled.to_device_env_major(back.value)
+    out = np.empty_like(tau)
+    runtime.synchronize()
+    _lib.check(lib.jxs_memcpy_d2h(out.ctypes.data_as(C.c_void_p), back, tau.nbytes, None), "d2h")
+    np.testing.assert_array_equal(out, tau)
+
+    class Foreign:  # what a torch / cupy / jax device array looks like to a consumer
+        __cuda_array_interface__ = {"shape": (N, n), "typestr": "<f4", "data": (raw.value, False), "version": 3}
+
+    d = models.random_data("icub", N, seed=71, dtype=np.float32)
+    a = js.model.step(model, to_gpu(model, d), joint_force_references=Foreign()).state_block()
+    b = js.model.step(model, to_gpu(model, d), joint_force_references=tau).state_block()
+    np.testing.assert_array_equal(a, b)
+    with pytest.raises(ValueError):
+        Foreign.__cuda_array_interface__ = dict(Foreign.__cuda_array_interface__, typestr="<f8")
+        js.model.step(model, to_gpu(model, d), joint_force_references=Foreign())
+    lib.jxs_free(raw)
+    lib.jxs_free(back)
