@@ -20,6 +20,8 @@
 //   I point->link api/contact.py:557-603            G ABA               rbda/aba.py:12-292
 //   C integrator  api/integrators.py:14-88          R RNEA              rbda/rnea.py:12-238
 //   A step glue   api/model.py:2601-2681            N cache refresh     api/data.py:405-523
+//   RK4           api/integrators.py:91-167, api/ode.py:134-225 (MODE_STEP_RK4)
+//   S5 rigid contacts rbda/contacts/rigid.py:176-539 (MODE_STEP_RIGID, member functions in jxs_rigid.inc)
 #pragma once
 #include "jxs_params.h"
 
@@ -408,7 +410,7 @@ struct Core {
     }
 
     // ---- J,K,L,I: soft contacts ----------------------------------------------------------
-    if (with_contacts) contacts(lane, ps0, R, r, vl, va, pB, doff, vBc, om, fl, fa);  // updates ps0.m
+    if (with_contacts) contacts(lane, ps0, R, r, vl, va, pB, doff, vBc, om, fl, fa);  // sets ps0.md
     ln.stamp(A, 5);  // contacts
 
     // ---- link inertia in C and bias force --------------------------------------------------
