@@ -462,7 +462,7 @@ int jxs_validate_state(jxs_model* model, const void* state, int N, int* counts3,
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipMemcpyAsync(counts3, d, 3 * sizeof(int), hipMemcpyDeviceToHost, s);
   if (e == hipSuccess) e = hipStreamSynchronize(s);
-  hipFree(d);
+  (void)hipFree(d);
   if (e != hipSuccess) return hip_fail(e, "jxs_validate_state");
   return JXS_OK;
 }
@@ -527,19 +527,19 @@ int jxs_step_repeat(jxs_model* model, void* state, const void* tau, const void* 
     const Key k{model->uid, state, tau, link_forces, force_repr, N, n_launches, stream};
     hipStream_t hs = static_cast<hipStream_t>(stream);
     if (exec == nullptr || !(k == key)) {
-      if (exec != nullptr) hipGraphExecDestroy(exec), exec = nullptr;
+      if (exec != nullptr) (void)hipGraphExecDestroy(exec), exec = nullptr;
       hipGraph_t g = nullptr;
       JXS_HIP(hipStreamBeginCapture(hs, hipStreamCaptureModeThreadLocal));
       const int rc = run_any(model, jxs::MODE_STEP, state, state, tau, link_forces, force_repr, nullptr, nullptr, nullptr,
                              nullptr, N, n_launches, stream, nullptr, /*fuse=*/false);
       hipError_t e = hipStreamEndCapture(hs, &g);
       if (rc != JXS_OK) {
-        if (g != nullptr) hipGraphDestroy(g);
+        if (g != nullptr) (void)hipGraphDestroy(g);
         return rc;
       }
       if (e != hipSuccess) return hip_fail(e, "hipStreamEndCapture");
       e = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
-      hipGraphDestroy(g);
+      (void)hipGraphDestroy(g);
       if (e != hipSuccess) {
         exec = nullptr;
         return hip_fail(e, "hipGraphInstantiate");
