@@ -410,6 +410,37 @@ struct Core {
     }
 
     // ---- J,K,L,I: soft contacts ----------------------------------------------------------
+    if (with_contacts && with_rows && P.n_chunks == 1) {
+      // The kinematics of the parent links reach the point lanes through the LDS scratch of the
+      // row-distributed layout (18 writes + 18 reads, one round trip) instead of 18 ds_bpermute:
+      // measured 9.70 -> 9.56 us per step (ds_bpermute issues every ~22 cycles for a lone wave).
+      const int KIN = lds_kin_offset(G);
+      const VI kb = lane * 18 + KIN;
+#pragma unroll
+      for (int e = 0; e < 9; ++e) ln.lds_write(kb + e, R[e]);
+#pragma unroll
+      for (int e = 0; e < 3; ++e) {
+        ln.lds_write(kb + (9 + e), r[e]);
+        ln.lds_write(kb + (12 + e), vl[e]);
+        ln.lds_write(kb + (15 + e), va[e]);
+      }
+      ln.lds_sync();
+      const VM valid = ps0.body >= 0;
+      V m[3], Rb[9], rb[3], vbl[3], vba[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) m[k] = vsel(valid, ps0.m[k], V(T(0)));
+      const VI kr = vsel(valid, ps0.body, lane * 0) * 18 + KIN;
+#pragma unroll
+      for (int e = 0; e < 9; ++e) Rb[e] = ln.lds_read(kr + e);
+#pragma unroll
+      for (int e = 0; e < 3; ++e) rb[e] = ln.lds_read(kr + (9 + e)), vbl[e] = ln.lds_read(kr + (12 + e)), vba[e] = ln.lds_read(kr + (15 + e));
+      ln.lds_sync();
+      V w6[6], mdl[3];
+      point_physics(valid, ps0.Lp, m, Rb, rb, vbl, vba, pB, doff, vBc, om, w6, mdl);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) ps0.md[k] = mdl[k];
+      link_wrench_sums(lane, ps0.tail, ps0.hd, w6, fl, fa);
+    } else
     if (with_contacts) contacts(lane, ps0, R, r, vl, va, pB, doff, vBc, om, fl, fa);  // sets ps0.md
     ln.stamp(A, 5);  // contacts
 
@@ -1118,6 +1149,139 @@ struct Core {
 
 #include "jxs_rigid.inc"
 
+  // Per-link sum of the point wrenches (api/contact.py:557-603): segmented suffix-sum over the slots of
+  // one link, then every link lane fetches the sum at the head slot of its segment.
+  JXS_HD void link_wrench_sums(const VI& lane, const VI& tail, const VI& hd_in, V* w6, V* fl, V* fa) const {
+    const V zero = V(T(0));
+    // segmented suffix-sum over the slots of one link (slots are sorted by link); when every
+    // segment lies inside a 16-lane row the partner lane+off is reached by a DPP row shift
+    if (P.seg_dpp_ok) {
+      if (P.seg_steps > 0) seg_step_dpp<1>(tail, w6);
+      if (P.seg_steps > 1) seg_step_dpp<2>(tail, w6);
+      if (P.seg_steps > 2) seg_step_dpp<4>(tail, w6);
+      if (P.seg_steps > 3) seg_step_dpp<8>(tail, w6);
+    } else {
+      for (int st = 0, off = 1; st < P.seg_steps; ++st, off <<= 1) {
+        const VM take = tail >= off;
+        const VI src = lane + off;
+        V g6[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) g6[k] = ln.shfl(w6[k], src);
+        ln.fence();
+#pragma unroll
+        for (int k = 0; k < 6; ++k) w6[k] = w6[k] + vsel(take, g6[k], zero);
+      }
+    }
+    const VI hd = hd_in;
+    const VM has = hd >= 0;
+    V h6[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) h6[k] = ln.shfl(w6[k], hd);
+    ln.fence();
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      fl[k] = fl[k] + vsel(has, h6[k], zero);
+      fa[k] = fa[k] + vsel(has, h6[3 + k], zero);
+    }
+  }
+
+  // Kinematics, penetration and Hunt-Crossley force of one collidable point per lane, given the
+  // kinematics (Rb, rb, vbl, vba) of its parent link in frame C: the wrench w6 in C and the rate md of
+  // the tangential deformation (rbda/collidable_points.py:9-65, rbda/contacts/common.py:25-63,
+  // rbda/contacts/soft.py:195-388).
+  JXS_HD void point_physics(const VM& valid, const V* Lp, const V* m, const V* Rb, const V* rb, const V* vbl,
+                            const V* vba, const V* pB, const V* doff, const V* vBc, const V* om, V* w6, V* md) const {
+    const V zero = V(T(0));
+    V rc0[3], rc[3], pw[3], pd[3], t[3];
+    mat3vec(Rb, Lp, rc0);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      rc0[k] = rc0[k] + rb[k];     // relative to the ABA base origin
+      rc[k] = rc0[k] + doff[k];    // relative to the base position, cached (FK) placement
+      pw[k] = rc[k] + pB[k];       // world position
+    }
+    // pdot_C = W_v_L,lin + W_w_L x W_p_C of the cached link kinematics
+    // (collidable_points.py:50-53), written about the C origin.
+    cross(vba, rc0, t);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) pd[k] = vbl[k] + t[k];
+    if (!P.floating) {
+      // cached link velocities of a fixed-base model include the stored base velocity
+      cross(om, rc, t);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) pd[k] = pd[k] + vBc[k] + t[k];
+    } else {
+      cross(om, doff, t);  // zero for URDF models (suc_H_i[0] = I when floating)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) pd[k] = pd[k] + t[k];
+    }
+    // penetration data (rbda/contacts/common.py:25-63): h = [0,0,height(x,y) - p_z],
+    // delta = max(0, h.n); FlatTerrain: n = +z; PlaneTerrain: constant unit normal,
+    // height(x,y) = h0 - (A x + B y) / C  (terrain/terrain.py:180-215)
+    V delta, pdn, mdn;  // penetration, pdot.n, m.n
+    V nh[3];
+    if (P.flat) {
+      nh[0] = zero, nh[1] = zero, nh[2] = V(T(1));
+      delta = vmax(zero, V(P.terrain_h) - pw[2]);
+      pdn = pd[2];
+      mdn = m[2];
+    } else {
+      nh[0] = V(P.nrm[0]), nh[1] = V(P.nrm[1]), nh[2] = V(P.nrm[2]);
+      const V height = V(P.terrain_h) - (P.nrm[0] * pw[0] + P.nrm[1] * pw[1]) * (T(1) / P.nrm[2]);
+      delta = vmax(zero, (height - pw[2]) * P.nrm[2]);
+      pdn = pd[0] * nh[0] + pd[1] * nh[1] + pd[2] * nh[2];
+      mdn = m[0] * nh[0] + m[1] * nh[1] + m[2] * nh[2];
+    }
+    const VM in_contact = delta > zero;
+    const V ddelta = vsel(in_contact, -pdn, zero);
+    V dp, dq;
+    if (P.pq_half) {
+      dp = vsqrt(delta + P.eps);
+      dq = dp;
+    } else {
+      dp = vpow(delta + P.eps, V(P.p));
+      dq = vpow(delta + P.eps, V(P.q));
+    }
+    const V Kdp = P.K * dp, Ddq = P.D * dq;
+    const V fn = vmax(zero, Kdp * delta + Ddq * ddelta);
+    // tangential / normal split of the point velocity and of the deformation
+    V vt[3], mn[3], mt[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      vt[k] = pd[k] - pdn * nh[k];
+      mn[k] = mdn * nh[k];
+      mt[k] = m[k] - mn[k];
+    }
+    V ft[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) ft[k] = -(Kdp * mt[k] + Ddq * vt[k]);
+    const V ft2 = ft[0] * ft[0] + ft[1] * ft[1] + ft[2] * ft[2];
+    const V mufn = P.mu * fn;
+    const VM no_contact = !in_contact;  // delta <= 0
+    const VM sticking = no_contact || (ft2 <= mufn * mufn);
+    const V nrm = vsqrt(ft2);
+    const V scale = vmin(mufn, nrm) * vrcp(nrm + vsel(nrm == zero, V(P.eps), zero));
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      ft[k] = vsel(sticking, ft[k], scale * ft[k]);
+      ft[k] = vsel(no_contact, zero, ft[k]);
+    }
+    // deformation rate: no contact | sticking | slipping
+    const V inv_Ddq = vrcp(Ddq);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const V md_nc = -(P.K_over_D * m[k]);
+      const V md_st = vt[k] - P.K_over_D * mn[k];
+      const V md_sl = -(ft[k] + Kdp * mt[k]) * inv_Ddq;
+      md[k] = vsel(no_contact, md_nc, vsel(sticking, md_st, md_sl));
+    }
+    // wrench in C: [f; r_C x f]  (W_f = [f; p x f], soft.py:377-388, moved to the C origin)
+    w6[0] = vsel(valid, fn * nh[0] + ft[0], zero);
+    w6[1] = vsel(valid, fn * nh[1] + ft[1], zero);
+    w6[2] = vsel(valid, fn * nh[2] + ft[2], zero);
+    cross(rc, w6, w6 + 3);
+  }
+
   JXS_HD void contacts(const VI& lane, PointSlot& ps0, const V* R, const V* r, const V* vl, const V* va,
                        const V* pB, const V* doff, const V* vBc, const V* om, V* fl, V* fa) const {
     const V zero = V(T(0));
@@ -1146,132 +1310,15 @@ struct Core {
         vba[e] = ln.shfl(va[e], body);
       }
       ln.fence();
-      V rc0[3], rc[3], pw[3], pd[3], t[3];
-      mat3vec(Rb, Lp, rc0);
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        rc0[k] = rc0[k] + rb[k];     // relative to the ABA base origin
-        rc[k] = rc0[k] + doff[k];    // relative to the base position, cached (FK) placement
-        pw[k] = rc[k] + pB[k];       // world position
-      }
-      // pdot_C = W_v_L,lin + W_w_L x W_p_C of the cached link kinematics
-      // (collidable_points.py:50-53), written about the C origin.
-      cross(vba, rc0, t);
-#pragma unroll
-      for (int k = 0; k < 3; ++k) pd[k] = vbl[k] + t[k];
-      if (!P.floating) {
-        // cached link velocities of a fixed-base model include the stored base velocity
-        cross(om, rc, t);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) pd[k] = pd[k] + vBc[k] + t[k];
-      } else {
-        cross(om, doff, t);  // zero for URDF models (suc_H_i[0] = I when floating)
-#pragma unroll
-        for (int k = 0; k < 3; ++k) pd[k] = pd[k] + t[k];
-      }
-      // penetration data (rbda/contacts/common.py:25-63): h = [0,0,height(x,y) - p_z],
-      // delta = max(0, h.n); FlatTerrain: n = +z; PlaneTerrain: constant unit normal,
-      // height(x,y) = h0 - (A x + B y) / C  (terrain/terrain.py:180-215)
-      V delta, pdn, mdn;  // penetration, pdot.n, m.n
-      V nh[3];
-      if (P.flat) {
-        nh[0] = zero, nh[1] = zero, nh[2] = V(T(1));
-        delta = vmax(zero, V(P.terrain_h) - pw[2]);
-        pdn = pd[2];
-        mdn = m[2];
-      } else {
-        nh[0] = V(P.nrm[0]), nh[1] = V(P.nrm[1]), nh[2] = V(P.nrm[2]);
-        const V height = V(P.terrain_h) - (P.nrm[0] * pw[0] + P.nrm[1] * pw[1]) * (T(1) / P.nrm[2]);
-        delta = vmax(zero, (height - pw[2]) * P.nrm[2]);
-        pdn = pd[0] * nh[0] + pd[1] * nh[1] + pd[2] * nh[2];
-        mdn = m[0] * nh[0] + m[1] * nh[1] + m[2] * nh[2];
-      }
-      const VM in_contact = delta > zero;
-      const V ddelta = vsel(in_contact, -pdn, zero);
-      V dp, dq;
-      if (P.pq_half) {
-        dp = vsqrt(delta + P.eps);
-        dq = dp;
-      } else {
-        dp = vpow(delta + P.eps, V(P.p));
-        dq = vpow(delta + P.eps, V(P.q));
-      }
-      const V Kdp = P.K * dp, Ddq = P.D * dq;
-      const V fn = vmax(zero, Kdp * delta + Ddq * ddelta);
-      // tangential / normal split of the point velocity and of the deformation
-      V vt[3], mn[3], mt[3];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        vt[k] = pd[k] - pdn * nh[k];
-        mn[k] = mdn * nh[k];
-        mt[k] = m[k] - mn[k];
-      }
-      V ft[3];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) ft[k] = -(Kdp * mt[k] + Ddq * vt[k]);
-      const V ft2 = ft[0] * ft[0] + ft[1] * ft[1] + ft[2] * ft[2];
-      const V mufn = P.mu * fn;
-      const VM no_contact = !in_contact;  // delta <= 0
-      const VM sticking = no_contact || (ft2 <= mufn * mufn);
-      const V nrm = vsqrt(ft2);
-      const V scale = vmin(mufn, nrm) * vrcp(nrm + vsel(nrm == zero, V(P.eps), zero));
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        ft[k] = vsel(sticking, ft[k], scale * ft[k]);
-        ft[k] = vsel(no_contact, zero, ft[k]);
-      }
-      // deformation rate: no contact | sticking | slipping
-      V md[3];
-      const V inv_Ddq = vrcp(Ddq);
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const V md_nc = -(P.K_over_D * m[k]);
-        const V md_st = vt[k] - P.K_over_D * mn[k];
-        const V md_sl = -(ft[k] + Kdp * mt[k]) * inv_Ddq;
-        md[k] = vsel(no_contact, md_nc, vsel(sticking, md_st, md_sl));
-      }
+      V w6[6], md[3];
+      point_physics(valid, Lp, m, Rb, rb, vbl, vba, pB, doff, vBc, om, w6, md);
 #pragma unroll
       for (int k = 0; k < 3; ++k)
       {
         if (ch == 0) ps0.md[k] = md[k];  // chunk 0 is carried in registers, integrated by run()
         else ln.gstore(A.state_out, prow * 3 + (P.row_m + k), m[k] + P.dt * md[k], valid, P.n_rows);
       }
-      // wrench in C: [f; r_C x f]  (W_f = [f; p x f], soft.py:377-388, moved to the C origin)
-      V w6[6];
-      w6[0] = vsel(valid, fn * nh[0] + ft[0], zero);
-      w6[1] = vsel(valid, fn * nh[1] + ft[1], zero);
-      w6[2] = vsel(valid, fn * nh[2] + ft[2], zero);
-      cross(rc, w6, w6 + 3);
-      // segmented suffix-sum over the slots of one link (slots are sorted by link); when every
-      // segment lies inside a 16-lane row the partner lane+off is reached by a DPP row shift
-      if (P.seg_dpp_ok) {
-        if (P.seg_steps > 0) seg_step_dpp<1>(tail, w6);
-        if (P.seg_steps > 1) seg_step_dpp<2>(tail, w6);
-        if (P.seg_steps > 2) seg_step_dpp<4>(tail, w6);
-        if (P.seg_steps > 3) seg_step_dpp<8>(tail, w6);
-      } else {
-        for (int st = 0, off = 1; st < P.seg_steps; ++st, off <<= 1) {
-          const VM take = tail >= off;
-          const VI src = lane + off;
-          V g6[6];
-#pragma unroll
-          for (int k = 0; k < 6; ++k) g6[k] = ln.shfl(w6[k], src);
-          ln.fence();
-#pragma unroll
-          for (int k = 0; k < 6; ++k) w6[k] = w6[k] + vsel(take, g6[k], zero);
-        }
-      }
-      const VI hd = ps.hd;
-      const VM has = hd >= 0;
-      V h6[6];
-#pragma unroll
-      for (int k = 0; k < 6; ++k) h6[k] = ln.shfl(w6[k], hd);
-      ln.fence();
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        fl[k] = fl[k] + vsel(has, h6[k], zero);
-        fa[k] = fa[k] + vsel(has, h6[3 + k], zero);
-      }
+      link_wrench_sums(lane, tail, ps.hd, w6, fl, fa);
     }
   }
 

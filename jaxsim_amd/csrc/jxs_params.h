@@ -83,7 +83,8 @@ enum RowI : int {
 // LDS record layout (words): 0..35 M (6x6), 36..41 S, 42..47 c, 48..53 pA, 54 tau
 // exchange area after the G records: base rows 42 words, a0 6 words, sdd G words
 enum RowLds : int { RL_M = 0, RL_S = 36, RL_C = 42, RL_PA = 48, RL_TAU = 54, RL_SDD = 55 };
-JXS_HD constexpr int lds_words_per_env(int G) { return G * kRowRec + 48; }  // records + base rows (42) + pad
+JXS_HD constexpr int lds_kin_offset(int G) { return G * kRowRec + 48; }  // link kinematics for the contact phase: [G][18]
+JXS_HD constexpr int lds_words_per_env(int G) { return lds_kin_offset(G) + 18 * G; }  // records + base rows (42) + pad + kinematics
 // rigid modes: Q and H packed lower triangles of order 3 n_cp + one exchange vector (jxs_rigid.inc)
 JXS_HD constexpr int rigid_lds_words_per_env(int n_cp) { return 3 * n_cp * (3 * n_cp + 1) + 3 * n_cp + 8; }
 constexpr int kQpMaxIter = 30;    // interior-point iterations (oracle/refrigid.py QP_MAX_ITER)
