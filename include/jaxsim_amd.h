@@ -145,7 +145,7 @@ int jxs_step(jxs_model* model, const void* state_in, void* state_out, const void
 
 /* `n_launches` back-to-back in-place jxs_step launches enqueued from one call (no fusion: one kernel
  * launch per step, exactly what a host loop over jxs_step enqueues, without the per-call cost of the
- * host language).  On a created stream the launch sequence is captured once into a hipGraph and
+ * host language).  On a created stream blocks of 50 launches are captured once into a hipGraph and
  * replayed while the arguments stay the same.                                                  */
 int jxs_step_repeat(jxs_model* model, void* state, const void* tau, const void* link_forces,
                     int force_repr, int N, int n_launches, void* stream);
