@@ -51,9 +51,10 @@ extern "C" {
 #define JXS_INTEGRATOR_SEMI_IMPLICIT_EULER 0
 #define JXS_INTEGRATOR_RUNGE_KUTTA4 1
 
-/* Contact models: src/jaxsim/rbda/contacts/{soft,rigid}.py */
+/* Contact models: src/jaxsim/rbda/contacts/{soft,rigid,relaxed_rigid}.py */
 #define JXS_CONTACT_SOFT 0
 #define JXS_CONTACT_RIGID 1
+#define JXS_CONTACT_RELAXED_RIGID 2
 
 /* Host description of one model: the static tables of `KinDynParameters`
  * (src/jaxsim/api/kin_dyn_parameters.py:86-284) plus the model-level constants of
@@ -94,6 +95,9 @@ typedef struct jxs_model_desc {
                                      (rbda/contacts/rigid.py:28-42) and p, q are ignored */
   double regularization_delassus; /* RigidContacts.regularization_delassus (rigid.py:99-101), 1e-6 */
   double solver_tol;              /* RigidContacts solver_options["solver_tol"] (rigid.py:103-108), 1e-3 */
+  /* JXS_CONTACT_RELAXED_RIGID: RelaxedRigidContactsParams (rbda/contacts/relaxed_rigid.py:29-75); mu above is
+     its friction coefficient, K and D are ignored exactly as the reference ignores them (:567-568) */
+  double rr_time_constant, rr_damping_coefficient, rr_d_min, rr_d_max, rr_width, rr_midpoint, rr_power;
 } jxs_model_desc;
 
 typedef struct jxs_model jxs_model; /* opaque, immutable after creation, shareable */

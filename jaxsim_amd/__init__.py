@@ -10,6 +10,8 @@ from .model import (  # noqa: F401
     IntegratorType,
     JaxSimModel,
     PlaneTerrain,
+    RelaxedRigidContacts,
+    RelaxedRigidContactsParams,
     RigidContacts,
     RigidContactsParams,
     SoftContacts,

@@ -64,6 +64,13 @@ class ModelDesc(C.Structure):
         ("contact_model", C.c_int32),
         ("regularization_delassus", C.c_double),
         ("solver_tol", C.c_double),
+        ("rr_time_constant", C.c_double),
+        ("rr_damping_coefficient", C.c_double),
+        ("rr_d_min", C.c_double),
+        ("rr_d_max", C.c_double),
+        ("rr_width", C.c_double),
+        ("rr_midpoint", C.c_double),
+        ("rr_power", C.c_double),
     ]
 
 
@@ -145,7 +152,13 @@ def make_desc(model, dtype) -> tuple[ModelDesc, list]:
     d.terrain_normal = (C.c_double * 3)(*[float(x) for x in nrm])
     d.integrator = int(model.integrator)
     cm = model.contact_model
-    d.contact_model = 1 if type(cm).__name__ == "RigidContacts" else 0
+    d.contact_model = {"RigidContacts": 1, "RelaxedRigidContacts": 2}.get(type(cm).__name__, 0)
+    if d.contact_model == 2:
+        if not cp.valid():
+            raise ValueError("invalid RelaxedRigidContactsParams")
+        d.rr_time_constant, d.rr_damping_coefficient = float(cp.time_constant), float(cp.damping_coefficient)
+        d.rr_d_min, d.rr_d_max, d.rr_width = float(cp.d_min), float(cp.d_max), float(cp.width)
+        d.rr_midpoint, d.rr_power = float(cp.midpoint), float(cp.power)
     d.regularization_delassus = float(getattr(cm, "regularization_delassus", 1e-6))
     d.solver_tol = float(getattr(cm, "solver_tol", 1e-3))
     return d, keep
@@ -161,6 +174,7 @@ def model_signature(model, dtype) -> tuple:
         ap.torque_max, ap.omega_th, ap.omega_max, ap.enable_friction, int(model.integrator),
         type(model.contact_model).__name__, getattr(model.contact_model, "regularization_delassus", None),
         getattr(model.contact_model, "solver_tol", None),
+        tuple(getattr(cp, k, None) for k in ("time_constant", "damping_coefficient", "d_min", "d_max", "width", "midpoint", "power")),
     )  # fmt: skip
 
 

@@ -42,7 +42,7 @@ def estimate_good_contact_parameters(
             pz = np.einsum("cij,cj->ci", H[body][:, :3, :3], kdp.contact_point[idx])[:, 2] + H[body][:, 2, 3]
             z_com -= float(pz.min())
         max_penetration = 0.01 * z_com
-    return SoftContactsParams.build_default_from_jaxsim_model(
+    soft = SoftContactsParams.build_default_from_jaxsim_model(
         model,
         standard_gravity=standard_gravity,
         static_friction_coefficient=static_friction_coefficient,
@@ -50,6 +50,13 @@ def estimate_good_contact_parameters(
         number_of_active_collidable_points_steady_state=number_of_active_collidable_points_steady_state,
         damping_ratio=damping_ratio,
     )
+    # the reference builds the parameter class of the active contact model from the same estimate
+    # (`model.contact_model._parameters_class().build_default_from_jaxsim_model`, contact.py:203-211,
+    # rbda/contacts/common.py:88-168): stiffness, damping and friction go to K, D, mu
+    cls = getattr(model.contact_model, "_parameters_class", SoftContactsParams)
+    if cls is SoftContactsParams:
+        return soft
+    return cls.build(K=soft.K, D=soft.D, mu=soft.mu)
 
 
 # ---- queries on the cached kinematics (src/jaxsim/api/contact.py:18-145,214-350) ------------------

@@ -207,8 +207,10 @@ int run_typed(jxs_model* model, int mode, const void* state_in, void* state_out,
   a.out_a = static_cast<T*>(out_a);
   a.out_H = static_cast<T*>(out_H);
   a.out_V = static_cast<T*>(out_V);
-  if (mode == jxs::MODE_STEP && state_out != state_in && mt->pk.n_disabled > 0) {
-    // rows of disabled collidable points are not touched by the kernel: carry them over
+  if (mode == jxs::MODE_STEP && state_out != state_in &&
+      (mt->pk.n_disabled > 0 || (mt->pk.P.rigid && mt->pk.P.n_points > 0))) {
+    // rows of disabled collidable points are not touched by the kernel, and the rigid contact models
+    // have no tangential deformation (their rows are passengers of the state block): carry them over
     const int tile = 64 / mt->pk.G;
     const size_t elems = (size_t)((N + tile - 1) / tile) * tile * mt->pk.P.n_rows;
     JXS_HIP(hipMemcpyAsync(state_out, state_in, sizeof(T) * elems, hipMemcpyDeviceToDevice, s));

@@ -204,6 +204,7 @@ struct Core {
     }
 #pragma unroll
     for (int stage = 0; stage < n_stages; ++stage) {
+    if (kRigid && stage == 1 && P.rigid == 2) break;  // RelaxedRigidContacts: no velocity reset (relaxed_rigid.py:265-281)
     // ---- base rotation: DCM of q/|q| (data.base_orientation, api/data.py:267-286) --------
     V R[9], r[3];
     {
@@ -690,7 +691,10 @@ struct Core {
         if (stage == 0) {
           // contact forces of the QP, then nudot = nudot_free + M^-1 J^T f  (api/ode.py:57-131)
           V fpt[3];
-          rigid_contact_forces(lane, level, parent, child, tf, ps0, rp, a6, fpt);
+          if (P.rigid == 2)
+            relaxed_contact_forces(lane, level, parent, child, tf, ps0, rp, a6, mass, fpt);
+          else
+            rigid_contact_forces(lane, level, parent, child, tf, ps0, rp, a6, fpt);
           V w6[6], cfl[3] = {V(T(0)), V(T(0)), V(T(0))}, cfa[3] = {V(T(0)), V(T(0)), V(T(0))};
   #pragma unroll
           for (int k = 0; k < 3; ++k) w6[k] = fpt[k];

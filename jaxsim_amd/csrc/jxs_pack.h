@@ -93,8 +93,10 @@ std::string pack_model(const jxs_model_desc& d, Packed<T>& out) {
   P.n_chunks = n_chunks;
   if (d.integrator == JXS_INTEGRATOR_RUNGE_KUTTA4 && n_chunks > 1)
     return "RungeKutta4 needs every enabled collidable point in one lane group (at most 64 points)";
-  if (d.contact_model != JXS_CONTACT_SOFT && d.contact_model != JXS_CONTACT_RIGID) return "unknown contact model";
-  P.rigid = (d.contact_model == JXS_CONTACT_RIGID && n_en > 0) ? 1 : 0;
+  if (d.contact_model != JXS_CONTACT_SOFT && d.contact_model != JXS_CONTACT_RIGID &&
+      d.contact_model != JXS_CONTACT_RELAXED_RIGID)
+    return "unknown contact model";
+  P.rigid = n_en == 0 ? 0 : d.contact_model == JXS_CONTACT_RIGID ? 1 : d.contact_model == JXS_CONTACT_RELAXED_RIGID ? 2 : 0;
   P.n_cp = n_en;
   if (P.rigid) {
     // one point per lane, three rows of the QP per point, both matrices in LDS (jxs_rigid.inc)
@@ -102,7 +104,15 @@ std::string pack_model(const jxs_model_desc& d, Packed<T>& out) {
     if (n_chunks > 1) return "RigidContacts needs every enabled collidable point in one lane group";
     if (!d.floating_base) return "RigidContacts on a fixed-base model is not supported";
     if (d.integrator != JXS_INTEGRATOR_SEMI_IMPLICIT_EULER) return "RigidContacts is built for the SemiImplicitEuler integrator";
-    if (!(d.regularization_delassus >= 0.0) || !(d.solver_tol > 0.0)) return "invalid RigidContacts options";
+    if (P.rigid == 1 && (!(d.regularization_delassus >= 0.0) || !(d.solver_tol > 0.0))) return "invalid RigidContacts options";
+    if (P.rigid == 2) {
+      // RelaxedRigidContactsParams.valid (relaxed_rigid.py:184-200); a zero time constant or width, or a
+      // midpoint at 0 / 1, divides by zero in _regularizers (:540-568)
+      if (!(d.rr_time_constant > 0.0) || !(d.rr_damping_coefficient > 0.0) || !(d.rr_d_min >= 0.0) ||
+          !(d.rr_d_max <= 1.0) || !(d.rr_d_min <= d.rr_d_max) || !(d.rr_d_max > 0.0) || !(d.rr_width > 0.0) ||
+          !(d.rr_midpoint > 0.0) || !(d.rr_midpoint < 1.0) || !(d.rr_power >= 0.0) || !(d.mu >= 0.0))
+        return "invalid RelaxedRigidContactsParams";
+    }
     if (d.suc_H_i[3] != 0.0 || d.suc_H_i[7] != 0.0 || d.suc_H_i[11] != 0.0)
       return "RigidContacts: a base link pose offset (suc_H_i[0]) is not supported";
   }
@@ -172,6 +182,21 @@ std::string pack_model(const jxs_model_desc& d, Packed<T>& out) {
   P.p = (T)d.p;
   P.q = (T)d.q;
   P.K_over_D = (T)d.K / (T)d.D;
+  if (P.rigid == 2) {
+    P.K = (T)(1.0 / ((d.rr_d_max * d.rr_time_constant * d.rr_damping_coefficient) *
+                     (d.rr_d_max * d.rr_time_constant * d.rr_damping_coefficient)));  // relaxed_rigid.py:567
+    P.D = (T)(2.0 / (d.rr_d_max * d.rr_time_constant));                                // :568
+    P.rr_dmin = (T)d.rr_d_min, P.rr_dmax = (T)d.rr_d_max, P.rr_inv_width = (T)(1.0 / d.rr_width);
+    P.rr_mid = (T)d.rr_midpoint, P.rr_pow = (T)d.rr_power;
+    P.rr_ca = (T)(1.0 / std::pow(d.rr_midpoint, d.rr_power - 1.0));
+    P.rr_cb = (T)(1.0 / std::pow(1.0 - d.rr_midpoint, d.rr_power - 1.0));
+    P.rr_rcoef = (T)(2.0 * d.mu * d.mu * (1.0 + d.mu * d.mu));
+    P.rr_tiny = std::numeric_limits<T>::min();
+    // refinement steps of the solve against the operator applied through the tree: fp64 converges in
+    // one; in fp32 the default mu = 0.005 puts the regulariser at the rounding level of the Delassus
+    // entries (condition ~1e6) and four steps are what still pays
+    P.rr_refine = sizeof(T) == 8 ? 2 : 4;
+  }
   P.pq_half = (d.p == 0.5 && d.q == 0.5) ? 1 : 0;
   P.terrain_h = (T)d.terrain_height;
   for (int k = 0; k < 3; ++k) P.nrm[k] = (T)d.terrain_normal[k];

@@ -135,11 +135,18 @@ struct KParams {
   T eps;                         // finfo(dtype).eps                     rbda/contacts/soft.py:246
   T quat_K;                      // Baumgarte gain of Quaternion.derivative (0.1)  math/quaternion.py:72
   // RigidContacts (rbda/contacts/rigid.py:95-174); K, D, mu above are then RigidContactsParams
-  int rigid;                     // contact model: 0 SoftContacts, 1 RigidContacts
+  int rigid;                     // contact model: 0 SoftContacts, 1 RigidContacts, 2 RelaxedRigidContacts
   int n_cp;                      // enabled collidable points (= used slots of chunk 0 in the rigid modes)
   T reg_delassus;                // regularization_delassus (1e-6)
   T qp_tol;                      // solver_options["solver_tol"] (1e-3)
   T impact_rel_tol;              // relative Tikhonov shift of the impact preconditioner
+  // RelaxedRigidContacts (rbda/contacts/relaxed_rigid.py:29-75, 540-591); K, D above then hold the
+  // stiffness 1 / (d_max Omega zeta)^2 and damping 2 / (d_max Omega) of the reference acceleration
+  T rr_dmin, rr_dmax, rr_inv_width, rr_mid, rr_pow;
+  T rr_ca, rr_cb;                // 1 / mid^(p-1), 1 / (1-mid)^(p-1)
+  T rr_rcoef;                    // 2 mu^2 (1 + mu^2)
+  T rr_tiny;                     // smallest positive normal number (guards pow of a non-positive base)
+  int rr_refine;                 // refinement steps against the operator applied through the tree
 };
 
 // Device/host pointers handed to the core for one launch.

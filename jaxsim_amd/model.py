@@ -183,6 +183,64 @@ class RigidContacts:
         return {"solver_tol": self.solver_tol}
 
 
+@dataclasses.dataclass
+class RelaxedRigidContactsParams:
+    """``RelaxedRigidContactsParams`` (``src/jaxsim/rbda/contacts/relaxed_rigid.py:29-75``).  ``K`` and
+    ``D`` are accepted and stored like in the reference, where they do not influence the forces
+    (``_regularizers`` recomputes both from the time constant, ``:567-568``)."""
+
+    time_constant: float = 0.02
+    damping_coefficient: float = 1.0
+    d_min: float = 0.9
+    d_max: float = 0.95
+    width: float = 0.001
+    midpoint: float = 0.5
+    power: float = 2.0
+    K: float = 0.0
+    D: float = 0.0
+    mu: float = 0.005
+
+    @classmethod
+    def build(cls, **kwargs):
+        names = {f.name for f in dataclasses.fields(cls)}
+        return cls(**{k: float(v) for k, v in kwargs.items() if k in names and v is not None})
+
+    def valid(self) -> bool:
+        return bool(
+            self.time_constant >= 0.0 and self.damping_coefficient > 0.0 and self.d_min >= 0.0
+            and self.d_max <= 1.0 and self.d_min <= self.d_max and self.width >= 0.0
+            and self.midpoint >= 0.0 and self.power >= 0.0 and self.mu >= 0.0
+        )  # fmt: skip
+
+
+@dataclasses.dataclass(frozen=True)
+class RelaxedRigidContacts:
+    """``RelaxedRigidContacts`` (``src/jaxsim/rbda/contacts/relaxed_rigid.py:203-488``): contact forces
+    from the regularised linear system ``(J M^-1 J^T + R) f = a_ref - a_free``, no velocity reset.
+    ``solver_options`` keeps the reference's L-BFGS keys (``tol``, ``maxiter``, ``memory_size``,
+    ``scale_init_precond``); the device solves the system the reference hands to
+    ``custom_linear_solve`` directly, so they select nothing."""
+
+    _solver_options_keys: tuple = ("tol", "maxiter", "memory_size", "scale_init_precond")
+    _solver_options_values: tuple = (1e-6, 50, 10, False)
+    _parameters_class = RelaxedRigidContactsParams
+
+    @classmethod
+    def build(cls, solver_options=None, **kwargs):
+        opts = dict(zip(cls._solver_options_keys, cls._solver_options_values)) | (
+            dict(solver_options) if solver_options is not None else {}
+        )
+        try:
+            hash(tuple(opts.values()))
+        except TypeError as exc:
+            raise ValueError("The values of the solver options must be hashable.") from exc
+        return cls(_solver_options_keys=tuple(opts.keys()), _solver_options_values=tuple(opts.values()))
+
+    @property
+    def solver_options(self) -> dict:
+        return dict(zip(self._solver_options_keys, self._solver_options_values))
+
+
 class IntegratorType(enum.IntEnum):
     """``IntegratorType`` (``src/jaxsim/api/model.py:32-40``); values are the C-ABI enum.
     ``RungeKutta4Fast`` (the reference's approximate variant) is not built."""

@@ -694,6 +694,10 @@ def is_rigid_contact_model(model) -> bool:
     return type(getattr(model, "contact_model", None)).__name__ == "RigidContacts"
 
 
+def is_relaxed_rigid_contact_model(model) -> bool:
+    return type(getattr(model, "contact_model", None)).__name__ == "RelaxedRigidContacts"
+
+
 def system_acceleration(model, data: OracleData, *, link_forces=None, joint_torques=None):
     """``system_acceleration`` (ode.py:16-131) evaluated in inertial representation, as the
     semi-implicit Euler integrator does (integrators.py:22)."""
@@ -704,11 +708,13 @@ def system_acceleration(model, data: OracleData, *, link_forces=None, joint_torq
     W_f_L_terrain = np.zeros_like(f_L)
     md = np.zeros_like(data.tangential_deformation)
     if kdp.number_of_collidable_points() > 0:  # ode.py:57
-        if is_rigid_contact_model(model):  # contact.py:538-546: rigid models see the applied forces
-            from . import refrigid
+        if is_rigid_contact_model(model) or is_relaxed_rigid_contact_model(model):
+            # contact.py:538-546: every model but SoftContacts sees the applied forces
+            from . import refrelaxed, refrigid
 
+            impl = refrigid if is_rigid_contact_model(model) else refrelaxed
             data_in = dataclasses.replace(data, velocity_representation=VelRepr.Inertial)  # integrators.py:22
-            W_f_L_terrain, _ = refrigid.link_contact_forces(model, data_in, link_forces=f_L, joint_torques=joint_torques)
+            W_f_L_terrain, _ = impl.link_contact_forces(model, data_in, link_forces=f_L, joint_torques=joint_torques)
         else:
             W_f_L_terrain, md = link_contact_forces(model, data)
     W_f_L_total = f_L + W_f_L_terrain

@@ -23,7 +23,7 @@ MODE_STEP, MODE_FD, MODE_ID, MODE_KIN = 0, 1, 2, 3
 
 
 def build(force: bool = False) -> pathlib.Path:
-    deps = [_SRC, _HERE / "emul" / "jxs_lanes_host.h"] + sorted((_ROOT / "jaxsim_amd" / "csrc").glob("*.h"))
+    deps = [_SRC, _HERE / "emul" / "jxs_lanes_host.h"] + sorted((_ROOT / "jaxsim_amd" / "csrc").glob("*.h")) + sorted((_ROOT / "jaxsim_amd" / "csrc").glob("*.inc"))
     deps.append(_ROOT / "include" / "jaxsim_amd.h")
     if force or not _SO.exists() or any(d.stat().st_mtime > _SO.stat().st_mtime for d in deps):
         cmd = ["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas",

@@ -61,6 +61,16 @@ def main():
         np.savez_compressed(OUT / f"rigid_{name}.npz", state=helpers.odata_to_block(model, d), tau=tau, link_forces=f,
                             step=helpers.odata_to_block(model, nxt), enabled=np.array(idx), K=params["K"], D=params.get("D", 0.0))  # fmt: skip
         print("wrote rigid", name)
+    refrigid.REDUCED_QP = False
+    # RelaxedRigidContacts: converged solution of the regularised system (oracle/refrelaxed.py)
+    for name, idx, mu in (("box", [0, 1, 2, 3, 4, 5, 6, 7], 0.5), ("anymal", helpers.ANYMAL_FEET_16, 0.3)):
+        model = helpers.relaxed_model(zoo(name), idx, mu=mu)
+        d = zoo.random_data(name, 6, seed=5, rep=oracle.VelRepr.Mixed)
+        tau, f = helpers.random_inputs(model, 6, 2030, np.float64)
+        nxt = oracle.step(model, d, link_forces=f, joint_force_references=tau)
+        np.savez_compressed(OUT / f"relaxed_{name}.npz", state=helpers.odata_to_block(model, d), tau=tau, link_forces=f,
+                            step=helpers.odata_to_block(model, nxt), enabled=np.array(idx), mu=mu)  # fmt: skip
+        print("wrote relaxed", name)
 
 
 if __name__ == "__main__":

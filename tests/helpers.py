@@ -139,6 +139,13 @@ def rigid_model(model, idx, *, build=None, **params):
     return enable_points(with_params(model, contact_model=cm, contact_params=ja.RigidContactsParams(**params)), idx)
 
 
+def relaxed_model(model, idx, *, build=None, **params):
+    """Host model with the RelaxedRigidContacts model on the enabled points ``idx`` (reference idiom:
+    ``tests/test_simulations.py:295-318``)."""
+    cm = ja.RelaxedRigidContacts.build(**(build or {}))
+    return enable_points(with_params(model, contact_model=cm, contact_params=ja.RelaxedRigidContactsParams.build(**params)), idx)
+
+
 #: bottom corners of the four foot boxes of the synthetic quadruped (16 points), one corner per foot (4)
 ANYMAL_FEET_16 = [0, 1, 2, 3, 8, 9, 10, 11, 16, 17, 18, 19, 24, 25, 26, 27]
 ANYMAL_FEET_4 = [0, 8, 16, 24]

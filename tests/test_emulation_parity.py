@@ -452,6 +452,85 @@ def test_rigid_box_settles_known_answer(models, dtype, atol):
     assert out[2, 0] == pytest.approx(0.05, abs=atol)
 
 
+# ---- RelaxedRigidContacts (reference: rbda/contacts/relaxed_rigid.py) ----
+RELAXED_CASES = {
+    "box4": ("box", [0, 1, 2, 3], dict()),
+    "box8": ("box", list(range(8)), dict(mu=0.5)),
+    "anymal16": ("anymal", helpers.ANYMAL_FEET_16, dict(mu=0.5)),
+    "anymal4": ("anymal", helpers.ANYMAL_FEET_4, dict(time_constant=0.01, damping_coefficient=0.7, power=1.5)),
+    "chain9f6": ("chain9f", [0, 1, 2, 3, 8, 9], dict(mu=0.8, d_min=0.5, d_max=0.99, width=5e-3, midpoint=0.3)),
+    "icub16": ("icub16", list(range(16)), dict(mu=0.5)),
+}
+
+
+def _relaxed_case(models, key, N, seed, dtype=np.float64):
+    name, idx, params = RELAXED_CASES[key]
+    return helpers.relaxed_model(models(name), idx, **params), models.random_data(name, N, seed=seed, dtype=dtype)
+
+
+@pytest.mark.parametrize("key", list(RELAXED_CASES))
+def test_relaxed_step_matches_oracle(models, key):
+    model, d = _relaxed_case(models, key, 16, seed=5)
+    tau, f = helpers.random_inputs(model, 16, 7, np.float64)
+    ref = oracle.step(model, d, link_forces=f, joint_force_references=tau)
+    out = eb.run(model, eb.MODE_STEP, helpers.odata_to_block(model, d), tau=tau.T, link_forces=f.reshape(16, -1).T, force_repr=2)
+    # box4 keeps the default mu = 0.005: the regulariser is ~1e-6 of the Delassus entries
+    assert helpers.rel_err(out, helpers.odata_to_block(model, ref)) < (1e-9 if key == "box4" else 1e-11)
+    from oracle import refrelaxed
+
+    assert refrelaxed.relaxed_problem(model, d)["active"].any()
+
+
+@pytest.mark.parametrize("key,tol", [("box8", 2e-5), ("anymal16", 2e-5), ("anymal4", 2e-5), ("chain9f6", 1e-4), ("icub16", 2e-4), ("box4", 1e-1)])
+def test_relaxed_step_fp32(models, key, tol):
+    """fp32 kernel arithmetic against the fp64 oracle on the same (fp32-representable) inputs.  box4 runs
+    the bare default mu = 0.005: the regulariser sits at the fp32 rounding level of the Delassus entries
+    (condition ~1e6..1e7), the result is noise-limited at 1e-2 .. 1e-1 whatever the solver does -- the fp32
+    NumPy restatement is 3e-2 away from fp64 there (use fp64 or the estimated
+    parameters, mu = 0.5, with fp32)."""
+    model, d32 = _relaxed_case(models, key, 16, seed=5, dtype=np.float32)
+    tau, f = helpers.random_inputs(model, 16, 7, np.float32)
+    blk = helpers.odata_to_block(model, d32)
+    d64 = helpers.block_to_odata(model, blk.astype(np.float64), oracle.VelRepr.Mixed)
+    ref = oracle.step(model, d64, link_forces=f.astype(np.float64), joint_force_references=tau.astype(np.float64))
+    out = eb.run(model, eb.MODE_STEP, blk, tau=tau.T, link_forces=f.reshape(16, -1).T, force_repr=2)
+    assert out.dtype == np.float32
+    assert helpers.rel_err(out, helpers.odata_to_block(model, ref)) < tol
+
+
+def test_relaxed_tumbling_box_rollout(models):
+    """300 steps of a box dropped on an edge with forward speed."""
+    model = helpers.relaxed_model(models("box"), [0, 1, 2, 3], mu=0.5)
+    q = oracle.refmath.quaternion_from_euler_xyz(np.array([[0.3, 0.2, 0.1]]))
+    d = oracle.OracleData.build(model, base_position=[0, 0, 0.3], base_quaternion=q, base_linear_velocity=[0.5, 0, 0])
+    out = eb.run(model, eb.MODE_STEP, helpers.odata_to_block(model, d), n_steps=300)
+    for _ in range(300):
+        d = oracle.step(model, d)
+    assert helpers.rel_err(out, helpers.odata_to_block(model, d)) < 1e-8
+    assert d.base_position[0, 2] < 0.08  # it landed
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_relaxed_box_settles_known_answer(models, dtype):
+    """reference tests/test_simulations.py:295-346: x, y unchanged (atol 1e-5), z -> 0.05 (atol 1e-4)."""
+    model = helpers.relaxed_model(models("box"), [0, 1, 2, 3], build=dict(solver_options={"tol": 1e-3}))
+    d = oracle.OracleData.build(model, base_position=[0.0, 0.0, 0.2], velocity_representation=VelRepr.Inertial)
+    out = eb.run(model, eb.MODE_STEP, helpers.odata_to_block(model, d).astype(dtype), n_steps=1000)
+    assert abs(out[0, 0]) < 1e-5 and abs(out[1, 0]) < 1e-5
+    assert out[2, 0] == pytest.approx(0.05, abs=1e-4)
+
+
+def test_relaxed_unsupported_configurations_are_rejected(models):
+    import jaxsim_amd as ja
+
+    with pytest.raises(RuntimeError, match="16"):
+        eb.layout(helpers.relaxed_model(models("anymal"), list(range(20))))
+    with pytest.raises(RuntimeError, match="RelaxedRigidContactsParams"):
+        eb.layout(helpers.relaxed_model(models("box"), [0, 1, 2, 3], time_constant=0.0))
+    with pytest.raises(RuntimeError, match="SemiImplicitEuler"):
+        eb.layout(helpers.with_params(helpers.relaxed_model(models("box"), [0, 1, 2, 3]), integrator=ja.IntegratorType.RungeKutta4))
+
+
 def test_rigid_unsupported_configurations_are_rejected(models):
     import jaxsim_amd as ja
 

@@ -404,6 +404,19 @@ def test_rigid_box_settles_known_answer_gpu(models, dtype, atol):
     assert out[2, 0] == pytest.approx(0.05, abs=atol)
 
 
+@pytest.mark.parametrize("kind", ["rigid", "relaxed"])
+def test_rigid_models_carry_the_tangential_rows_through(models, kind):
+    """RigidContacts / RelaxedRigidContacts have no tangential deformation (rigid.py:448-458,
+    relaxed_rigid.py:251-263): the rows of the state block are passengers, also out of place and with
+    every point enabled."""
+    make = helpers.rigid_model if kind == "rigid" else helpers.relaxed_model
+    model = make(models("box"), list(range(8)))
+    d = models.random_data("box", 9, seed=3)
+    assert np.abs(d.tangential_deformation).max() > 0
+    out = js.model.step(model, to_gpu(model, d))
+    np.testing.assert_array_equal(out.state_block()[13:], helpers.odata_to_block(model, d)[13:])
+
+
 def test_rigid_tumbling_box_rollout_gpu(models, reduced_qp):
     model = helpers.rigid_model(models("box"), [0, 1, 2, 3], K=1e5)
     q = oracle.refmath.quaternion_from_euler_xyz(np.array([[0.3, 0.2, 0.1]]))
@@ -440,6 +453,112 @@ def test_config5_quadruped_rigid_contacts_with_gravity_compensation(models, redu
     g24 = js.data.JaxSimModelData.from_state_block(model, helpers.odata_to_block(model, d32)[:, :24], ja.VelRepr.Mixed)
     out24 = js.model.step(model, g24, joint_force_references=tau.to_host()[:, :24].T).state_block()
     np.testing.assert_array_equal(out24, out[:, :24])
+
+
+# ---- RelaxedRigidContacts (rbda/contacts/relaxed_rigid.py; the model of the reference's own
+# test_simulation_step benchmark, tests/test_benchmark.py:142-152) ---------------------------------
+RELAXED_CASES = {
+    "box4": ("box", [0, 1, 2, 3], dict()),
+    "box8": ("box", list(range(8)), dict(mu=0.5)),
+    "anymal16": ("anymal", helpers.ANYMAL_FEET_16, dict(mu=0.5)),
+    "anymal4": ("anymal", helpers.ANYMAL_FEET_4, dict(time_constant=0.01, damping_coefficient=0.7, power=1.5)),
+    "chain9f6": ("chain9f", [0, 1, 2, 3, 8, 9], dict(mu=0.8, d_min=0.5, d_max=0.99, width=5e-3, midpoint=0.3)),
+    "icub16": ("icub16", list(range(16)), dict(mu=0.5)),
+}
+
+
+@pytest.mark.parametrize("key", list(RELAXED_CASES))
+def test_relaxed_step_matches_oracle_gpu(models, key):
+    name, idx, params = RELAXED_CASES[key]
+    model = helpers.relaxed_model(models(name), idx, **params)
+    N = 21  # not a multiple of the environments per wave
+    d = models.random_data(name, N, seed=5)
+    tau, f = helpers.random_inputs(model, N, 7, np.float64)
+    ref = oracle.step(model, d, link_forces=f, joint_force_references=tau)
+    out = js.model.step(model, to_gpu(model, d), link_forces=f, joint_force_references=tau)
+    # box4 keeps the default mu = 0.005: the regulariser is ~1e-6 of the Delassus entries
+    assert helpers.rel_err(out.state_block(), helpers.odata_to_block(model, ref)) < (1e-8 if key == "box4" else 1e-10)
+
+
+@pytest.mark.parametrize("key,tol", [("box8", 1e-4), ("anymal16", 1e-4), ("anymal4", 1e-4), ("chain9f6", 3e-4), ("icub16", 5e-4)])
+def test_relaxed_step_fp32_gpu(models, key, tol):
+    """fp32 against the fp64 oracle on the same inputs (host emulation of the same arithmetic: 5e-6 ..
+    4e-5)."""
+    name, idx, params = RELAXED_CASES[key]
+    model = helpers.relaxed_model(models(name), idx, **params)
+    d = models.random_data(name, 40, seed=5, dtype=np.float32)
+    ref = oracle.step(model, helpers.upcast(d))
+    out = js.model.step(model, to_gpu(model, d))
+    blk = out.state_block()
+    assert blk.dtype == np.float32 and np.isfinite(blk).all()
+    assert helpers.rel_err(blk, helpers.odata_to_block(model, ref)) < tol
+
+
+def test_relaxed_bare_default_parameters_fp32_gpu(models):
+    """The bare defaults (mu = 0.005) put the regulariser at 1e-6 of the Delassus entries: with several
+    points of one rigid body in contact the converged solution carries internal forces of 1e6 N on a
+    1 kg box (measured) and sits at the fp32 rounding level -- the result is noise-limited (worst
+    environment 2e-1, the fp32 NumPy restatement 3e-2).  Finite everywhere and right for the typical
+    environment is what can be asserted; DESIGN.md section 4e says to use fp64 or the estimated
+    parameters (mu = 0.5) instead."""
+    model = helpers.relaxed_model(models("box"), [0, 1, 2, 3])
+    d = models.random_data("box", 40, seed=5, dtype=np.float32)
+    ref = helpers.odata_to_block(model, oracle.step(model, helpers.upcast(d)))
+    blk = js.model.step(model, to_gpu(model, d)).state_block()
+    assert np.isfinite(blk).all()
+    err = np.abs(blk - ref).max(axis=0) / np.abs(ref).max()
+    assert np.median(err) < 3e-3
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_relaxed_box_settles_known_answer_gpu(models, dtype):
+    """reference tests/test_simulations.py:295-346: x, y unchanged (atol 1e-5), z -> 0.05 (atol 1e-4)."""
+    model = helpers.relaxed_model(models("box"), [0, 1, 2, 3], build=dict(solver_options={"tol": 1e-3}))
+    d = oracle.OracleData.build(model, base_position=[0.0, 0.0, 0.2], velocity_representation=VelRepr.Inertial, dtype=dtype)
+    out = js.model.rollout(model, to_gpu(model, d), 1000).state_block()
+    assert abs(out[0, 0]) < 1e-5 and abs(out[1, 0]) < 1e-5
+    assert out[2, 0] == pytest.approx(0.05, abs=1e-4)
+
+
+def test_relaxed_tumbling_box_rollout_gpu(models):
+    model = helpers.relaxed_model(models("box"), [0, 1, 2, 3], mu=0.5)
+    q = oracle.refmath.quaternion_from_euler_xyz(np.array([[0.3, 0.2, 0.1]]))
+    d = oracle.OracleData.build(model, base_position=[0, 0, 0.3], base_quaternion=q, base_linear_velocity=[0.5, 0, 0])
+    out = js.model.rollout(model, to_gpu(model, d), 300).state_block()
+    for _ in range(300):
+        d = oracle.step(model, d)
+    assert helpers.rel_err(out, helpers.odata_to_block(model, d)) < 1e-8
+
+
+def test_relaxed_estimated_parameters_and_large_batch(models):
+    """The reference's benchmark idiom (tests/test_benchmark.py:142-152): RelaxedRigidContacts with
+    `estimate_good_contact_parameters`, stepped over a batch; finiteness, batch independence and
+    oracle parity on a slice at fp32."""
+    base = helpers.relaxed_model(models("anymal"), helpers.ANYMAL_FEET_16)
+    cp = js.contact.estimate_good_contact_parameters(base)
+    assert type(cp).__name__ == "RelaxedRigidContactsParams" and cp.mu == 0.5
+    model = helpers.with_params(base, contact_params=cp)
+    N = 2048
+    d32 = models.random_data("anymal", N, seed=13, dtype=np.float32)
+    out = js.model.step(model, to_gpu(model, d32)).state_block()
+    assert np.isfinite(out).all()
+    blk = helpers.odata_to_block(model, d32)
+    sub = helpers.block_to_odata(model, blk[:, :24].astype(np.float64), oracle.VelRepr.Mixed)
+    ref = oracle.step(model, sub)
+    assert helpers.rel_err(out[:, :24], helpers.odata_to_block(model, ref)) < 1e-4
+    g24 = js.data.JaxSimModelData.from_state_block(model, blk[:, :24], ja.VelRepr.Mixed)
+    np.testing.assert_array_equal(js.model.step(model, g24).state_block(), out[:, :24])
+
+
+@pytest.mark.parametrize("name", ["box", "anymal"])
+def test_gpu_golden_relaxed(models, name):
+    import test_golden as tg
+
+    g = tg.load(f"relaxed_{name}")
+    model = tg._relaxed_model(models, name, g)
+    data = js.data.JaxSimModelData.from_state_block(model, g["state"], ja.VelRepr.Mixed)
+    out = js.model.step(model, data, link_forces=g["link_forces"], joint_force_references=g["tau"])
+    assert helpers.rel_err(out.state_block(), g["step"]) < 1e-10
 
 
 @pytest.mark.parametrize("name", ["cartpole", "chain9f", "icub"])

@@ -3,7 +3,10 @@
 fp32, batch 4096.  Not the headline benchmark (bench.py measures config 3); the numbers feed
 DESIGN.md section 6.
 
-    python tools/bench_c5.py [--points 4|16] [--envs 4096] [--steps 200]
+    python tools/bench_c5.py [--points 4|16] [--envs 4096] [--steps 200] [--contact rigid|relaxed]
+
+`--contact relaxed` swaps in RelaxedRigidContacts with `estimate_good_contact_parameters` (the contact
+model of the reference's own `test_simulation_step` benchmark, tests/test_benchmark.py:142-152).
 """
 
 import argparse
@@ -26,6 +29,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--dtype", default="float32")
+    ap.add_argument("--contact", default="rigid", choices=["rigid", "relaxed"])
     args = ap.parse_args()
 
     import helpers  # tests/helpers.py: model zoo + rigid_model
@@ -35,7 +39,11 @@ def main():
     runtime.require_device()
     zoo = helpers.ModelZoo()
     idx = helpers.ANYMAL_FEET_4 if args.points == 4 else helpers.ANYMAL_FEET_16
-    model = helpers.rigid_model(zoo("anymal"), idx, K=1e4, D=2e2)
+    if args.contact == "rigid":
+        model = helpers.rigid_model(zoo("anymal"), idx, K=1e4, D=2e2)
+    else:
+        model = helpers.relaxed_model(zoo("anymal"), idx)
+        model = helpers.with_params(model, contact_params=js.contact.estimate_good_contact_parameters(model))
     dtype = np.dtype(args.dtype)
     d = zoo.random_data("anymal", args.envs, seed=0, dtype=dtype)
     data = js.data.JaxSimModelData.from_state_block(model, helpers.odata_to_block(model, d), 2)
@@ -60,8 +68,9 @@ def main():
     stream.synchronize()
     ms = e0.elapsed_ms(e1) / args.steps
     blk = data.state_block()
+    cname = "RigidContacts" if args.contact == "rigid" else "RelaxedRigidContacts"
     print(json.dumps({
-        "workload": f"config 5: anymal12 synthetic, RigidContacts ({args.points} points), gravity compensation, {args.dtype}",
+        "workload": f"config 5: anymal12 synthetic, {cname} ({args.points} points), gravity compensation, {args.dtype}",
         "envs": args.envs, "steps": args.steps, "ms_per_step": ms, "env_steps_per_s": args.envs / (ms * 1e-3),
         "finite_envs": float(np.isfinite(blk).all(axis=0).mean()), "lanes_per_env": int(dm.layout.group),
     }))  # fmt: skip
