@@ -100,7 +100,7 @@ std::string pack_model(const jxs_model_desc& d, Packed<T>& out) {
   P.n_cp = n_en;
   if (P.rigid) {
     // one point per lane, three rows of the QP per point, both matrices in LDS (jxs_rigid.inc)
-    if (n_en > kRigidMaxPoints) return "RigidContacts: at most 16 enabled collidable points are supported";
+    if (n_en > kRigidMaxPoints) return "RigidContacts / RelaxedRigidContacts: at most 32 enabled collidable points are supported";
     if (n_chunks > 1) return "RigidContacts needs every enabled collidable point in one lane group";
     if (!d.floating_base) return "RigidContacts on a fixed-base model is not supported";
     if (d.integrator != JXS_INTEGRATOR_SEMI_IMPLICIT_EULER) return "RigidContacts is built for the SemiImplicitEuler integrator";

@@ -88,7 +88,7 @@ JXS_HD constexpr int lds_words_per_env(int G) { return lds_kin_offset(G) + 18 * 
 // rigid modes: Q and H packed lower triangles of order 3 n_cp + one exchange vector (jxs_rigid.inc)
 JXS_HD constexpr int rigid_lds_words_per_env(int n_cp) { return 3 * n_cp * (3 * n_cp + 1) + 3 * n_cp + 8; }
 constexpr int kQpMaxIter = 30;    // interior-point iterations (oracle/refrigid.py QP_MAX_ITER)
-constexpr int kRigidMaxPoints = 16;
+constexpr int kRigidMaxPoints = 32;
 constexpr int kImpactCgIters = 5;  // preconditioned CG iterations of the impact solve (jxs_rigid.inc)
 
 enum Mode : int {

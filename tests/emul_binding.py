@@ -7,6 +7,7 @@ kernel core of the product (``jaxsim_amd/csrc/jxs_core.h``) against a host lane 
 from __future__ import annotations
 
 import ctypes as C
+import os
 import pathlib
 import subprocess
 
@@ -28,6 +29,7 @@ def build(force: bool = False) -> pathlib.Path:
     if force or not _SO.exists() or any(d.stat().st_mtime > _SO.stat().st_mtime for d in deps):
         cmd = ["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas",
                f"-I{_ROOT / 'jaxsim_amd' / 'csrc'}", f"-I{_HERE / 'emul'}", str(_SRC), "-o", str(_SO)]  # fmt: skip
+        cmd[1:1] = os.environ.get("JXS_EMUL_CXXFLAGS", "").split()  # developer aid, e.g. -DJXS_RIGID_DEBUG
         subprocess.run(cmd, check=True)
     return _SO
 

@@ -66,6 +66,26 @@ class ModelZoo:
         return d
 
 
+def standing_data(model, N, seed=0, dtype=np.float64, sink=2e-3, noise=0.03):
+    """States with (nearly) every bottom collidable point in contact: zero pose plus small noise, the
+    base lowered so that the lowest enabled points sit `sink` under the ground, small velocities."""
+    rng = np.random.default_rng(seed)
+    kdp = model.kin_dyn_parameters
+    n = kdp.number_of_joints()
+    s = noise * rng.uniform(-1, 1, size=(N, n))
+    rpy = 0.3 * noise * rng.uniform(-1, 1, size=(N, 3))
+    q = oracle.refmath.quaternion_from_euler_xyz(rpy)
+    d0 = oracle.OracleData.build(model, base_quaternion=q, joint_positions=s)
+    p, _ = oracle.refstep.collidable_points_pos_vel(model, link_transforms=d0.link_transforms, link_velocities=d0.link_velocities)
+    z = -p[:, :, 2].min(axis=1) - sink
+    pos = np.stack([rng.uniform(-1, 1, N), rng.uniform(-1, 1, N), z], axis=1)
+    return oracle.OracleData.build(
+        model, base_position=pos, base_quaternion=q, joint_positions=s, dtype=dtype,
+        base_linear_velocity=0.1 * rng.uniform(-1, 1, (N, 3)), base_angular_velocity=0.1 * rng.uniform(-1, 1, (N, 3)),
+        joint_velocities=0.2 * rng.uniform(-1, 1, (N, n)),
+    )
+
+
 def odata_to_block(model, d: oracle.OracleData, dtype=None) -> np.ndarray:
     L = st.StateLayout.of(model)
     return st.pack_state(

@@ -520,6 +520,27 @@ def test_relaxed_box_settles_known_answer_gpu(models, dtype):
     assert out[2, 0] == pytest.approx(0.05, abs=1e-4)
 
 
+@pytest.mark.parametrize("kind,name,idx,dtype,tol", [
+    ("relaxed", "icub", list(range(32)), np.float64, 1e-10),
+    ("relaxed", "icub", list(range(32)), np.float32, 2e-4),
+    ("relaxed", "anymal", helpers.ANYMAL_FEET_16, np.float32, 2e-4),
+    ("rigid", "icub", list(range(32)), np.float64, 1e-7),
+])  # fmt: skip
+def test_standing_on_every_sole_point_gpu(models, reduced_qp, kind, name, idx, dtype, tol):
+    """Standing states with all 16 bottom points of the feet in contact (rank <= 18 of 48); the 32-point
+    humanoid is BASELINE.json config 3's model with all its points enabled -- with RelaxedRigidContacts
+    the analogue of the reference's own test_simulation_step benchmark (tests/test_benchmark.py:142-152)."""
+    if kind == "relaxed":
+        model = helpers.relaxed_model(models(name), idx, mu=0.5)
+    else:
+        model = helpers.rigid_model(models(name), idx, K=1e4, D=1e2)
+    d = helpers.standing_data(model, 21, seed=5, dtype=dtype, noise=0.003)
+    ref = oracle.step(model, helpers.upcast(d))
+    out = js.model.step(model, to_gpu(model, d)).state_block()
+    assert out.dtype == dtype and np.isfinite(out).all()
+    assert helpers.rel_err(out, helpers.odata_to_block(model, ref)) < tol
+
+
 def test_relaxed_tumbling_box_rollout_gpu(models):
     model = helpers.relaxed_model(models("box"), [0, 1, 2, 3], mu=0.5)
     q = oracle.refmath.quaternion_from_euler_xyz(np.array([[0.3, 0.2, 0.1]]))

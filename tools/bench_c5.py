@@ -24,7 +24,8 @@ sys.path.insert(0, str(ROOT / "tests"))
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--points", type=int, default=4, choices=[4, 16])
+    ap.add_argument("--points", type=int, default=4, choices=[4, 16, 32])
+    ap.add_argument("--standing", action="store_true", help="standing states: every sole point in contact")
     ap.add_argument("--envs", type=int, default=4096)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
@@ -38,14 +39,19 @@ def main():
 
     runtime.require_device()
     zoo = helpers.ModelZoo()
-    idx = helpers.ANYMAL_FEET_4 if args.points == 4 else helpers.ANYMAL_FEET_16
+    # --points 32: the 24-link humanoid of config 3 with all its 32 collidable points enabled
+    robot = "icub" if args.points == 32 else "anymal"
+    idx = helpers.ANYMAL_FEET_4 if args.points == 4 else helpers.ANYMAL_FEET_16 if args.points == 16 else list(range(32))
     if args.contact == "rigid":
-        model = helpers.rigid_model(zoo("anymal"), idx, K=1e4, D=2e2)
+        model = helpers.rigid_model(zoo(robot), idx, K=1e4, D=2e2)
     else:
-        model = helpers.relaxed_model(zoo("anymal"), idx)
+        model = helpers.relaxed_model(zoo(robot), idx)
         model = helpers.with_params(model, contact_params=js.contact.estimate_good_contact_parameters(model))
     dtype = np.dtype(args.dtype)
-    d = zoo.random_data("anymal", args.envs, seed=0, dtype=dtype)
+    if args.standing:
+        d = helpers.standing_data(model, args.envs, seed=0, dtype=dtype, noise=0.003)
+    else:
+        d = zoo.random_data(robot, args.envs, seed=0, dtype=dtype)
     data = js.data.JaxSimModelData.from_state_block(model, helpers.odata_to_block(model, d), 2)
     dm = runtime.device_model(model, dtype)
     lib = _lib.load()
@@ -70,7 +76,7 @@ def main():
     blk = data.state_block()
     cname = "RigidContacts" if args.contact == "rigid" else "RelaxedRigidContacts"
     print(json.dumps({
-        "workload": f"config 5: anymal12 synthetic, {cname} ({args.points} points), gravity compensation, {args.dtype}",
+        "workload": f"config 5: {robot} synthetic{' (standing)' if args.standing else ''}, {cname} ({args.points} points), gravity compensation, {args.dtype}",
         "envs": args.envs, "steps": args.steps, "ms_per_step": ms, "env_steps_per_s": args.envs / (ms * 1e-3),
         "finite_envs": float(np.isfinite(blk).all(axis=0).mean()), "lanes_per_env": int(dm.layout.group),
     }))  # fmt: skip
