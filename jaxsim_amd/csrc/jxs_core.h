@@ -23,6 +23,7 @@
 //   RK4           api/integrators.py:91-167, api/ode.py:134-225 (MODE_STEP_RK4)
 //   S5 rigid contacts rbda/contacts/rigid.py:176-539 (MODE_STEP_RIGID, member functions in jxs_rigid.inc)
 #pragma once
+#include <limits>
 #include "jxs_params.h"
 
 namespace jxs {
@@ -38,6 +39,10 @@ struct Core {
   const KParams<T>& P;
   const KArgs<T>& A;
   const L& ln;
+  // rigid contact models: bit j set = point j is active in some environment of this wave (set by
+  // rigid_delassus; block columns of the other points are skipped by the factorisation and the solves)
+  mutable unsigned rg_amask_ = 0xffffffffu;
+  mutable VM rg_mine_;  // this lane's own point has its bit set
 
   JXS_HD Core(const KParams<T>& p, const KArgs<T>& a, const L& l) : P(p), A(a), ln(l) {}
 

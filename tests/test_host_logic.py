@@ -208,3 +208,31 @@ def test_model_reduction_locks_joints_and_lumps_links(models):
     np.testing.assert_array_equal(same.kin_dyn_parameters.parent_array, full.kin_dyn_parameters.parent_array)
     with pytest.raises(ValueError, match="not existing"):
         js.model.reduce(full, considered_joints=names + ["nope"])
+
+
+def test_relaxed_rigid_contacts_host_objects(models):
+    """``RelaxedRigidContacts.build`` / ``RelaxedRigidContactsParams`` mirror the reference
+    (relaxed_rigid.py:29-75,203-251): default L-BFGS option keys are kept, user options are merged,
+    unhashable option values are rejected; parameter validity follows ``valid()`` (:184-200)."""
+    import jaxsim_amd as ja
+    import jaxsim_amd.api as js
+
+    cm = ja.RelaxedRigidContacts.build()
+    assert cm.solver_options == {"tol": 1e-6, "maxiter": 50, "memory_size": 10, "scale_init_precond": False}
+    assert ja.RelaxedRigidContacts.build(solver_options={"tol": 1e-3}).solver_options["tol"] == 1e-3
+    with pytest.raises(ValueError, match="hashable"):
+        ja.RelaxedRigidContacts.build(solver_options={"tol": [1e-3]})
+    p = cm._parameters_class()
+    assert (p.time_constant, p.damping_coefficient, p.d_min, p.d_max, p.width, p.midpoint, p.power, p.mu) == (
+        0.02, 1.0, 0.9, 0.95, 0.001, 0.5, 2.0, 0.005)  # fmt: skip
+    assert p.valid() and not ja.RelaxedRigidContactsParams.build(d_min=0.99, d_max=0.95).valid()
+    assert not ja.RelaxedRigidContactsParams.build(damping_coefficient=0.0).valid()
+    # estimate_good_contact_parameters builds the parameter class of the active contact model
+    # (api/contact.py:203-211): stiffness / damping / friction go to K, D, mu
+    base = models("box")
+    soft = js.contact.estimate_good_contact_parameters(base)
+    for cm_, cls in ((ja.RelaxedRigidContacts.build(), ja.RelaxedRigidContactsParams), (ja.RigidContacts.build(), ja.RigidContactsParams)):
+        with base.editable(validate=False) as m:
+            m.contact_model = cm_
+        got = js.contact.estimate_good_contact_parameters(m)
+        assert type(got) is cls and got.mu == 0.5 and got.K == soft.K and got.D == soft.D

@@ -16,9 +16,19 @@ from jaxsim_amd import _lib, runtime  # noqa: E402
 
 pts = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+kind = sys.argv[3] if len(sys.argv) > 3 else "rigid"       # rigid | relaxed
+standing = len(sys.argv) > 4 and sys.argv[4] == "standing"
 zoo = helpers.ModelZoo()
-model = helpers.rigid_model(zoo("anymal"), helpers.ANYMAL_FEET_4 if pts == 4 else helpers.ANYMAL_FEET_16, K=1e4, D=2e2)
-d = zoo.random_data("anymal", N, seed=0, dtype=np.float32)
+robot = "icub" if pts == 32 else "anymal"
+idx = helpers.ANYMAL_FEET_4 if pts == 4 else helpers.ANYMAL_FEET_16 if pts == 16 else list(range(32))
+if kind == "rigid":
+    model = helpers.rigid_model(zoo(robot), idx, K=1e4, D=2e2)
+else:
+    model = helpers.relaxed_model(zoo(robot), idx, mu=0.5)
+if standing:
+    d = helpers.standing_data(model, N, seed=0, dtype=np.float32, noise=0.003)
+else:
+    d = zoo.random_data(robot, N, seed=0, dtype=np.float32)
 data = js.data.JaxSimModelData.from_state_block(model, helpers.odata_to_block(model, d), 2)
 lib = _lib.load()
 dm = runtime.device_model(model, np.float32)
@@ -35,6 +45,18 @@ lib.jxs_step(dm.handle, ptr, ptr, None, None, 2, N, None)
 runtime.synchronize()
 out = np.zeros((blocks, 16), dtype=np.int64)
 lib.jxs_memcpy_d2h(out.ctypes.data_as(C.c_void_p), buf, out.nbytes, None)
+if kind == "relaxed":
+    has = (out[:, 11] > 0) & (out[:, 13] > 0)
+    o = out[has]
+    tot = o[:, 10] - o[:, 0]
+    print(f"points={pts} N={N} relaxed{' standing' if standing else ''}: {blocks} waves, {has.sum()} with contacts")
+    print("  total                 %9.0f (max %d)" % (tot.mean(), tot.max()))
+    print("  delassus              %9.0f" % (o[:, 12] - o[:, 11]).mean())
+    print("  regulariser+H+cholesky%9.0f" % (o[:, 14] - o[:, 12]).mean())
+    print("  first solve           %9.0f" % (o[:, 15] - o[:, 14]).mean())
+    print("  refinement            %9.0f" % (o[:, 13] - o[:, 15]).mean())
+    print("  everything else       %9.0f" % (tot - (o[:, 13] - o[:, 11])).mean())
+    sys.exit(0)
 has = (out[:, 11] > 0) & (out[:, 14] > 0)
 print(f"points={pts} N={N}: {blocks} waves, {has.sum()} with contacts in both stages")
 o = out[has]
