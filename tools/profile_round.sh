@@ -1,0 +1,24 @@
+#!/usr/bin/env bash
+# Collect the rocprofv3 evidence of one round on the GPU box (run from the repo root through gpurun):
+#   tools/profile_round.sh <run-name>      -> gpurun_out/<run-name>/{stats,pmc_*,c5,...}
+# then, back in the container:  python tools/summarize_profiles.py gpurun_out/<run-name> r01
+# Counter passes are separate runs (`--pmc` is never combined with sys/hip/hsa tracing).
+set -u
+R=$PWD
+OUT=$R/gpurun_out/$1
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+B="python $R/bench.py --steps 500 --warmup 20 --no-cpu-baseline --saturated-envs 0"
+rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/stats" -- $B > "$OUT/bench.log" 2>&1
+rocprofv3 --output-format csv --kernel-trace --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -- $B > "$OUT/pmc_fetch.log" 2>&1
+rocprofv3 --output-format csv --kernel-trace --pmc WRITE_SIZE -d "$OUT/pmc_write" -- $B > "$OUT/pmc_write.log" 2>&1
+rocprofv3 --output-format csv --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY \
+  -d "$OUT/pmc_sq" -- $B > "$OUT/pmc_sq.log" 2>&1
+rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/c5" -- python "$R/tools/bench_c5.py" > "$OUT/c5.log" 2>&1
+rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/c5_relaxed" -- python "$R/tools/bench_c5.py" --contact relaxed --points 16 > "$OUT/c5_relaxed.log" 2>&1
+cd "$R"
+python bench.py > "$OUT/bench_N1.json" 2> "$OUT/bench_N1.err"
+if [ -f jaxsim_amd/csrc/libjaxsim_amd_timing.so ]; then
+  JAXSIM_AMD_LIB=$R/jaxsim_amd/csrc/libjaxsim_amd_timing.so python tools/phase_timing.py > "$OUT/phases.log" 2>&1
+fi
+tail -c 600 "$OUT/bench_N1.json"
