@@ -2,4 +2,4 @@
 then ``js.model.step(model, data)``, ``js.data.JaxSimModelData.build(...)``,
 ``js.contact.estimate_good_contact_parameters(...)``."""
 
-from . import contact, data, model  # noqa: F401
+from . import contact, data, model, references  # noqa: F401

@@ -582,6 +582,32 @@ def test_gpu_golden_relaxed(models, name):
     assert helpers.rel_err(out.state_block(), g["step"]) < 1e-10
 
 
+@pytest.mark.parametrize("rep", [VelRepr.Inertial, VelRepr.Mixed, VelRepr.Body])
+def test_step_with_references_object(models, rep):
+    """The reference's user flow (README-style loops, api/references.py:23-449): forces are put into a
+    ``JaxSimModelReferences`` in the representation of the data, accumulated by link name, read back with
+    ``references.link_forces(model, data)`` and handed to ``step``."""
+    model = models("anymal")
+    N = 9
+    d = models.random_data("anymal", N, seed=4, rep=rep)
+    g = to_gpu(model, d)
+    assert g.velocity_representation == REP[rep]
+    tau, f = helpers.random_inputs(model, N, 8, np.float64)
+    refs = js.references.JaxSimModelReferences.zero(model, data=g, velocity_representation=g.velocity_representation)
+    refs = refs.set_joint_force_references(tau, model=model)
+    names = model.link_names()
+    refs = refs.apply_link_forces(f[:, :5], model=model, data=g, link_names=names[:5])
+    refs = refs.apply_link_forces(0.25 * f[:, 5:], model=model, data=g, link_names=names[5:], additive=True)
+    refs = refs.apply_link_forces(0.75 * f[:, 5:], model=model, data=g, link_names=names[5:], additive=True)
+    np.testing.assert_allclose(refs.link_forces(model, g), f, atol=1e-10)
+    # stored inertial-fixed: the oracle's conversion with the oracle's link transforms
+    np.testing.assert_allclose(
+        refs._link_forces, oracle.refstep.other_representation_to_inertial(f, rep, d.link_transforms, is_force=True), atol=1e-9)  # fmt: skip
+    out = js.model.step(model, g, link_forces=refs.link_forces(model, g), joint_force_references=refs.joint_force_references(model))
+    ref = oracle.step(model, d, link_forces=f, joint_force_references=tau)
+    assert helpers.rel_err(out.state_block(), helpers.odata_to_block(model, ref)) < helpers.FP64_TOL
+
+
 @pytest.mark.parametrize("name", ["cartpole", "chain9f", "icub"])
 def test_gpu_golden_rk4(models, name):
     import test_golden as tg

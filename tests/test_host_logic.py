@@ -236,3 +236,93 @@ def test_relaxed_rigid_contacts_host_objects(models):
             m.contact_model = cm_
         got = js.contact.estimate_good_contact_parameters(m)
         assert type(got) is cls and got.mu == 0.5 and got.K == soft.K and got.D == soft.D
+
+
+class _FakeData:
+    """Stands in for JaxSimModelData where only the cached link transforms matter (no GPU)."""
+
+    def __init__(self, W_H_L, rep, batched=True):
+        self._link_transforms, self.velocity_representation, self._batched = W_H_L, rep, batched
+        self.batch_size = W_H_L.shape[0] if batched else 1
+
+    def valid(self, model=None):
+        return True
+
+
+def _random_transforms(rng, N, nL):
+    from oracle import refmath
+
+    H = np.zeros((N, nL, 4, 4))
+    q = rng.normal(size=(N * nL, 4))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    H[:, :, :3, :3] = refmath.so3_from_quaternion(q).reshape(N, nL, 3, 3)
+    H[:, :, :3, 3] = rng.normal(size=(N, nL, 3))
+    H[:, :, 3, 3] = 1
+    return H
+
+
+@pytest.mark.parametrize("rep", ["inertial", "mixed", "body"])
+def test_references_store_inertial_and_convert_back(models, rep):
+    """``JaxSimModelReferences`` (references.py:23-449): link forces are stored inertial-fixed and read
+    back in the active representation; conversion = ``other_representation_to_inertial`` with the link
+    transforms (api/common.py:160-222), checked against the oracle's restatement."""
+    import jaxsim_amd as ja
+    import jaxsim_amd.api as js
+    from oracle import refstep
+
+    model = models("anymal")
+    nL, n, N = model.number_of_links(), model.dofs(), 5
+    rng = np.random.default_rng(3)
+    W_H_L = _random_transforms(rng, N, nL)
+    vr = {"inertial": ja.VelRepr.Inertial, "mixed": ja.VelRepr.Mixed, "body": ja.VelRepr.Body}[rep]
+    data = _FakeData(W_H_L, vr)
+    f = rng.normal(size=(N, nL, 6))
+    tau = rng.normal(size=(N, n))
+    refs = js.references.JaxSimModelReferences.build(model, joint_force_references=tau, link_forces=f, data=data)
+    assert refs.velocity_representation == vr and refs.valid(model)
+    expect = refstep.other_representation_to_inertial(f, rep, W_H_L, is_force=True)
+    np.testing.assert_allclose(refs._link_forces, expect, atol=1e-12)
+    np.testing.assert_allclose(refs.link_forces(model, data), f, atol=1e-12)
+    np.testing.assert_array_equal(refs.joint_force_references(model), tau)
+    # by name, additive, and a different read-out representation
+    names = (model.link_names()[3], model.link_names()[0])
+    extra = rng.normal(size=(N, 2, 6))
+    r2 = refs.apply_link_forces(extra, model=model, data=data, link_names=names, additive=True)
+    got = r2.link_forces(model, data, link_names=names)
+    np.testing.assert_allclose(got, f[:, [3, 0]] + extra, atol=1e-12)
+    r3 = refs.apply_link_forces(extra, model=model, data=data, link_names=names, additive=False)
+    np.testing.assert_allclose(r3.link_forces(model, data, link_names=names), extra, atol=1e-12)
+    untouched = [i for i in range(nL) if i not in (0, 3)]
+    np.testing.assert_allclose(r3.link_forces(model, data)[:, untouched], f[:, untouched], atol=1e-12)
+    as_inertial = r3.switch_velocity_representation(ja.VelRepr.Inertial).link_forces(model)
+    np.testing.assert_allclose(as_inertial, r3._link_forces, atol=0)
+    jn = (model.joint_names()[4], model.joint_names()[1])
+    r4 = refs.set_joint_force_references(np.ones((N, 2)), model=model, joint_names=jn)
+    np.testing.assert_array_equal(r4.joint_force_references(model, joint_names=jn), np.ones((N, 2)))
+
+
+def test_references_error_behaviour(models):
+    """Same errors as the reference (references.py:205-215, 371-395)."""
+    import jaxsim_amd as ja
+    import jaxsim_amd.api as js
+
+    model = models("box")
+    R = js.references.JaxSimModelReferences
+    z = R.zero(model)
+    assert z._link_forces.shape == (1, 6) and z._joint_force_references.shape == (0,)
+    with pytest.raises(ValueError, match="without a model"):
+        z.link_forces(link_names=("box",))
+    mixed = z.switch_velocity_representation(ja.VelRepr.Mixed)
+    with pytest.raises(ValueError, match="Missing model "):
+        mixed.link_forces()
+    with pytest.raises(ValueError, match="Missing model data"):
+        mixed.link_forces(model)
+    with pytest.raises(ValueError, match="must match"):
+        z.apply_link_forces(np.zeros((2, 6)), model=model, link_names=model.link_names())
+    with pytest.raises(ValueError, match="unknown link"):
+        z.apply_link_forces(np.zeros((1, 6)), model=model, link_names=("nope",))
+    with pytest.raises(ValueError, match="expected joint forces"):
+        R.build(model, link_forces=np.zeros((3, 6)))
+    # no-model path: inertial forces for all links, additive or not
+    a = z.apply_link_forces(np.ones((1, 6)))
+    np.testing.assert_array_equal(a.apply_link_forces(np.ones((1, 6)), additive=True)._link_forces, 2 * np.ones((1, 6)))
