@@ -58,6 +58,7 @@ def parse_args():
     ap.add_argument("--force-dist", action="store_true", help="developer: run the multi-rank code path even with WORLD_SIZE=1")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=10.0)
     ap.add_argument("--saturated-envs", type=int, default=65536, help="secondary figure: batch that saturates one GPU (0 = skip)")
+    ap.add_argument("--no-other-contact-models", action="store_true", help="skip the secondary RigidContacts / RelaxedRigidContacts figures")
     return ap.parse_args()
 
 
@@ -117,6 +118,75 @@ def synthetic_state(model, n_envs, seed, dtype):
         p[:, 2] += 0.005 - pz.min(axis=1)
         data = data.replace(model, base_position=p)
     return data
+
+
+def other_contact_models(dtype, stream, steps=200, warmup=20):
+    """Secondary figures (never `value`): the two other contact models of the step path on one GPU.
+
+    * BASELINE.json configs[4]: quadruped, RigidContacts (one point per foot), tau = RNEA gravity term
+      recomputed on the device every step, batch 4096;
+    * the reference's own `test_simulation_step` benchmark idiom (tests/test_benchmark.py:142-152):
+      RelaxedRigidContacts + `estimate_good_contact_parameters` on the humanoid with all 32 points, batch 1024.
+    """
+    import ctypes as C
+    import dataclasses
+
+    import jaxsim_amd as ja
+    import jaxsim_amd.api as js
+    from jaxsim_amd import _lib, robots, runtime
+
+    lib = _lib.load()
+    out = {}
+
+    def timed(model, n_envs, seed, with_tau):
+        data = synthetic_state(model, n_envs, seed=seed, dtype=dtype)
+        dm = runtime.device_model(model, dtype)
+        st = C.c_void_p(data._state.ptr)
+        tau = runtime.DeviceArray(model.dofs(), n_envs, dtype, tile=data._state.tile, zero=True)
+        tp = C.c_void_p(tau.ptr)
+
+        def run(k):
+            for _ in range(k):
+                if with_tau:
+                    _lib.check(lib.jxs_gravity_torques(dm.handle, st, tp, n_envs, stream.handle), "jxs_gravity_torques")
+                _lib.check(lib.jxs_step(dm.handle, st, st, tp if with_tau else None, None, 2, n_envs, stream.handle), "jxs_step")
+
+        run(warmup)
+        stream.synchronize()
+        e0, e1 = runtime.Event(), runtime.Event()
+        e0.record(stream)
+        run(steps)
+        e1.record(stream)
+        stream.synchronize()
+        us = e0.elapsed_ms(e1) / steps * 1e3
+        finite = float(np.isfinite(data.state_block()).all(axis=0).mean())
+        return {"envs": n_envs, "steps": steps, "us_per_step": us, "env_steps_per_s": n_envs / (us * 1e-6), "finite_envs": finite}
+
+    def enable(model, idx):
+        kdp = model.kin_dyn_parameters
+        en = np.zeros(kdp.number_of_collidable_points(), dtype=bool)
+        en[list(idx)] = True
+        model.kin_dyn_parameters = dataclasses.replace(kdp, contact_enabled=en)
+
+    try:
+        quad = ja.JaxSimModel.build_from_model_description(robots.anymal12_urdf())
+        enable(quad, [0, 8, 16, 24])  # one bottom corner of every foot box
+        quad.contact_model = ja.RigidContacts.build()
+        quad.contact_params = ja.RigidContactsParams(K=1e4, D=2e2)
+        out["config5_rigid_contacts"] = timed(quad, 4096, 100, True) | {
+            "workload": "anymal12 synthetic, RigidContacts (4 points), tau = RNEA gravity term every step (jxs_gravity_torques + jxs_step)"}  # fmt: skip
+    except Exception as e:
+        out["config5_rigid_contacts"] = {"error": repr(e)}
+    try:
+        hum = ja.JaxSimModel.build_from_model_description(robots.icub23_urdf(sole_boxes_per_foot=2))
+        hum.contact_model = ja.RelaxedRigidContacts.build()
+        hum.contact_params = js.contact.estimate_good_contact_parameters(hum)
+        out["relaxed_rigid_contacts"] = timed(hum, 1024, 200, False) | {
+            "workload": "icub23 synthetic, all 32 collidable points, RelaxedRigidContacts with estimate_good_contact_parameters (jxs_step)"}  # fmt: skip
+    except Exception as e:
+        out["relaxed_rigid_contacts"] = {"error": repr(e)}
+    out["note"] = "secondary figures, not `value`; DESIGN.md sections 4d, 4e, 6"
+    return out
 
 
 def cpu_baseline(model, block, budget_s):
@@ -356,6 +426,8 @@ def main():
                 saturated["fp32_frac_of_vector_peak"] = FLOPS_PER_ENV_STEP * saturated["env_steps_per_s"] / 1e12 / FP32_PEAK_TFLOPS
                 saturated["note"] = "same step kernel, one GPU filled; secondary figure, not `value`"
             out["saturated"] = saturated
+        if world == 1 and not args.no_other_contact_models:
+            out["other_contact_models"] = other_contact_models(dtype, stream)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(model, initial_block, args.cpu_baseline_seconds)
