@@ -742,15 +742,15 @@ def test_step_repeat_graph_equals_single_launches(models):
     model = models("icub")
     d = models.random_data("icub", 50, seed=70, dtype=np.float32)
     ref = to_gpu(model, d)
-    for _ in range(3 * 57):
+    for _ in range(2 * 57 + 307):
         ref = js.model.step(model, ref)
     lib, dm = _lib.load(), runtime.device_model(model, np.float32)
     stream = runtime.Stream()
     for trial in range(2):  # second trial: a new state buffer -> the graph is re-captured
         g = to_gpu(model, d)
         runtime.synchronize()
-        for _ in range(3):  # each call: one replay of the 50-launch graph + 7 plain launches
-            _lib.check(lib.jxs_step_repeat(dm.handle, C.c_void_p(g._state.ptr), None, None, 2, 50, 57, stream.handle), "repeat")
+        for n in (57, 307, 57):  # 50-launch graph + 7 plain launches; 250-launch graph + 50-launch graph + 7
+            _lib.check(lib.jxs_step_repeat(dm.handle, C.c_void_p(g._state.ptr), None, None, 2, 50, n, stream.handle), "repeat")
         stream.synchronize()
         np.testing.assert_array_equal(g.state_block(), ref.state_block())
 
