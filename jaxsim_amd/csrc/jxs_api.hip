@@ -59,7 +59,7 @@ __global__ __launch_bounds__(64) void jxs_kernel(const T* pre_state_in, const T*
   P.row_m = 13 + 2 * pre_n;  // the state-block rows of SURVEY section 8(a) row D, derived instead of loaded
   extern __shared__ __align__(16) unsigned char jxs_smem[];
   const jxs::DeviceLanes<T, G> ln(A.N, reinterpret_cast<T*>(jxs_smem),
-                                  MODE == jxs::MODE_STEP_RIGID ? jxs::rigid_lds_words_per_env(P.n_cp)
+                                  MODE == jxs::MODE_STEP_RIGID ? jxs::rigid_lds_words_per_env(P.n_cp, P.rigid)
                                                                : jxs::lds_words_per_env(G));
   jxs::Core<jxs::DeviceLanes<T, G>> core(P, A, ln);
   core.template run<MODE>();
@@ -83,7 +83,7 @@ hipError_t launch_one(const jxs::KParams<T>& P, const jxs::KArgs<T>& A, hipStrea
                                    MODE == jxs::MODE_STEP_RK4);
   size_t lds_bytes = rows ? sizeof(T) * (size_t)envs_per_wave * jxs::lds_words_per_env(G) : 0;
   if (MODE == jxs::MODE_STEP_RIGID) {
-    lds_bytes = sizeof(T) * (size_t)envs_per_wave * jxs::rigid_lds_words_per_env(P.n_cp);
+    lds_bytes = sizeof(T) * (size_t)envs_per_wave * jxs::rigid_lds_words_per_env(P.n_cp, P.rigid);
     if (lds_bytes > 64 * 1024) {  // beyond the default dynamic-LDS window (gfx950 has 160 KiB per CU)
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&jxs_kernel<T, G, MODE>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);

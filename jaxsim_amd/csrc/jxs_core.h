@@ -43,6 +43,7 @@ struct Core {
   // rigid_delassus; block columns of the other points are skipped by the factorisation and the solves)
   mutable unsigned rg_amask_ = 0xffffffffu;
   mutable VM rg_mine_;  // this lane's own point has its bit set
+  mutable int rg_hoff_ = 0;  // LDS word offset of the working matrix H: behind Q, or Q itself (relaxed model)
 
   JXS_HD Core(const KParams<T>& p, const KArgs<T>& a, const L& l) : P(p), A(a), ln(l) {}
 

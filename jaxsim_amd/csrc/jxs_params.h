@@ -86,7 +86,10 @@ enum RowLds : int { RL_M = 0, RL_S = 36, RL_C = 42, RL_PA = 48, RL_TAU = 54, RL_
 JXS_HD constexpr int lds_kin_offset(int G) { return G * kRowRec + 48; }  // link kinematics for the contact phase: [G][18]
 JXS_HD constexpr int lds_words_per_env(int G) { return lds_kin_offset(G) + 18 * G; }  // records + base rows (42) + pad + kinematics
 // rigid modes: Q and H packed lower triangles of order 3 n_cp + one exchange vector (jxs_rigid.inc)
-JXS_HD constexpr int rigid_lds_words_per_env(int n_cp) { return 3 * n_cp * (3 * n_cp + 1) + 3 * n_cp + 8; }
+// RelaxedRigidContacts (rigid == 2) factorises in place of the Delassus matrix: one triangle
+JXS_HD constexpr int rigid_lds_words_per_env(int n_cp, int rigid = 1) {
+  return (rigid == 2 ? 1 : 2) * ((3 * n_cp * (3 * n_cp + 1)) / 2) + 3 * n_cp + 8;
+}
 constexpr int kQpMaxIter = 30;    // interior-point iterations (oracle/refrigid.py QP_MAX_ITER)
 constexpr int kRigidMaxPoints = 32;
 constexpr int kImpactCgIters = 5;  // preconditioned CG iterations of the impact solve (jxs_rigid.inc)

@@ -27,7 +27,7 @@ void run_group(const jxs::Packed<T>& pk, jxs::KArgs<T> a, int mode) {
   a.head = pk.head.data();
   a.rti = pk.rti.data();
   for (int env = 0; env < a.N; ++env) {
-    jxs::HostLanes<T, G> ln(a.N, env, (size_t)std::max(jxs::rigid_lds_words_per_env(pk.P.n_cp), jxs::lds_words_per_env(G)));
+    jxs::HostLanes<T, G> ln(a.N, env, (size_t)std::max(jxs::rigid_lds_words_per_env(pk.P.n_cp, pk.P.rigid), jxs::lds_words_per_env(G)));
     jxs::Core<jxs::HostLanes<T, G>> core(pk.P, a, ln);
     switch (mode) {
       case jxs::MODE_STEP: core.template run<jxs::MODE_STEP>(); break;
