@@ -59,7 +59,7 @@ __global__ __launch_bounds__(64) void jxs_kernel(const T* pre_state_in, const T*
   P.row_m = 13 + 2 * pre_n;  // the state-block rows of SURVEY section 8(a) row D, derived instead of loaded
   extern __shared__ __align__(16) unsigned char jxs_smem[];
   const jxs::DeviceLanes<T, G> ln(A.N, reinterpret_cast<T*>(jxs_smem),
-                                  MODE == jxs::MODE_STEP_RIGID ? jxs::rigid_lds_words_per_env(P.n_cp, P.rigid)
+                                  (MODE == jxs::MODE_STEP_RIGID || MODE == jxs::MODE_STEP_RK4_RIGID) ? jxs::rigid_lds_words_per_env(P.n_cp, P.rigid)
                                                                : jxs::lds_words_per_env(G));
   jxs::Core<jxs::DeviceLanes<T, G>> core(P, A, ln);
   core.template run<MODE>();
@@ -82,7 +82,7 @@ hipError_t launch_one(const jxs::KParams<T>& P, const jxs::KArgs<T>& A, hipStrea
   const bool rows = P.row_mode && (MODE == jxs::MODE_STEP || MODE == jxs::MODE_ROLLOUT || MODE == jxs::MODE_FD ||
                                    MODE == jxs::MODE_STEP_RK4);
   size_t lds_bytes = rows ? sizeof(T) * (size_t)envs_per_wave * jxs::lds_words_per_env(G) : 0;
-  if (MODE == jxs::MODE_STEP_RIGID) {
+  if (MODE == jxs::MODE_STEP_RIGID || MODE == jxs::MODE_STEP_RK4_RIGID) {
     lds_bytes = sizeof(T) * (size_t)envs_per_wave * jxs::rigid_lds_words_per_env(P.n_cp, P.rigid);
     if (lds_bytes > 64 * 1024) {  // beyond the default dynamic-LDS window (gfx950 has 160 KiB per CU)
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&jxs_kernel<T, G, MODE>),
@@ -115,6 +115,7 @@ hipError_t launch_mode(int mode, int G, const jxs::KParams<T>& P, const jxs::KAr
     case jxs::MODE_ROLLOUT: return launch_g<T, jxs::MODE_ROLLOUT>(G, P, A, s);
     case jxs::MODE_STEP_RK4: return launch_g<T, jxs::MODE_STEP_RK4>(G, P, A, s);
     case jxs::MODE_STEP_RIGID: return launch_g<T, jxs::MODE_STEP_RIGID>(G, P, A, s);
+    case jxs::MODE_STEP_RK4_RIGID: return launch_g<T, jxs::MODE_STEP_RK4_RIGID>(G, P, A, s);
     default: return launch_g<T, jxs::MODE_KIN>(G, P, A, s);
   }
 }
@@ -220,7 +221,8 @@ int run_typed(jxs_model* model, int mode, const void* state_in, void* state_out,
   a.id_zero_vel = out_tau != nullptr ? 1 : 0;
   a.n_steps = 1;
   if (mode == jxs::MODE_STEP && mt->pk.integrator == JXS_INTEGRATOR_RUNGE_KUTTA4) {
-    mode = jxs::MODE_STEP_RK4;  // four dynamics evaluations per launch; a rollout is one launch per step
+    // four dynamics evaluations per launch; a rollout is one launch per step
+    mode = mt->pk.P.rigid ? jxs::MODE_STEP_RK4_RIGID : jxs::MODE_STEP_RK4;
   }
   if (mode == jxs::MODE_STEP && mt->pk.P.rigid) mode = jxs::MODE_STEP_RIGID;  // QP contacts + impact, one launch per step
   if (fuse && mode == jxs::MODE_STEP && repeat > 1 && mt->pk.P.n_chunks <= 1) {

@@ -72,8 +72,8 @@ struct Core {
   // ==========================================================================================
   template <int MODE>
   JXS_HD void run() {
-    constexpr bool kRK4 = (MODE == MODE_STEP_RK4);
-    constexpr bool kRigid = (MODE == MODE_STEP_RIGID);
+    constexpr bool kRK4 = (MODE == MODE_STEP_RK4 || MODE == MODE_STEP_RK4_RIGID);
+    constexpr bool kRigid = (MODE == MODE_STEP_RIGID || MODE == MODE_STEP_RK4_RIGID);
     constexpr bool kStep = (MODE == MODE_STEP || MODE == MODE_ROLLOUT || kRK4 || kRigid);
     const VI lane = ln.lane();
     ln.stamp(A, 0);
@@ -210,7 +210,7 @@ struct Core {
     }
 #pragma unroll
     for (int stage = 0; stage < n_stages; ++stage) {
-    if (kRigid && stage == 1 && P.rigid == 2) break;  // RelaxedRigidContacts: no velocity reset (relaxed_rigid.py:265-281)
+    if (kRigid && !kRK4 && stage == 1 && P.rigid == 2) break;  // RelaxedRigidContacts: no velocity reset (relaxed_rigid.py:265-281)
     // ---- base rotation: DCM of q/|q| (data.base_orientation, api/data.py:267-286) --------
     V R[9], r[3];
     {
@@ -694,10 +694,11 @@ struct Core {
         RigidPoints rp;
         rigid_points(ps0, R, r, vl, va, pB, rp);
         const VI zero_lane = lane * 0;
-        if (stage == 0) {
-          // contact forces of the QP, then nudot = nudot_free + M^-1 J^T f  (api/ode.py:57-131)
+        if (kRK4 || stage == 0) {
+          // contact forces of the QP, then nudot = nudot_free + M^-1 J^T f  (api/ode.py:57-131); with
+          // RungeKutta4 (relaxed model only) at every stage, as system_dynamics is (api/ode.py:174-225)
           V fpt[3];
-          if (P.rigid == 2)
+          if (kRK4 || P.rigid == 2)
             relaxed_contact_forces(lane, level, parent, child, tf, ps0, rp, a6, mass, fpt);
           else
             rigid_contact_forces(lane, level, parent, child, tf, ps0, rp, a6, fpt);
@@ -747,7 +748,7 @@ struct Core {
       return;
     }
 
-    if (kRigid && stage == 1) {
+    if (kRigid && !kRK4 && stage == 1) {
       // impact stage: the velocities were reset above, nothing to integrate
     } else if (!kRK4) {
     // ---- C: semi-implicit Euler (api/integrators.py:14-88) ---------------------------------

@@ -101,7 +101,8 @@ enum Mode : int {
   MODE_KIN = 3,   // cached kinematics of JaxSimModelData  api/data.py:405-523
   MODE_ROLLOUT = 4,  // MODE_STEP repeated KArgs::n_steps times in one launch (state in registers)
   MODE_STEP_RK4 = 5,  // js.model.step with IntegratorType.RungeKutta4  api/integrators.py:91-167
-  MODE_STEP_RIGID = 6  // js.model.step with the RigidContacts model    rbda/contacts/rigid.py:176-539
+  MODE_STEP_RIGID = 6,  // js.model.step with the RigidContacts / RelaxedRigidContacts model  rbda/contacts/rigid.py:176-539
+  MODE_STEP_RK4_RIGID = 7  // RungeKutta4 with RelaxedRigidContacts (contact forces solved at every stage)
 };
 
 enum ForceRepr : int { REPR_INERTIAL = 0, REPR_BODY = 1, REPR_MIXED = 2 };  // api/common.py:39-47

@@ -36,6 +36,7 @@ void run_group(const jxs::Packed<T>& pk, jxs::KArgs<T> a, int mode) {
       case jxs::MODE_ROLLOUT: core.template run<jxs::MODE_ROLLOUT>(); break;
       case jxs::MODE_STEP_RK4: core.template run<jxs::MODE_STEP_RK4>(); break;
       case jxs::MODE_STEP_RIGID: core.template run<jxs::MODE_STEP_RIGID>(); break;
+      case jxs::MODE_STEP_RK4_RIGID: core.template run<jxs::MODE_STEP_RK4_RIGID>(); break;
       default: core.template run<jxs::MODE_KIN>(); break;
     }
   }
@@ -71,7 +72,7 @@ int run_typed(const jxs_model_desc* d, int mode, const void* state_in, void* sta
   }
   int launches = 1;
   const bool rk4 = (mode == jxs::MODE_STEP && pk.integrator == JXS_INTEGRATOR_RUNGE_KUTTA4);
-  if (rk4) mode = jxs::MODE_STEP_RK4;
+  if (rk4) mode = pk.P.rigid ? jxs::MODE_STEP_RK4_RIGID : jxs::MODE_STEP_RK4;
   const bool rigid = (mode == jxs::MODE_STEP && pk.P.rigid);
   if (rigid) mode = jxs::MODE_STEP_RIGID;
   if ((rk4 || rigid) && n_steps > 1) {

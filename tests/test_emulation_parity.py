@@ -556,8 +556,36 @@ def test_relaxed_unsupported_configurations_are_rejected(models):
         eb.layout(helpers.relaxed_model(models("sphere"), list(range(50))))
     with pytest.raises(RuntimeError, match="RelaxedRigidContactsParams"):
         eb.layout(helpers.relaxed_model(models("box"), [0, 1, 2, 3], time_constant=0.0))
-    with pytest.raises(RuntimeError, match="SemiImplicitEuler"):
-        eb.layout(helpers.with_params(helpers.relaxed_model(models("box"), [0, 1, 2, 3]), integrator=ja.IntegratorType.RungeKutta4))
+
+
+@pytest.mark.parametrize("key", ["box8", "anymal16", "chain9f6", "icub16"])
+def test_relaxed_rk4_step_matches_oracle(models, key):
+    """RungeKutta4 with RelaxedRigidContacts: the contact forces are solved at each of the four stages
+    (api/integrators.py:91-167 calls system_dynamics -> system_acceleration -> link_contact_forces per
+    stage); the reference runs its relaxed-rigid test for every integrator (tests/test_simulations.py:295)."""
+    import jaxsim_amd as ja
+
+    model, d = _relaxed_case(models, key, 8, seed=5)
+    model = helpers.with_params(model, integrator=ja.IntegratorType.RungeKutta4)
+    tau, f = helpers.random_inputs(model, 8, 7, np.float64)
+    ref = oracle.step(model, d, link_forces=f, joint_force_references=tau)
+    euler = oracle.step(helpers.with_params(model, integrator=ja.IntegratorType.SemiImplicitEuler), d, link_forces=f, joint_force_references=tau)
+    out = eb.run(model, eb.MODE_STEP, helpers.odata_to_block(model, d), tau=tau.T, link_forces=f.reshape(8, -1).T, force_repr=2)
+    assert helpers.rel_err(out, helpers.odata_to_block(model, ref)) < 1e-10
+    assert helpers.rel_err(helpers.odata_to_block(model, euler), helpers.odata_to_block(model, ref)) > 1e-6  # a different integrator
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_relaxed_rk4_box_settles_known_answer(models, dtype):
+    """reference tests/test_simulations.py:295-346 with integrator = RungeKutta4."""
+    import jaxsim_amd as ja
+
+    model = helpers.relaxed_model(models("box"), [0, 1, 2, 3], build=dict(solver_options={"tol": 1e-3}))
+    model = helpers.with_params(model, integrator=ja.IntegratorType.RungeKutta4)
+    d = oracle.OracleData.build(model, base_position=[0.0, 0.0, 0.2], velocity_representation=VelRepr.Inertial)
+    out = eb.run(model, eb.MODE_STEP, helpers.odata_to_block(model, d).astype(dtype), n_steps=1000)
+    assert abs(out[0, 0]) < 1e-5 and abs(out[1, 0]) < 1e-5
+    assert out[2, 0] == pytest.approx(0.05, abs=1e-4)
 
 
 def test_rigid_unsupported_configurations_are_rejected(models):

@@ -541,6 +541,35 @@ def test_standing_on_every_sole_point_gpu(models, reduced_qp, kind, name, idx, d
     assert helpers.rel_err(out, helpers.odata_to_block(model, ref)) < tol
 
 
+@pytest.mark.parametrize("key", ["box8", "anymal16", "chain9f6", "icub16"])
+def test_relaxed_rk4_step_matches_oracle_gpu(models, key):
+    """RungeKutta4 with RelaxedRigidContacts (contact forces solved at each stage); the reference runs
+    its relaxed-rigid test for every integrator (tests/test_simulations.py:295)."""
+    name, idx, params = RELAXED_CASES[key]
+    model = helpers.with_params(helpers.relaxed_model(models(name), idx, **params), integrator=ja.IntegratorType.RungeKutta4)
+    N = 21
+    d = models.random_data(name, N, seed=5)
+    tau, f = helpers.random_inputs(model, N, 7, np.float64)
+    ref = oracle.step(model, d, link_forces=f, joint_force_references=tau)
+    out = js.model.step(model, to_gpu(model, d), link_forces=f, joint_force_references=tau)
+    assert helpers.rel_err(out.state_block(), helpers.odata_to_block(model, ref)) < 1e-10
+    d32 = models.random_data(name, N, seed=5, dtype=np.float32)
+    out32 = js.model.step(model, to_gpu(model, d32)).state_block()
+    ref32 = oracle.step(model, helpers.upcast(d32))
+    assert out32.dtype == np.float32 and helpers.rel_err(out32, helpers.odata_to_block(model, ref32)) < 5e-4
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_relaxed_rk4_box_settles_known_answer_gpu(models, dtype):
+    """reference tests/test_simulations.py:295-346 with integrator = RungeKutta4."""
+    model = helpers.relaxed_model(models("box"), [0, 1, 2, 3], build=dict(solver_options={"tol": 1e-3}))
+    model = helpers.with_params(model, integrator=ja.IntegratorType.RungeKutta4)
+    d = oracle.OracleData.build(model, base_position=[0.0, 0.0, 0.2], velocity_representation=VelRepr.Inertial, dtype=dtype)
+    out = js.model.rollout(model, to_gpu(model, d), 1000).state_block()
+    assert abs(out[0, 0]) < 1e-5 and abs(out[1, 0]) < 1e-5
+    assert out[2, 0] == pytest.approx(0.05, abs=1e-4)
+
+
 def test_relaxed_tumbling_box_rollout_gpu(models):
     model = helpers.relaxed_model(models("box"), [0, 1, 2, 3], mu=0.5)
     q = oracle.refmath.quaternion_from_euler_xyz(np.array([[0.3, 0.2, 0.1]]))
