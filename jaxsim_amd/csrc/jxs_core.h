@@ -192,7 +192,9 @@ struct Core {
     // (api/ode.py:174-225) at x0, x0 + dt/2 k1, x0 + dt/2 k2, x0 + dt k3.  One stage for Euler.
     // RigidContacts: stage 0 is the step with QP contact forces, stage 1 re-evaluates the kinematics
     // and the articulated inertias at the new state for the impact (rbda/contacts/rigid.py:391-446).
-    constexpr int n_stages = kRK4 ? 4 : (kRigid ? 2 : 1);
+    // RigidContacts appends one more pass over the new state for the impact (kImpactStage).
+    constexpr int kImpactStage = kRK4 ? 4 : 1;
+    constexpr int n_stages = kRigid ? kImpactStage + 1 : (kRK4 ? 4 : 1);
     V x0s, x0sd, x0q[4], x0p[3], x0v[3], x0w[3], x0m[3];  // stage-0 state (quaternion normalised)
     V ks, ksd, kq[4], kp[3], kv[3], kw[3], km[3];           // weighted sum of the stage derivatives
     V xfl[3], xfa[3];                                       // external link wrench in the stage-0 frame C
@@ -208,9 +210,10 @@ struct Core {
         kp[k] = V(T(0)), kv[k] = V(T(0)), kw[k] = V(T(0)), km[k] = V(T(0));
       }
     }
-#pragma unroll
+    // (the RungeKutta4 + rigid-contact kernel keeps this loop rolled: one copy of the contact solvers)
+#pragma unroll(kRK4 && kRigid ? 1 : 8)
     for (int stage = 0; stage < n_stages; ++stage) {
-    if (kRigid && !kRK4 && stage == 1 && P.rigid == 2) break;  // RelaxedRigidContacts: no velocity reset (relaxed_rigid.py:265-281)
+    if (kRigid && stage == kImpactStage && P.rigid == 2) break;  // RelaxedRigidContacts: no velocity reset (relaxed_rigid.py:265-281)
     // ---- base rotation: DCM of q/|q| (data.base_orientation, api/data.py:267-286) --------
     V R[9], r[3];
     {
@@ -694,11 +697,11 @@ struct Core {
         RigidPoints rp;
         rigid_points(ps0, R, r, vl, va, pB, rp);
         const VI zero_lane = lane * 0;
-        if (kRK4 || stage == 0) {
-          // contact forces of the QP, then nudot = nudot_free + M^-1 J^T f  (api/ode.py:57-131); with
-          // RungeKutta4 (relaxed model only) at every stage, as system_dynamics is (api/ode.py:174-225)
+        if (stage < kImpactStage) {
+          // contact forces, then nudot = nudot_free + M^-1 J^T f  (api/ode.py:57-131); with RungeKutta4 at
+          // every stage, as system_dynamics is (api/ode.py:174-225)
           V fpt[3];
-          if (kRK4 || P.rigid == 2)
+          if (P.rigid == 2)
             relaxed_contact_forces(lane, level, parent, child, tf, ps0, rp, a6, mass, fpt);
           else
             rigid_contact_forces(lane, level, parent, child, tf, ps0, rp, a6, fpt);
@@ -748,7 +751,7 @@ struct Core {
       return;
     }
 
-    if (kRigid && !kRK4 && stage == 1) {
+    if (kRigid && stage == kImpactStage) {
       // impact stage: the velocities were reset above, nothing to integrate
     } else if (!kRK4) {
     // ---- C: semi-implicit Euler (api/integrators.py:14-88) ---------------------------------

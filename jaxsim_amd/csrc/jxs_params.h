@@ -102,7 +102,7 @@ enum Mode : int {
   MODE_ROLLOUT = 4,  // MODE_STEP repeated KArgs::n_steps times in one launch (state in registers)
   MODE_STEP_RK4 = 5,  // js.model.step with IntegratorType.RungeKutta4  api/integrators.py:91-167
   MODE_STEP_RIGID = 6,  // js.model.step with the RigidContacts / RelaxedRigidContacts model  rbda/contacts/rigid.py:176-539
-  MODE_STEP_RK4_RIGID = 7  // RungeKutta4 with RelaxedRigidContacts (contact forces solved at every stage)
+  MODE_STEP_RK4_RIGID = 7  // RungeKutta4 with RigidContacts / RelaxedRigidContacts (contact forces solved at every stage)
 };
 
 enum ForceRepr : int { REPR_INERTIAL = 0, REPR_BODY = 1, REPR_MIXED = 2 };  // api/common.py:39-47

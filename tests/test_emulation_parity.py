@@ -588,6 +588,34 @@ def test_relaxed_rk4_box_settles_known_answer(models, dtype):
     assert out[2, 0] == pytest.approx(0.05, abs=1e-4)
 
 
+@pytest.mark.parametrize("key", ["box4", "anymal4", "chain9f6"])
+def test_rigid_rk4_step_matches_oracle(models, reduced_qp, key):
+    """RungeKutta4 with RigidContacts: QP forces at each stage, the impact on the integrated state
+    (api/model.py:2665-2679); the reference runs its rigid-contact test for every integrator
+    (tests/test_simulations.py:245)."""
+    import jaxsim_amd as ja
+
+    model, d = _rigid_case(models, key, 8, seed=5)
+    model = helpers.with_params(model, integrator=ja.IntegratorType.RungeKutta4)
+    tau, f = helpers.random_inputs(model, 8, 7, np.float64)
+    ref = oracle.step(model, d, link_forces=f, joint_force_references=tau)
+    out = eb.run(model, eb.MODE_STEP, helpers.odata_to_block(model, d), tau=tau.T, link_forces=f.reshape(8, -1).T, force_repr=2)
+    assert helpers.rel_err(out, helpers.odata_to_block(model, ref)) < 1e-7
+
+
+@pytest.mark.parametrize("dtype,atol", [(np.float64, 1e-4), (np.float32, 2e-4)])
+def test_rigid_rk4_box_settles_known_answer(models, dtype, atol):
+    """reference tests/test_simulations.py:245-292 with integrator = RungeKutta4."""
+    import jaxsim_amd as ja
+
+    model = helpers.rigid_model(models("box"), [0, 1, 2, 3], build=dict(solver_options={"solver_tol": 1e-3}), K=1e5)
+    model = helpers.with_params(model, integrator=ja.IntegratorType.RungeKutta4)
+    d = oracle.OracleData.build(model, base_position=[0.0, 0.0, 0.2], velocity_representation=VelRepr.Inertial)
+    out = eb.run(model, eb.MODE_STEP, helpers.odata_to_block(model, d).astype(dtype), n_steps=1000)
+    assert abs(out[0, 0]) < 1e-6 and abs(out[1, 0]) < 1e-6
+    assert out[2, 0] == pytest.approx(0.05, abs=atol)
+
+
 def test_rigid_unsupported_configurations_are_rejected(models):
     import jaxsim_amd as ja
 
@@ -596,8 +624,6 @@ def test_rigid_unsupported_configurations_are_rejected(models):
     with pytest.raises(RuntimeError, match="fixed-base"):
         fixed = ja.JaxSimModel.build_from_model_description(ja.robots.cartpole_urdf(with_collisions=True))
         eb.layout(helpers.rigid_model(fixed, [0, 1, 2, 3]))
-    with pytest.raises(RuntimeError, match="SemiImplicitEuler"):
-        eb.layout(helpers.with_params(helpers.rigid_model(models("box"), [0, 1, 2, 3]), integrator=ja.IntegratorType.RungeKutta4))
 
 
 @pytest.mark.parametrize("fixed_base,max_back", [(True, 1), (False, 1), (False, 3)])

@@ -417,6 +417,35 @@ def test_rigid_models_carry_the_tangential_rows_through(models, kind):
     np.testing.assert_array_equal(out.state_block()[13:], helpers.odata_to_block(model, d)[13:])
 
 
+@pytest.mark.parametrize("key", ["box4", "anymal4", "icub8"])
+def test_rigid_rk4_step_matches_oracle_gpu(models, reduced_qp, key):
+    """RungeKutta4 with RigidContacts: QP forces at each stage, impact on the integrated state; the
+    reference runs its rigid-contact test for every integrator (tests/test_simulations.py:245)."""
+    name, idx, params = RIGID_CASES[key]
+    model = helpers.with_params(helpers.rigid_model(models(name), idx, **params), integrator=ja.IntegratorType.RungeKutta4)
+    N = 21
+    d = models.random_data(name, N, seed=5)
+    tau, f = helpers.random_inputs(model, N, 7, np.float64)
+    ref = oracle.step(model, d, link_forces=f, joint_force_references=tau)
+    out = js.model.step(model, to_gpu(model, d), link_forces=f, joint_force_references=tau)
+    assert helpers.rel_err(out.state_block(), helpers.odata_to_block(model, ref)) < 1e-7
+    d32 = models.random_data(name, N, seed=5, dtype=np.float32)
+    out32 = js.model.step(model, to_gpu(model, d32)).state_block()
+    ref32 = oracle.step(model, helpers.upcast(d32))
+    assert out32.dtype == np.float32 and helpers.rel_err(out32, helpers.odata_to_block(model, ref32)) < 3e-3
+
+
+@pytest.mark.parametrize("dtype,atol", [(np.float64, 1e-4), (np.float32, 2e-4)])
+def test_rigid_rk4_box_settles_known_answer_gpu(models, dtype, atol):
+    """reference tests/test_simulations.py:245-292 with integrator = RungeKutta4."""
+    model = helpers.rigid_model(models("box"), [0, 1, 2, 3], build=dict(solver_options={"solver_tol": 1e-3}), K=1e5)
+    model = helpers.with_params(model, integrator=ja.IntegratorType.RungeKutta4)
+    d = oracle.OracleData.build(model, base_position=[0.0, 0.0, 0.2], velocity_representation=VelRepr.Inertial, dtype=dtype)
+    out = js.model.rollout(model, to_gpu(model, d), 1000).state_block()
+    assert abs(out[0, 0]) < 1e-6 and abs(out[1, 0]) < 1e-6
+    assert out[2, 0] == pytest.approx(0.05, abs=atol)
+
+
 def test_rigid_tumbling_box_rollout_gpu(models, reduced_qp):
     model = helpers.rigid_model(models("box"), [0, 1, 2, 3], K=1e5)
     q = oracle.refmath.quaternion_from_euler_xyz(np.array([[0.3, 0.2, 0.1]]))
