@@ -47,9 +47,12 @@ extern "C" {
 #define JXS_REPR_BODY 1
 #define JXS_REPR_MIXED 2
 
-/* IntegratorType: src/jaxsim/api/model.py:32-40.  RungeKutta4Fast is not built. */
+/* IntegratorType: src/jaxsim/api/model.py:32-40.  RungeKutta4Fast (api/integrators.py:170-276) only with
+ * the rigid contact models: the reference's version corrupts the SoftContacts state and fails without
+ * collidable points. */
 #define JXS_INTEGRATOR_SEMI_IMPLICIT_EULER 0
 #define JXS_INTEGRATOR_RUNGE_KUTTA4 1
+#define JXS_INTEGRATOR_RUNGE_KUTTA4_FAST 2
 
 /* Contact models: src/jaxsim/rbda/contacts/{soft,rigid,relaxed_rigid}.py */
 #define JXS_CONTACT_SOFT 0

@@ -198,6 +198,8 @@ struct Core {
     V x0s, x0sd, x0q[4], x0p[3], x0v[3], x0w[3], x0m[3];  // stage-0 state (quaternion normalised)
     V ks, ksd, kq[4], kp[3], kv[3], kw[3], km[3];           // weighted sum of the stage derivatives
     V xfl[3], xfa[3];                                       // external link wrench in the stage-0 frame C
+    // RungeKutta4Fast (api/integrators.py:170-276): contact link wrench and position derivatives of stage 0
+    V xcfl[3], xcfa[3], sd0, dq0[4], pd0[3];
     if (kRK4) {
       const V nrm0 = vsqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
       const V inv0 = vrcp(vsel(nrm0 == V(T(0)), V(T(1)), nrm0));
@@ -700,16 +702,30 @@ struct Core {
         if (stage < kImpactStage) {
           // contact forces, then nudot = nudot_free + M^-1 J^T f  (api/ode.py:57-131); with RungeKutta4 at
           // every stage, as system_dynamics is (api/ode.py:174-225)
-          V fpt[3];
-          if (P.rigid == 2)
-            relaxed_contact_forces(lane, level, parent, child, tf, ps0, rp, a6, mass, fpt);
-          else
-            rigid_contact_forces(lane, level, parent, child, tf, ps0, rp, a6, fpt);
-          V w6[6], cfl[3] = {V(T(0)), V(T(0)), V(T(0))}, cfa[3] = {V(T(0)), V(T(0)), V(T(0))};
+          V cfl[3] = {V(T(0)), V(T(0)), V(T(0))}, cfa[3] = {V(T(0)), V(T(0)), V(T(0))};
+          if (kRK4 && P.rk4fast && stage > 0) {
+            // RungeKutta4Fast: the inertial contact wrench of the initial state is held over the stages
+            // (integrators.py:175-187); only its moment is re-referred to this stage's frame C
+            V dp[3] = {x0p[0] - pB[0], x0p[1] - pB[1], x0p[2] - pB[2]}, t[3];
+            cross(dp, xcfl, t);
   #pragma unroll
-          for (int k = 0; k < 3; ++k) w6[k] = fpt[k];
-          cross(rp.rc, w6, w6 + 3);
-          scatter_point_wrenches(lane, ps0, w6, cfl, cfa);
+            for (int k = 0; k < 3; ++k) cfl[k] = xcfl[k], cfa[k] = xcfa[k] + t[k];
+          } else {
+            V fpt[3];
+            if (P.rigid == 2)
+              relaxed_contact_forces(lane, level, parent, child, tf, ps0, rp, a6, mass, fpt);
+            else
+              rigid_contact_forces(lane, level, parent, child, tf, ps0, rp, a6, fpt);
+            V w6[6];
+  #pragma unroll
+            for (int k = 0; k < 3; ++k) w6[k] = fpt[k];
+            cross(rp.rc, w6, w6 + 3);
+            scatter_point_wrenches(lane, ps0, w6, cfl, cfa);
+            if (kRK4) {
+  #pragma unroll
+              for (int k = 0; k < 3; ++k) xcfl[k] = cfl[k], xcfa[k] = cfa[k];
+            }
+          }
           V pAr[1][6], ar[1][6], sddr[1];
   #pragma unroll
           for (int k = 0; k < 3; ++k) pAr[0][k] = -cfl[k], pAr[0][3 + k] = -cfa[k];
@@ -786,33 +802,49 @@ struct Core {
     } else {
       // ---- system_dynamics at this stage (api/ode.py:134-225): position derivatives use the stage
       // velocity, the quaternion derivative the Baumgarte gain 1.0 ------------------------------------
-      V dq[4], dv[3], t[3];
+      V dq[4], dv[3], t[3], pdt[3];
       quat_derivative(q, om, T(1), dq);
       cross(aca, pB, t);
 #pragma unroll
-      for (int k = 0; k < 3; ++k) dv[k] = acl[k] - t[k];  // inertial-fixed linear acceleration
+      for (int k = 0; k < 3; ++k) dv[k] = acl[k] - t[k], pdt[k] = vBc[k];  // inertial-fixed linear acceleration; W_pdot_B = v_W + w x p_B
+      V sd_st = sd;
+      if (kRigid && P.rk4fast) {
+        // RungeKutta4Fast: system_position_dynamics is evaluated on the initial data at every stage
+        // (integrators.py:200-203): the position derivatives of stage 0 are reused
+        if (stage == 0) {
+          sd0 = sd;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) dq0[k] = dq[k];
+#pragma unroll
+          for (int k = 0; k < 3; ++k) pd0[k] = pdt[k];
+        }
+        sd_st = sd0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dq[k] = dq0[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) pdt[k] = pd0[k];
+      }
       const T wgt = (stage == 0 || stage == 3) ? T(1) : T(2);
-      ks = ks + wgt * sd, ksd = ksd + wgt * sdd;
+      ks = ks + wgt * sd_st, ksd = ksd + wgt * sdd;
 #pragma unroll
       for (int k = 0; k < 4; ++k) kq[k] = kq[k] + wgt * dq[k];
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        kp[k] = kp[k] + wgt * vBc[k];  // W_pdot_B = v_W + w x p_B
+        kp[k] = kp[k] + wgt * pdt[k];
         kv[k] = kv[k] + wgt * dv[k];
         kw[k] = kw[k] + wgt * aca[k];
         if (with_contacts) km[k] = km[k] + wgt * ps0.md[k];
       }
       if (stage < 3) {
         const V h = V(stage == 2 ? P.dt : P.dt * T(0.5));  // euler_mid, euler_mid, euler_fin
-        const V sd_st = sd, sdd_st = sdd;
+        const V sdd_st = sdd;
         s = x0s + h * sd_st;
         sd = x0sd + h * sdd_st;
 #pragma unroll
         for (int k = 0; k < 4; ++k) q[k] = x0q[k] + h * dq[k];  // re-normalised at the next stage start
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-          const V pdot = vBc[k];
-          pB[k] = x0p[k] + h * pdot;
+          pB[k] = x0p[k] + h * pdt[k];
           vW[k] = x0v[k] + h * dv[k];
           om[k] = x0w[k] + h * aca[k];
           if (with_contacts) ps0.m[k] = x0m[k] + h * ps0.md[k];

@@ -47,9 +47,11 @@ std::string pack_model(const jxs_model_desc& d, Packed<T>& out) {
     if (std::fabs(n2 - 1.0) > 1e-9) return "terrain_normal must be a unit vector";
     if (std::fabs(nn[2]) < 1e-12) return "the z component of the terrain normal cannot be zero";  // terrain.py:197-200
   }
-  if (d.integrator != JXS_INTEGRATOR_SEMI_IMPLICIT_EULER && d.integrator != JXS_INTEGRATOR_RUNGE_KUTTA4)
-    return "unsupported integrator (SemiImplicitEuler = 0 and RungeKutta4 = 1 are built)";
-  out.integrator = d.integrator;
+  if (d.integrator != JXS_INTEGRATOR_SEMI_IMPLICIT_EULER && d.integrator != JXS_INTEGRATOR_RUNGE_KUTTA4 &&
+      d.integrator != JXS_INTEGRATOR_RUNGE_KUTTA4_FAST)
+    return "unsupported integrator (SemiImplicitEuler = 0, RungeKutta4 = 1, RungeKutta4Fast = 2)";
+  // RungeKutta4Fast runs the RungeKutta4 kernels with KParams::rk4fast set
+  out.integrator = d.integrator == JXS_INTEGRATOR_RUNGE_KUTTA4_FAST ? JXS_INTEGRATOR_RUNGE_KUTTA4 : d.integrator;
   for (int i = 1; i < nL; ++i) {
     if (d.parent[i] < 0 || d.parent[i] >= i) return "parent array must be topologically ordered (BFS indices)";
     if (d.joint_type[i] != 1 && d.joint_type[i] != 2) return "joint types must be revolute(1) or prismatic(2)";
@@ -79,7 +81,7 @@ std::string pack_model(const jxs_model_desc& d, Packed<T>& out) {
   G = std::max(G, 4);
   // RungeKutta4 keeps the tangential deformation of every point in registers across its stages: one
   // point chunk, so up to 64 points get a lane each (semi-implicit Euler prefers 32 lanes + 2 chunks)
-  if (d.integrator == JXS_INTEGRATOR_RUNGE_KUTTA4 && n_en > 32 && n_en <= 64) G = 64;
+  if (d.integrator != JXS_INTEGRATOR_SEMI_IMPLICIT_EULER && n_en > 32 && n_en <= 64) G = 64;
   out.G = G;
   const int n_chunks = (n_en + G - 1) / G;
   const int n_slots = n_chunks * G;
@@ -91,13 +93,17 @@ std::string pack_model(const jxs_model_desc& d, Packed<T>& out) {
   P.n_points = d.n_points;
   P.n_slots = n_slots;
   P.n_chunks = n_chunks;
-  if (d.integrator == JXS_INTEGRATOR_RUNGE_KUTTA4 && n_chunks > 1)
+  if (d.integrator != JXS_INTEGRATOR_SEMI_IMPLICIT_EULER && n_chunks > 1)
     return "RungeKutta4 needs every enabled collidable point in one lane group (at most 64 points)";
   if (d.contact_model != JXS_CONTACT_SOFT && d.contact_model != JXS_CONTACT_RIGID &&
       d.contact_model != JXS_CONTACT_RELAXED_RIGID)
     return "unknown contact model";
   P.rigid = n_en == 0 ? 0 : d.contact_model == JXS_CONTACT_RIGID ? 1 : d.contact_model == JXS_CONTACT_RELAXED_RIGID ? 2 : 0;
   P.n_cp = n_en;
+  P.rk4fast = d.integrator == JXS_INTEGRATOR_RUNGE_KUTTA4_FAST ? 1 : 0;
+  if (P.rk4fast && !P.rigid)
+    return "RungeKutta4Fast is built for RigidContacts / RelaxedRigidContacts with collidable points: the reference's "
+           "version corrupts the tangential deformation of SoftContacts and fails without collidable points";
   if (P.rigid) {
     // one point per lane, three rows of the QP per point, both matrices in LDS (jxs_rigid.inc)
     if (n_en > kRigidMaxPoints) return "RigidContacts / RelaxedRigidContacts: at most 32 enabled collidable points are supported";

@@ -151,6 +151,7 @@ struct KParams {
   T rr_rcoef;                    // 2 mu^2 (1 + mu^2)
   T rr_tiny;                     // smallest positive normal number (guards pow of a non-positive base)
   int rr_refine;                 // refinement steps against the operator applied through the tree
+  int rk4fast;                   // RungeKutta4Fast: contact forces and position derivatives of the initial state (api/integrators.py:170-276)
 };
 
 // Device/host pointers handed to the core for one launch.

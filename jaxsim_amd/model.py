@@ -243,10 +243,13 @@ class RelaxedRigidContacts:
 
 class IntegratorType(enum.IntEnum):
     """``IntegratorType`` (``src/jaxsim/api/model.py:32-40``); values are the C-ABI enum.
-    ``RungeKutta4Fast`` (the reference's approximate variant) is not built."""
+    ``RungeKutta4Fast`` (``api/integrators.py:170-276``: contact forces and position derivatives frozen
+    at the initial state) is built for RigidContacts / RelaxedRigidContacts, where the reference's version
+    is well defined."""
 
     SemiImplicitEuler = 0
     RungeKutta4 = 1
+    RungeKutta4Fast = 2
 
 
 class JaxSimModel:

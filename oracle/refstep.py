@@ -812,7 +812,65 @@ def rk4_integration(model, data: OracleData, link_forces, joint_torques) -> Orac
     return dataclasses.replace(data, **x_tf).update_caches(model)
 
 
-_INTEGRATORS = {0: semi_implicit_euler_integration, 1: rk4_integration}  # integrators.py:279-283
+def rk4fast_integration(model, data: OracleData, link_forces, joint_torques) -> OracleData:
+    """``rk4fast_integration`` (integrators.py:170-276), as written:
+
+    * the contact forces are computed once from the initial state and added to the external link
+      forces as a constant inertial wrench (``:175-187``);
+    * the position derivatives of every stage are those of the **initial** data --
+      ``system_position_dynamics(data=data, ...)`` is called with ``data``, not the stage data
+      (``:200-203``) -- so positions advance with the initial velocities, only the accelerations are
+      re-evaluated (ABA at the stage state with the frozen wrenches);
+    * with SoftContacts the derivative of the tangential deformation is stored *as the state*
+      (``contact_state = update_contact_state(contact_state_derivative)``, ``:189-191,225``) and the
+      state itself is returned as its derivative (``:214``): the deformation after the step is
+      meaningless.  Without collidable points ``W_f_L_terrain`` is undefined (``:175-187``, NameError).
+      Both cases are refused here; the function is restated for the contact models without contact
+      state (RigidContacts, RelaxedRigidContacts), where it is well defined."""
+    kdp = model.kin_dyn_parameters
+    if not (is_rigid_contact_model(model) or is_relaxed_rigid_contact_model(model)):
+        raise NotImplementedError("rk4fast_integration corrupts the tangential deformation of SoftContacts in the reference")
+    if kdp.number_of_collidable_points() == 0:
+        raise NotImplementedError("rk4fast_integration fails in the reference without collidable points (W_f_L_terrain undefined)")
+    from . import refrelaxed, refrigid
+
+    dtype = data.dtype
+    dt = dtype.type(model.time_step)
+    impl = refrigid if is_rigid_contact_model(model) else refrelaxed
+    data_in = dataclasses.replace(data, velocity_representation=VelRepr.Inertial)
+    W_f_L_terrain, _ = impl.link_contact_forces(model, data_in, link_forces=link_forces, joint_torques=joint_torques)
+    W_f_L_total = link_forces + W_f_L_terrain
+    W_pd_B, W_Qd_B, sd = system_position_dynamics(data, 1.0)  # of the initial data, at every stage
+
+    def f(x):
+        data_ti = dataclasses.replace(data, velocity_representation=VelRepr.Inertial, **x).update_caches(model)
+        W_vd_WB, sdd = forward_dynamics_aba(model, data_ti, joint_forces=joint_torques, link_forces=W_f_L_total)
+        return dict(base_position=W_pd_B, base_quaternion=W_Qd_B, joint_positions=sd, base_linear_velocity=W_vd_WB[:, :3],
+                    base_angular_velocity=W_vd_WB[:, 3:], joint_velocities=sdd)  # fmt: skip
+
+    nrm = rm.safe_norm(data.base_quaternion, keepdims=True)
+    x_t0 = dict(
+        base_position=data.base_position,
+        base_quaternion=data.base_quaternion / np.where(nrm == 0, 1.0, nrm).astype(dtype),
+        joint_positions=data.joint_positions,
+        base_linear_velocity=data.base_linear_velocity,
+        base_angular_velocity=data.base_angular_velocity,
+        joint_velocities=data.joint_velocities,
+    )
+
+    def advance(x, dxdt, h):
+        return {k: (x[k] + h * dxdt[k]).astype(dtype) for k in x}
+
+    k1 = f(x_t0)
+    k2 = f(advance(x_t0, k1, dtype.type(0.5) * dt))
+    k3 = f(advance(x_t0, k2, dtype.type(0.5) * dt))
+    k4 = f(advance(x_t0, k3, dt))
+    dxdt = {k: (k1[k] + 2 * k2[k] + 2 * k3[k] + k4[k]) / 6 for k in x_t0}
+    x_tf = advance(x_t0, dxdt, dt)
+    return dataclasses.replace(data, **x_tf).update_caches(model)
+
+
+_INTEGRATORS = {0: semi_implicit_euler_integration, 1: rk4_integration, 2: rk4fast_integration}  # integrators.py:279-283
 
 
 def step(model, data: OracleData, *, link_forces=None, joint_force_references=None) -> OracleData:

@@ -446,6 +446,31 @@ def test_rigid_rk4_box_settles_known_answer_gpu(models, dtype, atol):
     assert out[2, 0] == pytest.approx(0.05, abs=atol)
 
 
+@pytest.mark.parametrize("kind,key", [("relaxed", "box8"), ("relaxed", "anymal16"), ("relaxed", "icub16"), ("rigid", "box4"), ("rigid", "anymal4")])
+def test_rk4fast_step_matches_oracle_gpu(models, reduced_qp, kind, key):
+    """RungeKutta4Fast (api/integrators.py:170-276) with the contact models without contact state,
+    against oracle/refstep.py::rk4fast_integration (the reference's function as written)."""
+    name, idx, params = (RELAXED_CASES if kind == "relaxed" else RIGID_CASES)[key]
+    make = helpers.relaxed_model if kind == "relaxed" else helpers.rigid_model
+    model = helpers.with_params(make(models(name), idx, **params), integrator=ja.IntegratorType.RungeKutta4Fast)
+    N = 21
+    d = models.random_data(name, N, seed=5)
+    tau, f = helpers.random_inputs(model, N, 7, np.float64)
+    ref = oracle.step(model, d, link_forces=f, joint_force_references=tau)
+    out = js.model.step(model, to_gpu(model, d), link_forces=f, joint_force_references=tau)
+    assert helpers.rel_err(out.state_block(), helpers.odata_to_block(model, ref)) < (1e-10 if kind == "relaxed" else 1e-7)
+    d32 = models.random_data(name, N, seed=5, dtype=np.float32)
+    out32 = js.model.step(model, to_gpu(model, d32)).state_block()
+    ref32 = oracle.step(model, helpers.upcast(d32))
+    assert out32.dtype == np.float32 and helpers.rel_err(out32, helpers.odata_to_block(model, ref32)) < 3e-3
+
+
+def test_rk4fast_is_refused_for_soft_contacts_gpu(models):
+    with pytest.raises(Exception, match="RungeKutta4Fast"):
+        model = helpers.with_params(models("box"), integrator=ja.IntegratorType.RungeKutta4Fast)
+        js.model.step(model, to_gpu(model, models.random_data("box", 2)))
+
+
 def test_rigid_tumbling_box_rollout_gpu(models, reduced_qp):
     model = helpers.rigid_model(models("box"), [0, 1, 2, 3], K=1e5)
     q = oracle.refmath.quaternion_from_euler_xyz(np.array([[0.3, 0.2, 0.1]]))
