@@ -169,7 +169,8 @@ def parse_urdf(
     considered_joints: list[str] | tuple[str, ...] | None = None,
     locked_joint_positions: dict[str, float] | None = None,
 ) -> ModelDescription:
-    """Parse a URDF string or path into a reduced (fixed joints lumped) description.
+    """Parse a URDF (or SDF, see ``parse_sdf``) string or path into a reduced (fixed joints lumped)
+    description.
 
     ``considered_joints`` (``api/model.py:128-223,807-878``): the 1-DoF joints to keep; every other
     joint is locked at ``locked_joint_positions.get(name, 0.0)`` and removed by lumping its child into
@@ -177,10 +178,18 @@ def parse_urdf(
     if is_path is None:
         is_path = not urdf.lstrip().startswith("<")
     root = ET.parse(urdf).getroot() if is_path else ET.fromstring(urdf)
-    if root.tag != "robot":
-        raise ValueError("not a URDF <robot> document")
-    name = root.get("name", "model")
+    if root.tag == "sdf":
+        raw = _read_sdf(root)
+    elif root.tag == "robot":
+        raw = _read_urdf(root)
+    else:
+        raise ValueError("not a URDF <robot> or SDF <sdf> document")
+    return _assemble(*raw, considered_joints=considered_joints, locked_joint_positions=locked_joint_positions)
 
+
+def _read_urdf(root):
+    """Raw links / joints / collision points of a URDF ``<robot>``."""
+    name = root.get("name", "model")
     # ---- raw links / joints / collisions --------------------------------------------
     raw_links: dict[str, LinkDescription] = {}
     link_order: list[str] = []
@@ -238,6 +247,12 @@ def parse_urdf(
             )
         )
 
+    return name, raw_links, link_order, raw_points, raw_joints, []
+
+
+def _assemble(name, raw_links, link_order, raw_points, raw_joints, extra_frames, *, considered_joints, locked_joint_positions):
+    """Reduction, fixed-base folding, lumping of fixed joints, BFS indexing (shared by URDF and SDF).
+    ``extra_frames``: explicit frames ``(name, link, link_H_frame)`` of the source document."""
     # ---- model reduction: lock the joints that are not considered --------------------------
     if considered_joints is not None:
         movable = {j.name for j in raw_joints if j.jtype != FIXED}
@@ -342,6 +357,156 @@ def parse_urdf(
             CollidablePoint(parent_link=survivor, position=S_H_l[:3, :3] @ cp.position + S_H_l[:3, 3])
         )
 
+    for fname, lname, L_H_F in extra_frames:
+        if lname in owner:
+            survivor, S_H_l = owner[lname]
+            frames.append(FrameDescription(name=fname, parent_name=survivor, pose=S_H_l @ L_H_F))
+
     return ModelDescription(
         name=name, fixed_base=fixed_base, links=links, joints=kept_joints, collidable_points=points, frames=frames
     )
+
+
+# ---- SDF (the reference reads it through `rod`, src/jaxsim/parsers/rod/parser.py:26-120) -------------------
+def _sdf_pose(elem):
+    """``<pose relative_to=...>x y z roll pitch yaw</pose>`` of an SDF element -> (4x4, relative_to)."""
+    pe = elem.find("pose") if elem is not None else None
+    if pe is None:
+        return np.eye(4), None
+    v = _floats(pe.text, 6)
+    return hm.transform_from_xyz_rpy(v[:3], v[3:]), (pe.get("relative_to") or None)
+
+
+def _read_sdf(root, model_name: str | None = None):
+    """Raw links / joints / collision points of the first (or the named) ``<model>`` of an SDF document,
+    converted to the URDF frame convention like the reference does
+    (``sdf_model.switch_frame_convention(rod.FrameConvention.Urdf)``, ``rod/parser.py:76-84``): the
+    frame of a non-root link is the frame of its parent joint, inertial / collision / child-joint poses
+    are re-expressed in it.  Pose graph: ``relative_to`` names a link, joint or ``<frame>`` of the model;
+    defaults are the model frame for links, the child link for joints, ``attached_to`` for frames.
+    Joint axes are expressed in the joint frame unless ``expressed_in`` says otherwise (SDF >= 1.7)."""
+    models = list(root.iter("model"))
+    if model_name is not None:
+        models = [m for m in models if m.get("name") == model_name]
+    if not models:
+        raise ValueError("no <model> in the SDF document")
+    me = models[0]
+    name = me.get("name", "model")
+    W_H_M, _ = _sdf_pose(me)
+
+    elems = {}  # frame name -> (pose, relative_to default resolved)
+    link_elems = {le.get("name"): le for le in me.findall("link")}
+    joint_elems = {je.get("name"): je for je in me.findall("joint")}
+    for n, le in link_elems.items():
+        H, rel = _sdf_pose(le)
+        elems[n] = (H, rel or "__model__")
+    for n, je in joint_elems.items():
+        H, rel = _sdf_pose(je)
+        elems[n] = (H, rel or je.find("child").text.strip())
+    for fe in me.findall("frame"):
+        H, rel = _sdf_pose(fe)
+        elems[fe.get("name")] = (H, rel or fe.get("attached_to") or "__model__")
+
+    cache: dict[str, np.ndarray] = {"__model__": np.eye(4), "world": np.linalg.inv(W_H_M)}
+
+    def M_H(frame: str, stack=()) -> np.ndarray:
+        if frame not in cache:
+            if frame not in elems:
+                raise ValueError(f"unknown frame {frame!r} in the SDF pose graph")
+            if frame in stack:
+                raise ValueError(f"cyclic relative_to chain through {frame!r}")
+            H, rel = elems[frame]
+            cache[frame] = M_H(rel, stack + (frame,)) @ H
+        return cache[frame]
+
+    parent_joint = {je.find("child").text.strip(): n for n, je in joint_elems.items()}
+
+    def frame_of(link: str) -> np.ndarray:  # URDF convention: the parent joint's frame, the link's own for a root
+        return M_H(parent_joint[link]) if link in parent_joint else M_H(link)
+
+    raw_links, link_order, raw_points, extra_frames = {}, [], [], []
+    for lname, le in link_elems.items():
+        link_order.append(lname)
+        F_H_L = np.linalg.inv(frame_of(lname)) @ M_H(lname)
+        ine = le.find("inertial")
+        m, M = 0.0, np.zeros((6, 6))
+        if ine is not None and ine.find("mass") is not None:
+            m = float(ine.find("mass").text)
+            ie = ine.find("inertia")
+            g = lambda k: float(ie.find(k).text) if ie is not None and ie.find(k) is not None else 0.0  # noqa: E731
+            I_com = np.array([[g("ixx"), g("ixy"), g("ixz")], [g("ixy"), g("iyy"), g("iyz")], [g("ixz"), g("iyz"), g("izz")]])
+            F_H_CoM = F_H_L @ _sdf_pose(ine)[0]
+            X = hm.adjoint(F_H_CoM, inverse=True)
+            M = X.T @ hm.inertia_to_sixd(m, np.zeros(3), I_com) @ X
+        raw_links[lname] = LinkDescription(name=lname, mass=m, inertia=M)
+        for ce in le.findall("collision"):
+            geom = ce.find("geometry")
+            if geom is None:
+                continue
+            H = F_H_L @ _sdf_pose(ce)[0]
+            if geom.find("box") is not None:
+                pts = _box_points(_floats(geom.find("box").find("size").text, 3), H)
+            elif geom.find("sphere") is not None:
+                pts = _sphere_points(float(geom.find("sphere").find("radius").text), H)
+            else:
+                continue  # cylinder / mesh: skipped like the reference default
+            raw_points += [CollidablePoint(parent_link=lname, position=p) for p in pts]
+    for fe in me.findall("frame"):
+        att = fe.get("attached_to")
+        while att in elems and att not in link_elems:  # a frame attached to a frame / joint: follow to the link
+            att = joint_elems[att].find("child").text.strip() if att in joint_elems else elems[att][1]
+        if att in link_elems:
+            extra_frames.append((fe.get("name"), att, np.linalg.inv(frame_of(att)) @ M_H(fe.get("name"))))
+
+    fmax = float(np.finfo(float).max)
+    raw_joints = []
+    if any(je.find("parent").text.strip() == "world" for je in joint_elems.values()):
+        raw_links["world"] = LinkDescription(name="world", mass=0.0, inertia=np.zeros((6, 6)))
+    for jname, je in joint_elems.items():
+        jt = je.get("type")
+        if jt not in {"revolute", "continuous", "prismatic", "fixed"}:
+            raise ValueError(f"unsupported joint type {jt!r} (joint {jname!r})")
+        jtype = {"revolute": REVOLUTE, "continuous": REVOLUTE, "prismatic": PRISMATIC, "fixed": FIXED}[jt]
+        parent, child = je.find("parent").text.strip(), je.find("child").text.strip()
+        ax = je.find("axis")
+        axis = np.array([1.0, 0.0, 0.0])
+        lo, up, damping, friction = -fmax, fmax, 0.0, 0.0
+        if ax is not None:
+            xe = ax.find("xyz")
+            if xe is not None:
+                axis = _floats(xe.text, 3)
+                if xe.get("expressed_in"):
+                    R = (np.linalg.inv(M_H(jname)) @ M_H(xe.get("expressed_in")))[:3, :3]
+                    axis = R @ axis
+            lim, dyn = ax.find("limit"), ax.find("dynamics")
+            if lim is not None and lim.find("lower") is not None:
+                lo = float(lim.find("lower").text)
+            if lim is not None and lim.find("upper") is not None:
+                up = float(lim.find("upper").text)
+            if dyn is not None and dyn.find("damping") is not None:
+                damping = float(dyn.find("damping").text)
+            if dyn is not None and dyn.find("friction") is not None:
+                friction = float(dyn.find("friction").text)
+        if jtype != FIXED:
+            nrm = np.linalg.norm(axis)
+            if nrm == 0:
+                raise ValueError(f"zero axis in joint {jname!r}")
+            axis = axis / nrm
+        if jt == "continuous":
+            lo, up = -fmax, fmax
+        P_frame = np.linalg.inv(W_H_M) if parent == "world" else frame_of(parent)
+        raw_joints.append(
+            JointDescription(
+                name=jname, parent=parent, child=child, jtype=jtype, axis=axis,
+                pose=np.linalg.inv(P_frame) @ M_H(jname), position_limit=(lo, up),
+                friction_static=friction, friction_viscous=damping,
+                position_limit_damper=float(os.environ.get("JAXSIM_JOINT_POSITION_LIMIT_DAMPER", 0.0)),
+                position_limit_spring=float(os.environ.get("JAXSIM_JOINT_POSITION_LIMIT_SPRING", 0.0)),
+            )  # fmt: skip
+        )
+    return name, raw_links, link_order, raw_points, raw_joints, extra_frames
+
+
+def parse_sdf(sdf: str, **kwargs) -> ModelDescription:
+    """SDF string or path -> reduced description (``parse_urdf`` dispatches on the root tag)."""
+    return parse_urdf(sdf, **kwargs)

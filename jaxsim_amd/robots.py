@@ -108,6 +108,42 @@ def double_pendulum_urdf(with_base_collision: bool = False) -> str:
     )
 
 
+def double_pendulum_sdf(with_base_collision: bool = False, link_offset=(0.0, 0.0, 0.0)) -> str:
+    """The model of ``double_pendulum_urdf`` written as SDF 1.7 the way the reference's fixture is
+    structured (``tests/assets/double_pendulum.sdf``): a fixed world joint, joint poses given
+    ``relative_to`` the base link, child link poses ``relative_to`` their joint, explicit ``<frame>``
+    elements.  ``link_offset`` moves the child link frames away from their joint frames (identity in the
+    reference's file) to exercise the conversion to the URDF frame convention."""
+    ox, oy, oz = link_offset
+    inertial = lambda m, z: (  # noqa: E731
+        f"<inertial><pose>0 0 {z} 0 0 0</pose><mass>{m}</mass>"
+        "<inertia><ixx>1.0</ixx><ixy>0</ixy><ixz>0</ixz><iyy>1.0</iyy><iyz>0</iyz><izz>1.0</izz></inertia></inertial>"
+    )
+    coll = ('<collision name="c"><pose>0 0 1 0 0 0</pose><geometry><box><size>0.2 0.2 2.15</size></box></geometry></collision>'
+            if with_base_collision else "")  # fmt: skip
+
+    def arm(side, x):
+        return (
+            f'<joint name="{side}_joint" type="revolute"><pose relative_to="base_link">{x} 0 2 -3.1415 0 0</pose>'
+            f"<parent>base_link</parent><child>{side}_link</child>"
+            "<axis><xyz>1 0 0</xyz><limit><lower>-100</lower><upper>100</upper></limit>"
+            "<dynamics><damping>1.0</damping></dynamics></axis></joint>"
+            f'<link name="{side}_link"><pose relative_to="{side}_joint">{ox} {oy} {oz} 0 0 0</pose>'
+            + inertial(1.0, 0.5 - oz if (ox, oy) == (0.0, 0.0) else 0.5)
+            + "</link>"
+            f'<frame name="{side}_link_extremity_frame" attached_to="{side}_link">'
+            f'<pose relative_to="{side}_link">{-x} 0 1 3.14 0 0</pose></frame>'
+        )
+
+    return (
+        '<?xml version="1.0"?><sdf version="1.7"><model name="double_pendulum">'
+        '<joint name="fixed_base" type="fixed"><parent>world</parent><child>base_link</child></joint>'
+        '<link name="base_link">' + inertial(100.0, 0) + coll + "</link>"
+        + arm("right", 0.2) + arm("left", -0.2)
+        + "</model></sdf>"
+    )
+
+
 def cartpole_urdf(with_collisions: bool = False) -> str:
     """rail(0) - prismatic-y -> cart(1) - continuous-x -> pole(2), fixed base.
 

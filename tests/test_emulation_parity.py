@@ -339,6 +339,23 @@ def test_rk4_pendulum_energy_drift_is_fourth_order(models):
     assert out["rk4"] < 1e-9 and out["rk4"] < 1e-3 * out["euler"], out
 
 
+def test_config1_double_pendulum_from_sdf(models):
+    """BASELINE.json configs[0]: 2-link pendulum, fixed base, no contacts, batch 1, fp64 -- built from
+    the SDF form of the model (the reference's fixture is an SDF file) and stepped against the oracle."""
+    import jaxsim_amd as ja
+    from jaxsim_amd import robots
+
+    model = ja.JaxSimModel.build_from_model_description(robots.double_pendulum_sdf())
+    d = oracle.random_model_data(model, batch_size=1, seed=3)
+    tau = np.array([[0.3, -0.2]])
+    out = eb.run(model, eb.MODE_STEP, helpers.odata_to_block(model, d), tau=tau.T, n_steps=1)
+    ref = oracle.step(model, d, joint_force_references=tau)
+    assert helpers.rel_err(out, helpers.odata_to_block(model, ref)) < helpers.FP64_TOL
+    # and it is the same model as the URDF form used everywhere else in the tests
+    ref_urdf = oracle.step(models("double_pendulum"), d, joint_force_references=tau)
+    np.testing.assert_allclose(helpers.odata_to_block(model, ref), helpers.odata_to_block(models("double_pendulum"), ref_urdf), atol=1e-12)
+
+
 def test_rk4_needs_one_chunk_of_points(models):
     """More enabled points than lanes of a group would need a second contact pass per stage:
     rejected at model creation (documented limit), not silently integrated with Euler."""

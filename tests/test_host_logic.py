@@ -326,3 +326,53 @@ def test_references_error_behaviour(models):
     # no-model path: inertial forces for all links, additive or not
     a = z.apply_link_forces(np.ones((1, 6)))
     np.testing.assert_array_equal(a.apply_link_forces(np.ones((1, 6)), additive=True)._link_forces, 2 * np.ones((1, 6)))
+
+
+def _tables(model):
+    k = model.kin_dyn_parameters
+    return dict(parent=k.parent_array, jt=k.joint_types, ax=k.joint_axis, lam=k.lambda_H_pre, suc=k.suc_H_i, m=k.link_mass,
+                com=k.link_com, I=k.link_inertia_com, M6=k.link_spatial_inertia, kv=k.friction_viscous, smin=k.position_limits_min, smax=k.position_limits_max,
+                body=k.contact_body, pt=k.contact_point)  # fmt: skip
+
+
+def test_sdf_front_end_matches_the_equivalent_urdf():
+    """SDF input (the reference reads its ``tests/assets/double_pendulum.sdf`` through `rod`,
+    ``parsers/rod/parser.py:26-120``): pose graph with ``relative_to``, joint poses defaulting to the child
+    link, world joint -> fixed base, ``<axis>`` children, explicit frames; converted to the URDF frame
+    convention.  The same model written as URDF gives the same tables."""
+    import jaxsim_amd as ja
+    from jaxsim_amd import robots
+
+    for coll in (False, True):
+        a = ja.JaxSimModel.build_from_model_description(robots.double_pendulum_sdf(with_base_collision=coll))
+        b = ja.JaxSimModel.build_from_model_description(robots.double_pendulum_urdf(with_base_collision=coll))
+        assert a.link_names() == b.link_names() and a.joint_names() == b.joint_names()
+        assert not a.floating_base() and a.number_of_links() == 3 and a.dofs() == 2
+        ta, tb = _tables(a), _tables(b)
+        for k in ta:
+            np.testing.assert_allclose(np.asarray(ta[k], dtype=float), np.asarray(tb[k], dtype=float), atol=1e-12, err_msg=k)
+    assert {"right_link_extremity_frame", "left_link_extremity_frame"} <= set(a.kin_dyn_parameters.frame_names)
+
+
+def test_sdf_link_frame_offset_and_axis_expressed_in():
+    """A child link frame away from its joint frame is folded into the inertial / collision poses (URDF
+    frame convention, ``rod/parser.py:76-84``): the dynamics tables do not change.  ``expressed_in``
+    re-expresses the joint axis."""
+    import jaxsim_amd as ja
+    from jaxsim_amd import robots
+    from jaxsim_amd.parsers import urdf as up
+
+    a = ja.JaxSimModel.build_from_model_description(robots.double_pendulum_sdf())
+    c = ja.JaxSimModel.build_from_model_description(robots.double_pendulum_sdf(link_offset=(0.0, 0.0, 0.3)))
+    ta, tc = _tables(a), _tables(c)
+    for k in ta:
+        np.testing.assert_allclose(np.asarray(ta[k], dtype=float), np.asarray(tc[k], dtype=float), atol=1e-12, err_msg=k)
+    # joint frame rolled by -3.1415 about x: an axis given in the model frame as (0, 1, 0) is (0, -1, ~0) in it
+    sdf = robots.double_pendulum_sdf().replace("<xyz>1 0 0</xyz>", '<xyz expressed_in="__model__">0 1 0</xyz>', 1)
+    d = up.parse_urdf(sdf)
+    j = next(j for j in d.joints if j.name == "right_joint")
+    np.testing.assert_allclose(j.axis, [0.0, np.cos(-3.1415), -np.sin(-3.1415)], atol=1e-12)
+    with pytest.raises(ValueError, match="unknown frame"):
+        up.parse_urdf(robots.double_pendulum_sdf().replace('relative_to="right_joint"', 'relative_to="nope"'))
+    with pytest.raises(ValueError, match="URDF <robot> or SDF"):
+        up.parse_urdf("<foo/>")
