@@ -471,6 +471,23 @@ def test_rk4fast_is_refused_for_soft_contacts_gpu(models):
         js.model.step(model, to_gpu(model, models.random_data("box", 2)))
 
 
+@pytest.mark.parametrize("kind", ["rigid", "relaxed"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_contact_solves_do_not_depend_on_wave_mates(models, kind, dtype):
+    """Several environments share a wave (4 for the quadruped) and its wave-uniform decisions (which
+    block columns to skip, when to stop refining / iterating): an environment stepped alone gives the
+    bits it gives inside a batch, like under the reference's vmap."""
+    make = helpers.rigid_model if kind == "rigid" else helpers.relaxed_model
+    params = dict(K=1e4, D=1e2) if kind == "rigid" else dict(mu=0.5)
+    model = make(models("anymal"), helpers.ANYMAL_FEET_16, **params)
+    d = models.random_data("anymal", 13, seed=5, dtype=dtype)
+    blk = helpers.odata_to_block(model, d)
+    full = js.model.step(model, to_gpu(model, d)).state_block()
+    for e in (0, 1, 6, 12):
+        one = js.data.JaxSimModelData.from_state_block(model, blk[:, [e]], ja.VelRepr.Mixed)
+        np.testing.assert_array_equal(js.model.step(model, one).state_block()[:, 0], full[:, e])
+
+
 def test_rigid_tumbling_box_rollout_gpu(models, reduced_qp):
     model = helpers.rigid_model(models("box"), [0, 1, 2, 3], K=1e5)
     q = oracle.refmath.quaternion_from_euler_xyz(np.array([[0.3, 0.2, 0.1]]))
