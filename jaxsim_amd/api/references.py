@@ -7,8 +7,7 @@ Like the reference, the link forces are **stored inertial-fixed** and converted 
 velocity representation with the link transforms of the data object (``:205-247``, ``:431-449``);
 unlike it, every array carries a leading batch axis when the data object is batched (``[N, nL, 6]`` /
 ``[N, n]``), matching ``jaxsim_amd.api.model.step``.  Host-side NumPy: the conversion is a handful of
-3x3 products per link, done once per user update, not per step.  ``apply_frame_forces``
-(``:451-560``) is not built (frames are outside the step path).
+3x3 products per link, done once per user update, not per step.
 """
 
 from __future__ import annotations
@@ -156,3 +155,30 @@ class JaxSimModelReferences:
         out = np.array(np.broadcast_to(self._link_forces, np.broadcast_shapes(self._link_forces.shape, W_f_L.shape[:-2] + self._link_forces.shape[-2:])))
         out[..., idxs, :] = (out[..., idxs, :] if additive else 0.0) + W_f_L
         return dataclasses.replace(self, _link_forces=out)
+
+    def apply_frame_forces(self, forces, model: JaxSimModel, data: JaxSimModelData, frame_names=None, additive: bool = False):
+        """``apply_frame_forces`` (references.py:451-560): 6D forces given at frames (rigidly attached to a
+        link) in the active representation with the *frame* as body frame; they are converted to inertial
+        with ``W_H_F = W_H_L L_H_F``, summed per parent link, and set as the forces of **all** links
+        (links without a listed frame get zero unless ``additive``), like the reference."""
+        f_F = np.asarray(forces, dtype=float)
+        if f_F.ndim == 1:
+            f_F = f_F[None, :]
+        kdp = model.kin_dyn_parameters
+        if isinstance(frame_names, str):
+            frame_names = (frame_names,)
+        idxs = _idxs(frame_names, kdp.frame_names, "frame")
+        if len(idxs) != f_F.shape[-2]:
+            raise ValueError(f"The number of frame names ({len(idxs)}) must match the number of forces ({f_F.shape[-2]})")
+        body = np.asarray(kdp.frame_body)[idxs]
+        if self.velocity_representation == VelRepr.Inertial:
+            W_f_F = f_F
+        else:
+            W_H_L = self._transforms(model, data, body)
+            W_H_F = W_H_L @ np.asarray(kdp.frame_transform)[idxs]
+            W_f_F = _other_to_inertial(f_F, self.velocity_representation, W_H_F, True)
+        mask = (body[:, None] == np.arange(model.number_of_links())[None, :]).astype(float)
+        W_f_L = np.einsum("fl,...fk->...lk", mask, W_f_F)
+        inertial = dataclasses.replace(self, velocity_representation=VelRepr.Inertial)
+        out = inertial.apply_link_forces(W_f_L, model=model, data=data, additive=additive)
+        return dataclasses.replace(out, velocity_representation=self.velocity_representation)

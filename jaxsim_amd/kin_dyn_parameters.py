@@ -49,6 +49,9 @@ class KinDynParameters:
     contact_body: np.ndarray  # [n_cp] int
     contact_point: np.ndarray  # [n_cp,3]
     contact_enabled: np.ndarray  # [n_cp] bool
+    # frame parameters (``kin_dyn_parameters.py:843-893``): parent link index and pose in it
+    frame_body: np.ndarray = dataclasses.field(default_factory=lambda: np.zeros(0, dtype=np.int64))  # [n_frames]
+    frame_transform: np.ndarray = dataclasses.field(default_factory=lambda: np.zeros((0, 4, 4)))  # [n_frames,4,4]
 
     def number_of_links(self) -> int:
         return int(self.parent_array.shape[0])
@@ -121,6 +124,8 @@ class KinDynParameters:
             link_names=tuple(l.name for l in links),
             joint_names=tuple(j.name for j in joints),
             frame_names=tuple(f.name for f in description.frames),
+            frame_body=np.array([name_to_index[f.parent_name] for f in description.frames], dtype=np.int64),
+            frame_transform=np.array([f.pose for f in description.frames], dtype=float).reshape(-1, 4, 4),
             parent_array=parent,
             joint_types=jtypes,
             joint_axis=axes,
