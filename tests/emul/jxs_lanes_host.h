@@ -155,6 +155,7 @@ struct HostLanes {
     return V(acc);
   }
   V env_bcast16(const V& x, int src) const { return V(x.v[src]); }
+  static unsigned uniform(unsigned x) { return x; }
   bool any(const VM& m) const {
     for (int i = 0; i < G; ++i)
       if (m.v[i]) return true;
