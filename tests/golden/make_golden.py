@@ -71,6 +71,23 @@ def main():
         np.savez_compressed(OUT / f"relaxed_{name}.npz", state=helpers.odata_to_block(model, d), tau=tau, link_forces=f,
                             step=helpers.odata_to_block(model, nxt), enabled=np.array(idx), mu=mu)  # fmt: skip
         print("wrote relaxed", name)
+    # RungeKutta4 / RungeKutta4Fast with the contact models without contact state
+    refrigid.REDUCED_QP = True
+    for tag, kind, name, idx, integ in (
+        ("relaxed_rk4_anymal", "relaxed", "anymal", helpers.ANYMAL_FEET_16, 1),
+        ("relaxed_rk4fast_anymal", "relaxed", "anymal", helpers.ANYMAL_FEET_16, 2),
+        ("rigid_rk4_box", "rigid", "box", [0, 1, 2, 3], 1),
+        ("rigid_rk4fast_box", "rigid", "box", [0, 1, 2, 3], 2),
+    ):
+        base = helpers.relaxed_model(zoo(name), idx, mu=0.4) if kind == "relaxed" else helpers.rigid_model(zoo(name), idx, K=1e5)
+        model = helpers.with_params(base, integrator=ja.IntegratorType(integ))
+        d = zoo.random_data(name, 5, seed=9, rep=oracle.VelRepr.Mixed)
+        tau, f = helpers.random_inputs(model, 5, 2031, np.float64)
+        nxt = oracle.step(model, d, link_forces=f, joint_force_references=tau)
+        np.savez_compressed(OUT / f"{tag}.npz", state=helpers.odata_to_block(model, d), tau=tau, link_forces=f,
+                            step=helpers.odata_to_block(model, nxt), enabled=np.array(idx), integrator=integ)  # fmt: skip
+        print("wrote", tag)
+    refrigid.REDUCED_QP = False
 
 
 if __name__ == "__main__":

@@ -708,6 +708,17 @@ def test_step_with_references_object(models, rep):
     assert helpers.rel_err(out.state_block(), helpers.odata_to_block(model, ref)) < helpers.FP64_TOL
 
 
+@pytest.mark.parametrize("tag", ["relaxed_rk4_anymal", "relaxed_rk4fast_anymal", "rigid_rk4_box", "rigid_rk4fast_box"])
+def test_gpu_golden_rigid_models_integrators(models, tag):
+    import test_golden as tg
+
+    g = tg.load(tag)
+    model = tg._integrator_golden_model(models, tag, g)
+    data = js.data.JaxSimModelData.from_state_block(model, g["state"], ja.VelRepr.Mixed)
+    out = js.model.step(model, data, link_forces=g["link_forces"], joint_force_references=g["tau"])
+    assert helpers.rel_err(out.state_block(), g["step"]) < (1e-10 if tg.INTEGRATOR_GOLDEN[tag][0] == "relaxed" else 1e-7)
+
+
 @pytest.mark.parametrize("name", ["cartpole", "chain9f", "icub"])
 def test_gpu_golden_rk4(models, name):
     import test_golden as tg
