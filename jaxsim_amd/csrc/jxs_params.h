@@ -120,7 +120,15 @@ struct KParams {
   unsigned int row_cross_levels;     // bit L: some parent pulls an extra child of level L across slots
   unsigned int row_ppull_levels;     // bit L: some link of level L has its parent in another slot
   JXS_HD int maxch(int L) const {
-    const unsigned long long w = L < 16 ? maxch_nib[0] : L < 32 ? maxch_nib[1] : L < 48 ? maxch_nib[2] : maxch_nib[3];
+    // Constant indices and mask arithmetic only: a `L < 16 ? maxch_nib[0] : ...` chain is turned into a load
+    // with a runtime index by the compiler, which puts this whole by-value struct into scratch memory and
+    // every field read behind a scratch load (seen in the rigid-contact kernels: 296 bytes of scratch, loops
+    // over P.n_cp / P.max_depth exec-masked because their bounds came back in VGPRs).
+    const unsigned long long m0 = 0ull - (unsigned long long)(L < 16);
+    const unsigned long long m1 = 0ull - (unsigned long long)(L >= 16 && L < 32);
+    const unsigned long long m2 = 0ull - (unsigned long long)(L >= 32 && L < 48);
+    const unsigned long long m3 = 0ull - (unsigned long long)(L >= 48);
+    const unsigned long long w = (maxch_nib[0] & m0) | (maxch_nib[1] & m1) | (maxch_nib[2] & m2) | (maxch_nib[3] & m3);
     return (int)((w >> ((L & 15) * 4)) & 15ull);
   }
   // state-block rows ([row][N], N fastest): SURVEY.md section 8(a) row D
