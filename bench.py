@@ -32,18 +32,39 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 FP32_PEAK_TFLOPS = 157.3  # vector FP32 peak (same guide)
 FLOPS_PER_ENV_STEP = 30e3  # structure-exploiting flop model, SURVEY.md section 8(d) / A.5
-# HBM-side bytes per launch from the rocprofv3 PMC passes committed under profiles/ (separate
-# --pmc FETCH_SIZE / WRITE_SIZE runs of this very command; FETCH_SIZE doubled as the microarch
-# guide prescribes for gfx950).  Only filled for the configuration that was profiled.
-def _profiled_traffic():
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc.json")) as f:
-            return {("icub23", 1024, "float32"): json.load(f).get("traffic_bytes_per_launch")}
-    except (OSError, ValueError):
-        return {}
+# HBM-side bytes per launch come from the rocprofv3 PMC passes committed under profiles/ (separate --pmc
+# FETCH_SIZE / WRITE_SIZE runs of this very command; FETCH_SIZE doubled as the microarch guide prescribes
+# for gfx950).  Counters cannot be read from inside this process, so the figure is tied to the kernel
+# sources it was measured on: the profile records a hash of jaxsim_amd/csrc/*, and a run of a different
+# kernel reports `traffic: null` instead of a stale number.
+def kernel_source_sha():
+    import hashlib
+
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "jaxsim_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".h", ".inc", ".hip", ".sh")):
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
 
 
-TRAFFIC_BYTES_PER_LAUNCH = _profiled_traffic()
+def profiled_traffic(model_name, n_envs, dtype_name):
+    """(bytes per launch | None, note) for the configuration that was profiled."""
+    for tag in ("r02", "r01"):
+        try:
+            with open(os.path.join(ROOT, "profiles", f"{tag}_pmc.json")) as f:
+                prof = json.load(f)
+        except (OSError, ValueError):
+            continue
+        cfg = prof.get("config", {"model": "icub23", "envs": 1024, "dtype": "float32"})
+        if (cfg.get("model"), cfg.get("envs"), cfg.get("dtype")) != (model_name, n_envs, dtype_name):
+            return None, f"profiles/{tag}_pmc.json holds another configuration"
+        sha = prof.get("kernel_source_sha")
+        if sha is not None and sha != kernel_source_sha():
+            return None, f"profiles/{tag}_pmc.json was measured on other kernel sources ({sha}); re-run tools/profile_round.sh"
+        return prof.get("traffic_bytes_per_launch"), f"profiles/{tag}_pmc.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, mean per launch)"
+    return None, "no PMC profile committed"
 
 
 def parse_args():
@@ -59,6 +80,9 @@ def parse_args():
     ap.add_argument("--cpu-baseline-seconds", type=float, default=10.0)
     ap.add_argument("--saturated-envs", type=int, default=65536, help="secondary figure: batch that saturates one GPU (0 = skip)")
     ap.add_argument("--no-other-contact-models", action="store_true", help="skip the secondary RigidContacts / RelaxedRigidContacts figures")
+    ap.add_argument("--dry-run-bootstrap", action="store_true",
+                    help="no GPU work: run only the multi-rank bootstrap of this script (job key, id exchange through the "
+                    "rendezvous file, host collective, shard bounds) and print what a rank-0 line would say about it")
     return ap.parse_args()
 
 
@@ -137,30 +161,44 @@ def other_contact_models(dtype, stream, steps=200, warmup=20):
 
     lib = _lib.load()
     out = {}
+    tname = "float" if np.dtype(dtype) == np.float32 else "double"
 
-    def timed(model, n_envs, seed, with_tau):
+    def timed(model, n_envs, seed, with_tau, kernel):
         data = synthetic_state(model, n_envs, seed=seed, dtype=dtype)
         dm = runtime.device_model(model, dtype)
         st = C.c_void_p(data._state.ptr)
         tau = runtime.DeviceArray(model.dofs(), n_envs, dtype, tile=data._state.tile, zero=True)
         tp = C.c_void_p(tau.ptr)
 
-        def run(k):
+        def run(k, gravity=with_tau):
             for _ in range(k):
-                if with_tau:
+                if gravity:
                     _lib.check(lib.jxs_gravity_torques(dm.handle, st, tp, n_envs, stream.handle), "jxs_gravity_torques")
                 _lib.check(lib.jxs_step(dm.handle, st, st, tp if with_tau else None, None, 2, n_envs, stream.handle), "jxs_step")
 
+        def events(k, **kw):
+            e0, e1 = runtime.Event(), runtime.Event()
+            e0.record(stream)
+            run(k, **kw)
+            e1.record(stream)
+            stream.synchronize()
+            return e0.elapsed_ms(e1) / k * 1e3
+
         run(warmup)
         stream.synchronize()
-        e0, e1 = runtime.Event(), runtime.Event()
-        e0.record(stream)
-        run(steps)
-        e1.record(stream)
-        stream.synchronize()
-        us = e0.elapsed_ms(e1) / steps * 1e3
+        us = events(steps)
+        # the step kernel alone (tau held): its launch period is what the roofline entry is computed from
+        us_step = events(steps, gravity=False) if with_tau else us
         finite = float(np.isfinite(data.state_block()).all(axis=0).mean())
-        return {"envs": n_envs, "steps": steps, "us_per_step": us, "env_steps_per_s": n_envs / (us * 1e-6), "finite_envs": finite}
+        lay = dm.layout
+        # read state + read tau + write state; the rigid contact models carry no
+        # tangential deformation (rbda/contacts/rigid.py:445-458), so the 3 n_cp term drops
+        alg = (2 * (13 + 2 * lay.n_joints) + lay.n_joints) * np.dtype(dtype).itemsize
+        gbs = alg * n_envs / (us_step * 1e-6) / 1e9
+        return {"envs": n_envs, "steps": steps, "us_per_step": us, "env_steps_per_s": n_envs / (us * 1e-6), "finite_envs": finite,
+                "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                             "traffic": None, "algorithmic_bytes_per_env_step": alg, "kernel": kernel,
+                             "kernel_avg_launch_us": us_step}}  # fmt: skip
 
     def enable(model, idx):
         kdp = model.kin_dyn_parameters
@@ -173,7 +211,7 @@ def other_contact_models(dtype, stream, steps=200, warmup=20):
         enable(quad, [0, 8, 16, 24])  # one bottom corner of every foot box
         quad.contact_model = ja.RigidContacts.build()
         quad.contact_params = ja.RigidContactsParams(K=1e4, D=2e2)
-        out["config5_rigid_contacts"] = timed(quad, 4096, 100, True) | {
+        out["config5_rigid_contacts"] = timed(quad, 4096, 100, True, f"jxs_kernel<{tname},16,MODE_STEP_RIGID>") | {
             "workload": "anymal12 synthetic, RigidContacts (4 points), tau = RNEA gravity term every step (jxs_gravity_torques + jxs_step)"}  # fmt: skip
     except Exception as e:
         out["config5_rigid_contacts"] = {"error": repr(e)}
@@ -181,7 +219,7 @@ def other_contact_models(dtype, stream, steps=200, warmup=20):
         hum = ja.JaxSimModel.build_from_model_description(robots.icub23_urdf(sole_boxes_per_foot=2))
         hum.contact_model = ja.RelaxedRigidContacts.build()
         hum.contact_params = js.contact.estimate_good_contact_parameters(hum)
-        out["relaxed_rigid_contacts"] = timed(hum, 1024, 200, False) | {
+        out["relaxed_rigid_contacts"] = timed(hum, 1024, 200, False, f"jxs_kernel<{tname},32,MODE_STEP_RIGID>") | {
             "workload": "icub23 synthetic, all 32 collidable points, RelaxedRigidContacts with estimate_good_contact_parameters (jxs_step)"}  # fmt: skip
     except Exception as e:
         out["relaxed_rigid_contacts"] = {"error": repr(e)}
@@ -232,8 +270,95 @@ def cpu_baseline(model, block, budget_s):
     }
 
 
+def timed_repetitions(run_steps, steps, reps, stream, barrier, lib):
+    """`reps` timed regions of EXACTLY `steps` launches each.  Every region is bracketed by a barrier
+    and a stream synchronisation on both sides; wall clock (perf_counter) and HIP events on the launch
+    stream are both taken.  The completion is waited for by polling (`jxs_stream_wait_spin`): a blocking
+    wait adds its wake-up latency, which is comparable to the whole region when `steps` is small."""
+    import ctypes as C  # noqa: F401
+
+    from jaxsim_amd import _lib, runtime
+
+    wall, evs = [], []
+    for _ in range(reps):
+        ev0, ev1 = runtime.Event(), runtime.Event()
+        barrier()
+        _lib.check(lib.jxs_stream_wait_spin(stream.handle), "jxs_stream_wait_spin")
+        t0 = time.perf_counter()
+        ev0.record(stream)
+        run_steps(steps)
+        ev1.record(stream)
+        _lib.check(lib.jxs_stream_wait_spin(stream.handle), "jxs_stream_wait_spin")
+        wall.append(time.perf_counter() - t0)
+        barrier()
+        evs.append(ev0.elapsed_ms(ev1) * 1e-3)
+    return wall, evs
+
+
+def secondary_dtype(model_name, n_local, dtype, stream, steps=200):
+    """Secondary figure: the same workload and launch pattern in the other precision (the reference's own
+    default arithmetic is fp64, src/jaxsim/__init__.py:17-35; the headline follows SURVEY.md section 8 = fp32)."""
+    import ctypes as C
+
+    from jaxsim_amd import _lib, runtime
+
+    lib = _lib.load()
+    model = build_model(model_name)
+    data = synthetic_state(model, n_local, seed=0, dtype=dtype)
+    dm = runtime.device_model(model, dtype)
+    sp = C.c_void_p(data._state.ptr)
+    _lib.check(lib.jxs_step_repeat(dm.handle, sp, None, None, 2, n_local, 50, stream.handle), "jxs_step_repeat")
+    _lib.check(lib.jxs_step_repeat(dm.handle, sp, None, None, 2, n_local, steps, stream.handle), "jxs_step_repeat")
+    stream.synchronize()
+    e0, e1 = runtime.Event(), runtime.Event()
+    e0.record(stream)
+    _lib.check(lib.jxs_step_repeat(dm.handle, sp, None, None, 2, n_local, steps, stream.handle), "jxs_step_repeat")
+    e1.record(stream)
+    stream.synchronize()
+    us = e0.elapsed_ms(e1) / steps * 1e3
+    lay = dm.layout
+    alg = (2 * (13 + 2 * lay.n_joints + 3 * lay.n_points) + lay.n_joints) * np.dtype(dtype).itemsize
+    gbs = alg * n_local / (us * 1e-6) / 1e9
+    tname = "float" if np.dtype(dtype) == np.float32 else "double"
+    return {"dtype": "f32" if np.dtype(dtype) == np.float32 else "f64", "envs": n_local, "steps": steps, "us_per_step": us,
+            "env_steps_per_s": n_local / (us * 1e-6), "nonfinite_envs": int((~np.isfinite(data.state_block()).all(axis=0)).sum()),
+            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_env_step": alg, "kernel": f"jxs_kernel<{tname},{lay.group},MODE_STEP>", "kernel_avg_launch_us": us},
+            "note": "same workload, launch pattern and initial state distribution in the other precision; secondary figure, not `value`"}  # fmt: skip
+
+
+def dry_run_bootstrap(args, rank, world, result_out):
+    """The host side of a multi-rank launch without any device: what must work before the first RCCL call
+    of a real 8-GPU run.  The 128-byte id is random bytes instead of ncclGetUniqueId; the collective is the
+    file collective that bench.py falls back to when RCCL is unavailable."""
+    from jaxsim_amd import distributed
+
+    key = distributed.job_key() + "_dry"
+    uid = distributed.file_rendezvous(rank, world, key, timeout_s=60.0, make_id=lambda: os.urandom(128))
+    fc = distributed.FileCollective(rank, world, key, device_sync=False)
+    fc.barrier()
+    n_total = args.envs_per_gpu * world
+    lo, hi = distributed.shard_bounds(n_total, rank, world)
+    los = fc.all_gather_scalars(float(lo))
+    his = fc.all_gather_scalars(float(hi))
+    ids = fc.all_gather_scalars(float(int.from_bytes(uid[:6], "little")))
+    t = [float(fc.all_gather_scalars(0.001 * (r + 1)).max()) for r in range(3)]  # the max-over-ranks reduction
+    ok = (los[0] == 0 and his[-1] == n_total and all(his[r] == los[r + 1] for r in range(world - 1))
+          and all(his[r] - los[r] == args.envs_per_gpu for r in range(world)) and len(set(ids.tolist())) == 1)  # fmt: skip
+    fc.barrier()
+    if rank == 0:
+        print(json.dumps({"dry_run_bootstrap": True, "ok": bool(ok), "n_gpus": world, "global_batch": n_total,
+                          "shards": [[int(a), int(b)] for a, b in zip(los, his)], "same_id_on_all_ranks": len(set(ids.tolist())) == 1,
+                          "max_over_ranks": t, "job_key": key}), file=result_out, flush=True)  # fmt: skip
+    if not ok:
+        raise SystemExit(f"rank {rank}: bootstrap dry run failed: {los} {his} {ids}")
+
+
 def main():
     args = parse_args()
+    if os.environ.get("JAXSIM_AMD_LIB"):
+        # the developer knob of jaxsim_amd/_lib.py would let any library stand in for the product
+        raise SystemExit("bench.py measures the in-tree library only: unset JAXSIM_AMD_LIB")
     # The contract is ONE JSON line on stdout.  Native libraries (RCCL prints "Librccl path : ..." through
     # C stdio, flushed at exit) share fd 1: keep a private handle for the result line and point fd 1 at
     # stderr for everything else.
@@ -247,8 +372,12 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and world == 1:
         raise SystemExit("multi-GPU runs are launched with torch.distributed.run (one rank per GPU)")
+    if args.steps < 1:
+        raise SystemExit("--steps must be >= 1")
 
     multi = world > 1 or args.force_dist
+    if args.dry_run_bootstrap:
+        return dry_run_bootstrap(args, rank, world, result_out)
     import jaxsim_amd.api as js
     from jaxsim_amd import _lib, distributed, runtime
 
@@ -271,6 +400,8 @@ def main():
     dtype = np.dtype(args.dtype)
     model = build_model(args.model)
     n_local = args.envs_per_gpu
+    lo, hi = distributed.shard_bounds(n_local * world, rank, world)
+    assert hi - lo == n_local
     data = synthetic_state(model, n_local, seed=rank, dtype=dtype)
     initial_block = data.state_block() if rank == 0 else None
     stream = runtime.Stream()
@@ -282,50 +413,43 @@ def main():
     state_ptr = C.c_void_p(data._state.ptr)
 
     def run_steps(k):
-        # one step kernel launch per step, enqueued up to 250 at a time from C (jxs_step_repeat is the
-        # host loop over jxs_step without the per-call cost of the interpreter -- eight ranks share the
-        # host -- captured once into a hipGraph and replayed)
-        while k > 0:
-            c = min(k, 250)
-            _lib.check(lib.jxs_step_repeat(dm.handle, state_ptr, None, None, 2, n_local, c, stream.handle), "jxs_step_repeat")
-            k -= c
+        # one step kernel launch per step, enqueued from C (jxs_step_repeat is the host loop over jxs_step
+        # without the per-call cost of the interpreter -- eight ranks share the host): blocks of 250 and 50
+        # launches and the remainder are each captured once into a hipGraph and replayed
+        if k > 0:
+            _lib.check(lib.jxs_step_repeat(dm.handle, state_ptr, None, None, 2, n_local, k, stream.handle), "jxs_step_repeat")
 
     def barrier():
         if comm is not None:
             comm.barrier()
 
     run_steps(args.warmup)
-    # jxs_step_repeat captures its replay graphs (250 and 50 launches) on first use: one untimed pass with
-    # the chunking of the timed region, so that no capture falls inside it
-    k = args.steps
-    run_steps(250 if k >= 250 else 0)
-    run_steps(k % 250 if k % 250 >= 50 else 0)
-    stream.synchronize()
-    ev0, ev1 = runtime.Event(), runtime.Event()
-
-    barrier()
-    runtime.synchronize(stream)
-    t0 = time.perf_counter()
-    ev0.record(stream)
+    # one untimed pass with the chunking of the timed regions: jxs_step_repeat captures its replay graphs on
+    # first use, so that no capture falls inside a timed region
     run_steps(args.steps)
-    ev1.record(stream)
-    runtime.synchronize(stream)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_ms(ev1) / max(args.steps, 1)  # HIP events on the launch stream
+    stream.synchronize()
+
+    # Timed regions: EXACTLY --steps launches each, >= 5 repetitions, the MEDIAN region is reported (the
+    # region of a short request, e.g. --steps 20 = 0.2 ms, is otherwise at the mercy of one host hiccup).
+    reps = 5 if args.steps >= 500 else 9
+    wall, evs = timed_repetitions(run_steps, args.steps, reps, stream, barrier, lib)
+    if comm is not None:  # max over ranks, repetition by repetition
+        wall = [float(comm.all_gather_scalars(w).max()) for w in wall]
+    elapsed = float(np.median(wall))
+    kernel_ms = float(np.median(evs)) * 1e3 / args.steps  # HIP events on the launch stream
 
     # secondary figure: the same K steps as ONE fused jxs_rollout launch (state in registers
     # between steps; what jax.lax.fori_loop over step is to the reference).  Not the headline.
-    lib.jxs_rollout.argtypes  # noqa: B018  (declared in _lib)
+    k_roll = max(args.steps, 200)
     rc = lib.jxs_rollout(dm.handle, state_ptr, None, None, 2, n_local, 10, stream.handle)
     runtime.synchronize(stream)
     ev2, ev3 = runtime.Event(), runtime.Event()
     ev2.record(stream)
-    rc = rc or lib.jxs_rollout(dm.handle, state_ptr, None, None, 2, n_local, args.steps, stream.handle)
+    rc = rc or lib.jxs_rollout(dm.handle, state_ptr, None, None, 2, n_local, k_roll, stream.handle)
     ev3.record(stream)
     runtime.synchronize(stream)
     _lib.check(rc, "jxs_rollout")
-    rollout_ms_per_step = ev2.elapsed_ms(ev3) / max(args.steps, 1)
+    rollout_ms_per_step = ev2.elapsed_ms(ev3) / k_roll
 
     # secondary figure: the same kernel with the chip saturated (64 Ki environments on this GPU) -- what
     # the step costs once enough waves hide each other's latencies.  Not the headline configuration.
@@ -333,9 +457,9 @@ def main():
     if world == 1 and args.saturated_envs > 0:
         try:
             n_sat = args.saturated_envs
-            reps = -(-n_sat // n_local)
+            reps_sat = -(-n_sat // n_local)
             big = js.data.JaxSimModelData.from_state_block(
-                model, np.tile(initial_block, (1, reps))[:, :n_sat].astype(dtype), data.velocity_representation
+                model, np.tile(initial_block, (1, reps_sat))[:, :n_sat].astype(dtype), data.velocity_representation
             )
             bp = C.c_void_p(big._state.ptr)
             _lib.check(lib.jxs_step_repeat(dm.handle, bp, None, None, 2, n_sat, 20, stream.handle), "jxs_step_repeat")
@@ -350,14 +474,13 @@ def main():
         except Exception as e:  # secondary: never lose the headline for it
             saturated = {"error": repr(e)}
 
-    if comm is not None:
-        elapsed = float(comm.all_gather_scalars(elapsed).max())  # max over ranks
-
     # final state concat: ONE RCCL all-gather over xGMI, outside the timed region
     allgather_ms = None
     final = data.state_block()
     allgather_error = None
+    comm_ranks = None
     if comm is not None:
+        comm_ranks = int(comm.world_size)
         try:
             if comm_error is not None:
                 raise RuntimeError(f"RCCL communicator unavailable: {comm_error}")
@@ -380,6 +503,8 @@ def main():
         n, n_cp = lay.n_joints, lay.n_points
         alg_bytes_per_env = (2 * (13 + 2 * n + 3 * n_cp) + n) * dtype.itemsize
         achieved_gbs = alg_bytes_per_env * n_local / (kernel_ms * 1e-3) / 1e9
+        traffic, traffic_note = profiled_traffic(args.model, n_local, dtype.name)
+        tname = "float" if dtype == np.float32 else "double"
         out = {
             "metric": "env-steps/sec (whole node), iCub 23-DoF soft-contact, batch 1024/8192",
             "value": value,
@@ -396,12 +521,18 @@ def main():
             "config": {
                 "workload": f"{args.model} synthetic floating-base humanoid, soft contacts (K={model.contact_params.K:.4g}, D={model.contact_params.D:.4g}, mu=0.5), "
                 f"semi-implicit Euler dt=1e-3, nL={lay.n_links} n={n} n_cp={n_cp}, "
-                f"{n_local} envs per GPU x {world} GPU(s) = {n_total} envs, one step kernel launch per step (jxs_step_repeat: hipGraph replays of 250 / 50 launches, captured during warm-up)",
+                f"{n_local} envs per GPU x {world} GPU(s) = {n_total} envs, one step kernel launch per step (jxs_step_repeat: hipGraph replays of 250 / 50 / remainder launches, captured during warm-up)",
                 "envs_per_gpu": n_local,
                 "global_batch": n_total,
                 "lanes_per_env": int(lay.group),
                 "aba_layout": "row-distributed (8 lanes per active link)" if lay.row_mode else "link per lane",
                 "parallelism": f"batch-sharded x{world}, no per-step communication",
+            },
+            "timing": {
+                "repetitions": reps,
+                "statistic": "median over repetitions of one timed region of exactly `steps` launches (barrier + stream sync on both sides of every region; max over ranks per repetition)",
+                "wall_us_per_step_each": [w / args.steps * 1e6 for w in wall],
+                "event_us_per_launch_each": [e / args.steps * 1e6 for e in evs],
             },
             "roofline": {
                 "bound": "hbm",
@@ -409,17 +540,18 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved_gbs / HBM_PEAK_GBS,
-                "traffic": TRAFFIC_BYTES_PER_LAUNCH.get((args.model, n_local, dtype.name)),
+                "traffic": traffic,
+                "traffic_source": traffic_note,
                 "algorithmic_bytes_per_env_step": alg_bytes_per_env,
-                "kernel": "jxs_kernel<float,32,MODE_STEP>" if dtype == np.float32 else "jxs_kernel<double,32,MODE_STEP>",
+                "kernel": f"jxs_kernel<{tname},{lay.group},MODE_STEP>",
                 "kernel_avg_launch_us": kernel_ms * 1e3,
                 "fp32_flop_model_per_env_step": FLOPS_PER_ENV_STEP,
                 "fp32_frac_of_vector_peak": FLOPS_PER_ENV_STEP * n_local / (kernel_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
             },
             "nonfinite_envs_rank0": nonfinite_envs,
-            "traffic_note": "rocprofv3 FETCH_SIZE/WRITE_SIZE per launch: profiles/ (see DESIGN.md section 6)",
             "allgather_ms": allgather_ms,
             "allgather_error": allgather_error,
+            "comm": None if comm is None else {"kind": type(comm).__name__, "ranks": comm_ranks, "error": comm_error},
             "fused_rollout": {"us_per_step": rollout_ms_per_step * 1e3, "env_steps_per_s_rank0": n_local / (rollout_ms_per_step * 1e-3),
                               "note": "same steps as one jxs_rollout launch; secondary figure, not `value`"},
         }
@@ -431,6 +563,11 @@ def main():
             out["saturated"] = saturated
         if world == 1 and not args.no_other_contact_models:
             out["other_contact_models"] = other_contact_models(dtype, stream)
+            try:
+                other = np.dtype(np.float64 if dtype == np.float32 else np.float32)
+                out["other_precision"] = secondary_dtype(args.model, n_local, other, stream)
+            except Exception as e:
+                out["other_precision"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(model, initial_block, args.cpu_baseline_seconds)

@@ -127,6 +127,9 @@ int jxs_memset(void* dst, int value, uint64_t bytes, void* stream);
 int jxs_stream_create(void** stream);
 int jxs_stream_destroy(void* stream);
 int jxs_stream_synchronize(void* stream);
+/* Same completion guarantee, waited for by polling from the calling thread (microsecond-scale wake-up;
+ * for timing short regions).                                                                   */
+int jxs_stream_wait_spin(void* stream);
 int jxs_device_synchronize(void);
 /* HIP events on a stream (bench.py times the step kernel with these). */
 int jxs_event_create(void** event);
@@ -152,8 +155,8 @@ int jxs_step(jxs_model* model, const void* state_in, void* state_out, const void
 
 /* `n_launches` back-to-back in-place jxs_step launches enqueued from one call (no fusion: one kernel
  * launch per step, exactly what a host loop over jxs_step enqueues, without the per-call cost of the
- * host language).  On a created stream blocks of 250 and of 50 launches are captured once into hipGraphs
- * and replayed while the arguments stay the same (the rest is launched plainly).                                                  */
+ * host language).  On a created stream blocks of 250 and of 50 launches, and the remainder (>= 2 launches),
+ * are captured once into hipGraphs and replayed while the arguments stay the same.             */
 int jxs_step_repeat(jxs_model* model, void* state, const void* tau, const void* link_forces,
                     int force_repr, int N, int n_launches, void* stream);
 

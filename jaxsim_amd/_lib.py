@@ -197,6 +197,7 @@ def _declare(lib):
         "jxs_stream_create": [C.POINTER(vp)],
         "jxs_stream_destroy": [vp],
         "jxs_stream_synchronize": [vp],
+        "jxs_stream_wait_spin": [vp],
         "jxs_device_synchronize": [],
         "jxs_event_create": [C.POINTER(vp)],
         "jxs_event_destroy": [vp],

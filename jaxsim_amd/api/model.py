@@ -124,6 +124,10 @@ def step(
         ),
         "jxs_step",
     )  # fmt: skip
+    if inplace:
+        # the buffer of `data` now holds the new state: its lazily downloaded fields and cached
+        # kinematics describe the old one
+        data._invalidate_caches()
     return JaxSimModelData(model, out, data.velocity_representation, data._batched)
 
 

@@ -182,6 +182,11 @@ class JaxSimModelData:
         """Download the raw ``[rows, N]`` block."""
         return self._state.to_host()
 
+    def _invalidate_caches(self) -> None:
+        """The device buffer was overwritten (``step(..., inplace=True)``): forget the host copies."""
+        self._host = None
+        self._kin = None
+
     def _fields(self) -> dict:
         if self._host is None:
             self._host = unpack_state(StateLayout.of(self._model_ref), self._state.to_host())

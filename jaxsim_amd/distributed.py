@@ -89,21 +89,41 @@ class Communicator:
             pass
 
 
-def file_rendezvous(rank: int, world_size: int, key: str, timeout_s: float = 120.0) -> bytes:
-    """Single-node bootstrap without any framework: rank 0 creates the RCCL unique id and
-    publishes it through an atomically renamed file under the temp dir; the other ranks poll for
-    it.  ``key`` must be the same on all ranks of one job and unique per job (the launcher's
-    MASTER_PORT / run id)."""
+def _rendezvous_dir() -> str:
+    """Per-user directory (mode 0700) under the temp dir for the bootstrap files: other users of the host
+    can neither read the RCCL id nor plant a file under a predictable name."""
     import os
     import tempfile
+
+    d = os.path.join(tempfile.gettempdir(), f"jaxsim_amd_{os.getuid()}")
+    os.makedirs(d, mode=0o700, exist_ok=True)
+    st = os.stat(d)
+    if st.st_uid != os.getuid():
+        raise _lib.JaxsimAmdError(f"{d} is owned by another user")
+    if st.st_mode & 0o077:
+        os.chmod(d, 0o700)
+    return d
+
+
+def file_rendezvous(rank: int, world_size: int, key: str, timeout_s: float = 120.0, make_id=None) -> bytes:
+    """Single-node bootstrap without any framework: rank 0 creates the RCCL unique id and
+    publishes it through an atomically renamed file in a per-user directory under the temp dir; the
+    other ranks poll for it.  ``key`` must be the same on all ranks of one job and unique per job (the
+    launcher's MASTER_PORT / run id / pid, ``job_key``).  ``make_id`` replaces the RCCL call (dry runs
+    of the bootstrap on a machine without GPUs)."""
+    import os
     import time
 
-    path = os.path.join(tempfile.gettempdir(), f"jaxsim_amd_rdzv_{key}.bin")
+    path = os.path.join(_rendezvous_dir(), f"rdzv_{key}.bin")
     # A file left behind by a crashed earlier job with the same key is ignored.  The window is wide:
     # ranks of one job can start minutes apart (the first import on a fresh box pages the image in).
     fresh_after = time.time() - 900.0
     if rank == 0:
-        uid = Communicator.create_unique_id()
+        try:
+            os.remove(path)  # a leftover of an earlier job with the same key must not be picked up
+        except OSError:
+            pass
+        uid = (make_id or Communicator.create_unique_id)()
         tmp = f"{path}.{os.getpid()}.tmp"
         with open(tmp, "wb") as f:
             f.write(uid)
@@ -144,10 +164,8 @@ def communicator_from_env(tag: str = "") -> Communicator:
     comm = Communicator(file_rendezvous(rank, world, key), rank, world)
     comm.barrier()
     if rank == 0:  # everyone has read the id once the first collective completed
-        import tempfile
-
         try:
-            os.remove(os.path.join(tempfile.gettempdir(), f"jaxsim_amd_rdzv_{key}.bin"))
+            os.remove(os.path.join(_rendezvous_dir(), f"rdzv_{key}.bin"))
         except OSError:
             pass
     return comm
@@ -157,13 +175,13 @@ class FileCollective:
     """Last-resort host collective for a single node (used by bench.py only if the RCCL
     communicator cannot be created): barriers and scalar gathers through files in the temp dir."""
 
-    def __init__(self, rank: int, world_size: int, key: str):
+    def __init__(self, rank: int, world_size: int, key: str, device_sync: bool = True):
         import os
-        import tempfile
 
         self.rank, self.world_size = int(rank), int(world_size)
-        self.dir = os.path.join(tempfile.gettempdir(), f"jaxsim_amd_fc_{key}")
-        os.makedirs(self.dir, exist_ok=True)
+        self.device_sync = bool(device_sync)
+        self.dir = os.path.join(_rendezvous_dir(), f"fc_{key}")
+        os.makedirs(self.dir, mode=0o700, exist_ok=True)
         self.seq = 0
 
     def all_gather_scalars(self, value: float, timeout_s: float = 300.0) -> np.ndarray:
@@ -191,7 +209,8 @@ class FileCollective:
         return out
 
     def barrier(self) -> None:
-        runtime.synchronize()
+        if self.device_sync:
+            runtime.synchronize()
         self.all_gather_scalars(0.0)
 
 
@@ -225,6 +244,12 @@ def all_gather_state(comm: Communicator, data) -> np.ndarray:
     from .state import untile_block
 
     st = data._state
+    # ncclAllGather takes ONE per-rank count: unequal shards (shard_bounds spreads a remainder over the
+    # first ranks) would hang or corrupt the gather -- check before touching the data path
+    cols = comm.all_gather_scalars(float(st.cols))
+    if not np.all(cols == cols[0]):
+        raise _lib.JaxsimAmdError(f"all_gather_state needs equal shards, got {cols.astype(int).tolist()} environments per rank; "
+                                  "pad the batch to a multiple of the world size")
     gathered = comm.all_gather(st)  # storage: [world][n_tiles][rows][tile]
     raw = gathered.to_host_raw().reshape(comm.world_size, -1)
     return concat_shards(np.stack([untile_block(raw[r], st.rows, st.cols, st.tile) for r in range(comm.world_size)]))

@@ -108,6 +108,24 @@ def double_pendulum_urdf(with_base_collision: bool = False) -> str:
     )
 
 
+def serial_double_pendulum_urdf(m1=1.3, m2=0.7, L1=0.45, c1=0.2, c2=0.3, I1=0.021, I2=0.013, damping=0.0, friction=0.0) -> str:
+    """Fixed base + a SERIAL planar double pendulum about the x axis (links along their local +z): the
+    classical coupled two-link arm whose equations of motion are known in closed form.  Link i has mass
+    m_i, its CoM c_i along the link from its joint, inertia I_i about the x axis through the CoM; joint 2
+    sits L1 along link 1.  Not a reference fixture: it exists for the oracle-independent analytic pins
+    (tests/test_oracle_independent.py)."""
+    return (
+        '<robot name="serial_double_pendulum"><link name="world"/>'
+        '<link name="base">' + _inertial(2.0, I=(0.01, 0.01, 0.01)) + "</link>"
+        '<link name="upper">' + _inertial(m1, com=(0, 0, c1), I=(I1, 0.5 * I1, 0.7 * I1)) + "</link>"
+        '<link name="lower">' + _inertial(m2, com=(0, 0, c2), I=(I2, 0.6 * I2, 0.4 * I2)) + "</link>"
+        + _joint("world_to_base", "fixed", "world", "base", (0, 0, 1.5), (0, 0, 0))
+        + _joint("shoulder", "continuous", "base", "upper", (0, 0, 0), (1, 0, 0), damping=damping, friction=friction)
+        + _joint("elbow", "continuous", "upper", "lower", (0, 0, L1), (1, 0, 0), damping=damping, friction=friction)
+        + "</robot>"
+    )
+
+
 def double_pendulum_sdf(with_base_collision: bool = False, link_offset=(0.0, 0.0, 0.0)) -> str:
     """The model of ``double_pendulum_urdf`` written as SDF 1.7 the way the reference's fixture is
     structured (``tests/assets/double_pendulum.sdf``): a fixed world joint, joint poses given

@@ -16,8 +16,12 @@ import numpy as np
 from . import _lib
 
 _pool_lock = threading.Lock()
-_pool: dict[int, list[int]] = {}
+# bucket size -> [(pointer, stream the buffer was last used on)]: kernels are asynchronous, so a pooled
+# buffer may still be read by work in flight on that stream.  A new owner on the SAME stream is ordered
+# behind it by the stream itself; an owner on another stream first waits for the old one (DeviceArray.__init__).
+_pool: dict[int, list[tuple[int, object]]] = {}
 _current_stream = None  # None = default (null) stream
+_NULL = "null-stream"
 
 
 def current_stream():
@@ -107,29 +111,57 @@ class DeviceArray:
         self.nbytes = self.n_tiles * self.tile * self.rows * self.dtype.itemsize
         self._bucket = max(self.nbytes, 1)
         lib = _lib.load()
-        ptr = None
+        ptr, last = None, None
         with _pool_lock:
             free = _pool.get(self._bucket)
             if free:
-                ptr = free.pop()
+                ptr, last = free.pop()
         if ptr is None:
             p = C.c_void_p()
             _lib.check(lib.jxs_malloc(C.byref(p), self._bucket), "jxs_malloc")
             ptr = p.value
-        self.ptr = ptr
+        elif last is not (_current_stream if _current_stream is not None else _NULL):
+            # recycled from another stream: its last kernels may still be reading the buffer
+            if last is _NULL:
+                _lib.check(lib.jxs_device_synchronize(), "jxs_device_synchronize")
+            else:
+                last.synchronize()
+        self._ptr = ptr
+        self._streams = {_current_stream if _current_stream is not None else _NULL}
         if zero:
             _lib.check(lib.jxs_memset(C.c_void_p(self.ptr), 0, self.nbytes, _sp()), "jxs_memset")
+
+    @property
+    def ptr(self):
+        """Raw device pointer.  Every consumer passes it to work on the CURRENT stream, so reading it
+        records that stream as a user of the buffer (see ``__del__``)."""
+        self._streams.add(_current_stream if _current_stream is not None else _NULL)
+        return self._ptr
 
     @property
     def shape(self):
         return (self.rows, self.cols)
 
     def __del__(self):
-        ptr = getattr(self, "ptr", None)
-        if ptr is not None:
+        ptr = getattr(self, "_ptr", None)
+        if ptr is None:
+            return
+        self._ptr = None
+        try:
+            streams = list(self._streams)
+            # the buffer goes back to the pool tagged with ONE stream; work still in flight on any other
+            # stream that touched it is waited for here (rare: set_stream() between uses)
+            tag = streams[-1] if len(streams) == 1 else (_current_stream if _current_stream is not None else _NULL)
+            for st in streams:
+                if st is not tag:
+                    if st is _NULL:
+                        _lib.check(_lib.load().jxs_device_synchronize(), "jxs_device_synchronize")
+                    else:
+                        st.synchronize()
             with _pool_lock:
-                _pool.setdefault(self._bucket, []).append(ptr)
-            self.ptr = None
+                _pool.setdefault(self._bucket, []).append((ptr, tag))
+        except Exception:  # interpreter shutdown: the driver reclaims the memory with the process
+            pass
 
     @staticmethod
     def from_host(a: np.ndarray, *, tile: int, dtype=None) -> "DeviceArray":
@@ -208,7 +240,7 @@ def trim_pool() -> None:
     lib = _lib.load()
     with _pool_lock:
         for ptrs in _pool.values():
-            for p in ptrs:
+            for p, _ in ptrs:
                 lib.jxs_free(C.c_void_p(p))
         _pool.clear()
 

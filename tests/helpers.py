@@ -169,3 +169,36 @@ def relaxed_model(model, idx, *, build=None, **params):
 #: bottom corners of the four foot boxes of the synthetic quadruped (16 points), one corner per foot (4)
 ANYMAL_FEET_16 = [0, 1, 2, 3, 8, 9, 10, 11, 16, 17, 18, 19, 24, 25, 26, 27]
 ANYMAL_FEET_4 = [0, 8, 16, 24]
+
+
+# ---- row B: joint-limit spring / damper and the torque-speed curve ---------------------------------
+def actuation_variant(model, seed):
+    """Tight position limits with spring AND damper, a low torque limit and a narrow torque-speed curve,
+    so that random states sit beyond the limits and in all three regions of the curve
+    (api/actuation_model.py:55-66 and :95-126; the damper term is the reference's `jnp.positive` quirk)."""
+    rng = np.random.default_rng(seed)
+    kdp = model.kin_dyn_parameters
+    n = kdp.number_of_joints()
+    kdp2 = dataclasses.replace(
+        kdp, position_limits_min=np.full(n, -0.3), position_limits_max=np.full(n, 0.3),
+        position_limit_spring=rng.uniform(50.0, 150.0, n), position_limit_damper=rng.uniform(0.05, 0.5, n),
+        friction_static=rng.uniform(0.0, 0.3, n), friction_viscous=rng.uniform(0.0, 0.5, n),
+    )  # fmt: skip
+    return with_params(model, kin_dyn_parameters=kdp2,
+                               actuation_params=ja.ActuationParams(torque_max=8.0, omega_th=0.3, omega_max=0.8))  # fmt: skip
+
+
+def actuation_state(models, name, model, N, seed, dtype):
+    d = models.random_data(name, N, seed=seed, dtype=dtype)
+    rng = np.random.default_rng(seed + 77)
+    n = model.dofs()
+    d.joint_positions[:] = rng.uniform(-0.8, 0.8, (N, n)).astype(dtype)
+    d.joint_velocities[:] = rng.uniform(-1.2, 1.2, (N, n)).astype(dtype)
+    d = d.update_caches(model)
+    s, w = np.asarray(d.joint_positions, float), np.abs(np.asarray(d.joint_velocities, float))
+    # the states really exercise every branch: below / above the limits, and the three speed regions
+    assert (s < -0.3).any() and (s > 0.3).any() and (np.abs(s) <= 0.3).any()
+    assert (w <= 0.3).any() and ((w > 0.3) & (w <= 0.8)).any() and (w > 0.8).any()
+    return d
+
+

@@ -58,7 +58,9 @@ def test_file_rendezvous_ignores_stale_files(tmp_path, monkeypatch):
     import time
 
     monkeypatch.setattr(tempfile, "tempdir", str(tmp_path))
-    stale = tmp_path / "jaxsim_amd_rdzv_k1.bin"
+    rd = pathlib.Path(distributed._rendezvous_dir())
+    assert rd.parent == tmp_path and (rd.stat().st_mode & 0o777) == 0o700
+    stale = rd / "rdzv_k1.bin"
     stale.write_bytes(b"x" * 128)
     old = time.time() - 3600
     os.utime(stale, (old, old))
@@ -66,9 +68,56 @@ def test_file_rendezvous_ignores_stale_files(tmp_path, monkeypatch):
 
     with pytest.raises(_lib.JaxsimAmdError):
         distributed.file_rendezvous(1, 2, "k1", timeout_s=0.2)
-    fresh = tmp_path / "jaxsim_amd_rdzv_k2.bin"
+    fresh = rd / "rdzv_k2.bin"
     fresh.write_bytes(bytes(range(128)))
     assert distributed.file_rendezvous(1, 2, "k2", timeout_s=1.0) == bytes(range(128))
+    # rank 0 replaces whatever an earlier job left under the same key
+    assert distributed.file_rendezvous(0, 2, "k2", make_id=lambda: b"z" * 128) == b"z" * 128
+    assert distributed.file_rendezvous(1, 2, "k2", timeout_s=1.0) == b"z" * 128
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_bootstrap_dry_run(world):
+    """bench.py's own multi-rank bootstrap (job key, id file, host collective, shard bounds of 1024 x world
+    environments) launched exactly like the driver launches the multi-GPU bench, without a device."""
+    import json
+
+    cmd = [
+        sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(HERE.parent / "bench.py"),
+        "--gpus", str(world), "--steps", "20", "--warmup", "5", "--dry-run-bootstrap",
+    ]  # fmt: skip
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    env.pop("JAXSIM_AMD_LIB", None)
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(line) == 1, res.stdout
+    out = json.loads(line[0])
+    assert out["ok"] and out["n_gpus"] == world and out["global_batch"] == 1024 * world
+    assert out["shards"][0] == [0, 1024] and out["shards"][-1] == [1024 * (world - 1), 1024 * world]
+
+
+def test_all_gather_state_refuses_unequal_shards(monkeypatch):
+    class FakeComm:
+        world_size = 2
+
+        def all_gather_scalars(self, v):
+            return np.array([v, v + 1.0])
+
+        def all_gather(self, st):
+            raise AssertionError("the data path must not be reached")
+
+    class St:
+        cols, rows, tile = 5, 3, 1
+
+    class Data:
+        _state = St()
+
+    from jaxsim_amd import _lib
+
+    with pytest.raises(_lib.JaxsimAmdError, match="equal shards"):
+        distributed.all_gather_state(FakeComm(), Data())
 
 
 def test_file_collective_two_ranks(tmp_path, monkeypatch):

@@ -734,3 +734,24 @@ def dataclasses_replace_inertial(d):
     import dataclasses
 
     return dataclasses.replace(d, velocity_representation=VelRepr.Inertial)
+
+
+@pytest.mark.parametrize("name", ["cartpole", "anymal", "icub"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_actuation_limits_and_torque_speed_curve(models, name, dtype):
+    """Row B with every branch live: joints beyond their limits (spring + the `jnp.positive` damper quirk,
+    api/actuation_model.py:55-66), |sd| in the three regions of the torque-speed curve (:95-126), the clip
+    active.  The GPU twin is test_gpu_parity.py::test_actuation_limits_and_torque_speed_curve_gpu."""
+    import jaxsim_amd as ja
+
+    model = helpers.actuation_variant(models(name), seed=3)
+    N = 10
+    d = helpers.actuation_state(models, name, model, N, 21, dtype)
+    rng = np.random.default_rng(5)
+    tau = rng.uniform(-20, 20, size=(N, model.dofs())).astype(dtype)
+    ref = oracle.step(model, helpers.upcast(d), joint_force_references=tau.astype(np.float64))
+    out = eb.run(model, eb.MODE_STEP, helpers.odata_to_block(model, d), tau=tau.T)
+    assert helpers.rel_err(out, helpers.odata_to_block(model, ref)) < helpers.tol_of(dtype)
+    plain = helpers.with_params(models(name), actuation_params=ja.ActuationParams())
+    off = oracle.step(plain, helpers.upcast(d), joint_force_references=tau.astype(np.float64))
+    assert helpers.rel_err(helpers.odata_to_block(model, off), helpers.odata_to_block(model, ref)) > 10 * helpers.tol_of(dtype) + 0.02

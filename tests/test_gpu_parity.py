@@ -27,12 +27,15 @@ def to_gpu(model, d: oracle.OracleData) -> js.data.JaxSimModelData:
 def test_native_library_is_the_one_in_tree():
     from jaxsim_amd import _lib
 
+    import os
+
     assert runtime.device_count() >= 1
+    assert not os.environ.get("JAXSIM_AMD_LIB")
     assert _lib.LIB_PATH.exists() and "jaxsim_amd/csrc/libjaxsim_amd.so" in str(_lib.LIB_PATH)
-    maps = open("/proc/self/maps").read()
     _lib.load()
-    maps = open("/proc/self/maps").read()
-    assert "libjaxsim_amd.so" in maps
+    # the mapped object must be THE in-tree file (resolved path), not merely something of that name
+    mapped = {ln.split()[-1] for ln in open("/proc/self/maps") if "libjaxsim_amd" in ln}
+    assert mapped == {str(_lib.LIB_PATH.resolve())}, mapped
 
 
 @pytest.mark.parametrize("name", ALL)
@@ -970,3 +973,85 @@ def test_device_side_layout_conversion_and_array_interface(models):
         js.model.step(model, to_gpu(model, d), joint_force_references=Foreign())
     lib.jxs_free(raw)
     lib.jxs_free(back)
+
+
+# ---- row B on the device: joint-limit spring / damper and the torque-speed curve --------------------
+@pytest.mark.parametrize("name", ["cartpole", "anymal", "icub"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_actuation_limits_and_torque_speed_curve_gpu(models, name, dtype):
+    model = helpers.actuation_variant(models(name), seed=3)
+    N = 50
+    d = helpers.actuation_state(models, name, model, N, 21, dtype)
+    rng = np.random.default_rng(5)
+    tau = rng.uniform(-20, 20, size=(N, model.dofs())).astype(dtype)  # beyond torque_max: the clip is active
+    ref = oracle.step(model, helpers.upcast(d), joint_force_references=tau.astype(np.float64))
+    out = js.model.step(model, to_gpu(model, d), joint_force_references=tau)
+    assert helpers.rel_err(out.state_block(), helpers.odata_to_block(model, ref)) < helpers.tol_of(dtype)
+    # the limit terms and the clip matter at this tolerance: without them the result is far away
+    plain = helpers.with_params(models(name), actuation_params=ja.ActuationParams())
+    off = oracle.step(plain, helpers.upcast(d), joint_force_references=tau.astype(np.float64))
+    assert helpers.rel_err(helpers.odata_to_block(model, off), helpers.odata_to_block(model, ref)) > 10 * helpers.tol_of(dtype) + 0.02
+
+
+def test_actuation_known_answers_gpu(models):
+    """reference tests/test_actuation.py:11-48: tau_ref = 30 with tau_max = 10, omega_th = 1, omega_max = 2:
+    at |sd| = 1.5 the applied torque is limited to 5, at |sd| = 2.5 to 0; checked through the joint
+    acceleration of a frictionless pendulum (sdd = (tau - gravity term) / I, the same for both runs)."""
+    base = helpers.with_params(models("pendulum"), actuation_params=ja.ActuationParams(enable_friction=False))
+    lim = helpers.with_params(models("pendulum"), actuation_params=ja.ActuationParams(torque_max=10.0, omega_th=1.0, omega_max=2.0, enable_friction=False))  # fmt: skip
+    for w, expect in ((0.5, 10.0), (1.5, 5.0), (2.5, 0.0), (-1.5, 5.0)):
+        d = oracle.OracleData.build(base, joint_positions=[[0.4]], joint_velocities=[[w]])
+        dt = base.time_step
+
+        def sd_after(model, tau):
+            blk = js.model.step(model, to_gpu(model, d), joint_force_references=np.array([[tau]])).state_block()
+            return blk[model.number_of_links() - 1 + 13, 0]  # joint velocity row (13 + n + ... for n = 1)
+
+        # unclipped response is linear in tau: d(sd)/d(tau) = dt / I
+        gain = (sd_after(base, 1.0) - sd_after(base, 0.0))
+        applied = (sd_after(lim, 30.0) - sd_after(base, 0.0)) / gain
+        assert applied == pytest.approx(expect, abs=1e-9), (w, applied)
+        assert dt > 0
+
+
+def test_bench_model_step_matches_oracle_full_size_gpu():
+    """The exact model of bench.py (joint-limit springs 100 N m/rad, estimated contact parameters, joint
+    damping and Coulomb friction of the synthetic URDF) on the bench's own initial states, N = 1024."""
+    import bench
+
+    model = bench.build_model("icub23")
+    data = bench.synthetic_state(model, 1024, seed=0, dtype=np.float32)
+    blk0 = data.state_block()
+    s = blk0[7 : 7 + model.dofs()]
+    assert (np.abs(s) > 0.98).any()  # some joints start at / beyond where the +-1 rad limit spring acts
+    # push a few joints well beyond the limits so that the spring is exercised at full size
+    blk0[7 : 7 + model.dofs(), ::5] *= 1.3
+    g = js.data.JaxSimModelData.from_state_block(model, blk0)
+    out = js.model.step(model, g).state_block()
+    ref = oracle.step(model, helpers.block_to_odata(model, blk0.astype(np.float64)))
+    refb = helpers.odata_to_block(model, ref)
+    assert (np.abs(blk0[7 : 7 + model.dofs()]) > 1.0).sum() > 100
+    assert helpers.rel_err(out, refb) < helpers.FP32_TOL
+    per_env = np.max(np.abs(out - refb) / np.maximum(1.0, np.abs(refb)), axis=0)
+    assert np.median(per_env) < 5e-5
+
+
+# ---- RigidContacts: the device against the reference's UN-reduced QP statement ------------------------
+@pytest.mark.parametrize("key", ["anymal4", "box4", "icub8"])
+def test_rigid_step_matches_unreduced_statement_gpu(models, key):
+    """`test_rigid_step_matches_oracle_gpu` compares with the oracle switched to the kernel's reduced QP
+    statement.  Here the oracle solves the reference's own statement (inactive points squeezed to zero
+    between their constraints, rbda/contacts/rigid.py:331-362, 476-500) and both sides run at
+    solver_tol = 1e-10: the minimiser of the strictly convex QP is unique, so the device is tied to the
+    reference's statement, not only to the oracle's variant of it."""
+    from oracle import refrigid
+
+    assert refrigid.REDUCED_QP is False
+    name, idx, params = RIGID_CASES[key]
+    model = helpers.rigid_model(models(name), idx, build=dict(solver_options={"solver_tol": 1e-10}), **params)
+    N = 21
+    d = models.random_data(name, N, seed=5)
+    tau, f = helpers.random_inputs(model, N, 7, np.float64)
+    ref = oracle.step(model, d, link_forces=f, joint_force_references=tau)
+    out = js.model.step(model, to_gpu(model, d), link_forces=f, joint_force_references=tau)
+    assert helpers.rel_err(out.state_block(), helpers.odata_to_block(model, ref)) < 1e-7
