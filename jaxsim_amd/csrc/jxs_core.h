@@ -84,6 +84,10 @@ struct Core {
     // wave cycles parked in s_waitcnt before this was hoisted).  Loads are unconditional -- rows
     // are clamped into range and the value masked afterwards -- so no exec-mask branches.
     // ======================================================================================
+    // Stage A: everything whose address needs only the PRELOADED kernel arguments (table and state
+    // pointers, row counts: SGPRs that arrive with the wave) is issued first and unconditionally, so that
+    // these loads are in flight while the scalar loads of the rest of the argument block (KParams, the
+    // other pointers) are still on their own round trip; branches on those values come afterwards.
     const VI jtype = ln.lconsti(A.lti, LI_JTYPE);
     const VI parent = ln.lconsti(A.lti, LI_PARENT);
     const VI level = ln.lconsti(A.lti, LI_LEVEL);
@@ -91,9 +95,19 @@ struct Core {
     const VI jrow = ln.lconsti(A.lti, LI_JROW);  // joint arrays are 0-based: ii = i - 1 (rbda/aba.py:133)
     VI jump[kMaxRounds], child[kMaxChildren];
 #pragma unroll
-    for (int k = 0; k < kMaxRounds; ++k) jump[k] = (k < P.n_rounds) ? ln.lconsti(A.lti, LI_JUMP + k) : lane * 0 - 1;
+    for (int k = 0; k < kMaxRounds; ++k) jump[k] = ln.lconsti(A.lti, LI_JUMP + k);  // -1 beyond the last round
 #pragma unroll
     for (int k = 0; k < kMaxChildren; ++k) child[k] = ln.lconsti(A.lti, LI_CHILD + k);
+    // state (row D): the joint rows need the lane's joint index, one dependent round trip behind the tables
+    V pB[3], q[4], vW[3], om[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      pB[k] = ln.gload_u(A.state_in, P.row_pos + k, P.n_rows);
+      vW[k] = ln.gload_u(A.state_in, P.row_vlin + k, P.n_rows);
+      om[k] = ln.gload_u(A.state_in, P.row_vang + k, P.n_rows);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) q[k] = ln.gload_u(A.state_in, P.row_quat + k, P.n_rows);
     V ax[3], Rpre[9], ppre[3], cL[3], IL[6];
 #pragma unroll
     for (int k = 0; k < 3; ++k) ax[k] = ln.lconstf(A.ltf, LF_AXIS + k);
@@ -112,26 +126,24 @@ struct Core {
       klim = ln.lconstf(A.ltf, LF_KLIM), dlim = ln.lconstf(A.ltf, LF_DLIM);
       kc = ln.lconstf(A.ltf, LF_KC), kv = ln.lconstf(A.ltf, LF_KV);
     }
-    V Rsuc[9], psuc[3];
-    if (P.any_suc) {
+    V Rsuc[9], psuc[3];  // identity for most models (P.any_suc says whether they are used): three wide loads
 #pragma unroll
-      for (int k = 0; k < 9; ++k) Rsuc[k] = ln.lconstf(A.ltf, LF_RSUC + k);
+    for (int k = 0; k < 9; ++k) Rsuc[k] = ln.lconstf(A.ltf, LF_RSUC + k);
 #pragma unroll
-      for (int k = 0; k < 3; ++k) psuc[k] = ln.lconstf(A.ltf, LF_PSUC + k);
-    }
-    // state (row D)
+    for (int k = 0; k < 3; ++k) psuc[k] = ln.lconstf(A.ltf, LF_PSUC + k);
+    // collidable-point tables of chunk 0 (further chunks are loaded inside the contact loop); the tables
+    // hold at least one (empty) slot per lane, so the load is legal whatever the contact model
+    PointSlot ps0;
+    if (kStep) load_slot_tables(lane, 0, ps0);
     const VI jrow_c = vsel(jrow >= 0, jrow, lane * 0);
     V s = ln.gload(A.state_in, jrow_c + P.row_s, P.n_rows);
     V sd = ln.gload(A.state_in, jrow_c + P.row_sd, P.n_rows);
-    V pB[3], q[4], vW[3], om[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      pB[k] = ln.gload_u(A.state_in, P.row_pos + k, P.n_rows);
-      vW[k] = ln.gload_u(A.state_in, P.row_vlin + k, P.n_rows);
-      om[k] = ln.gload_u(A.state_in, P.row_vang + k, P.n_rows);
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) q[k] = ln.gload_u(A.state_in, P.row_quat + k, P.n_rows);
+    ln.fence();
+    ln.stamp_after(A, 11, jrow);   // profiling build: index tables arrived
+    ln.stamp_after(A, 12, q[3]);   // base rows of the state arrived
+    ln.stamp_after(A, 13, ps0.hd); // point-slot tables arrived
+    ln.stamp_after(A, 14, sd);     // joint rows of the state arrived (dependent on the index table)
+    // Stage B: loads that need the rest of the argument block.
     if (MODE == MODE_ID && A.id_zero_vel) {
       sd = V(T(0));
 #pragma unroll
@@ -144,13 +156,10 @@ struct Core {
 #pragma unroll
       for (int k = 0; k < 6; ++k) f6in[k] = ln.gload(A.link_f, lrow + k, P.nL * 6);
     }
-    // collidable-point tables of chunk 0 (further chunks are loaded inside the contact loop)
     RowTabs rt;
     const bool with_rows = P.row_mode && (kStep || MODE == MODE_FD) && !kRigid;
     if (with_rows) load_row_tabs(rt);
-    PointSlot ps0;
     const bool with_contacts = (kStep && !kRigid) && P.n_chunks > 0;  // soft contacts (state m)
-    if (with_contacts || (kRigid && P.n_chunks > 0)) load_slot_tables(lane, 0, ps0);
 
     const VM is_joint = jtype != 0;
     const VM is_rev = jtype == 1;
@@ -985,12 +994,12 @@ struct Core {
   JXS_HD void load_row_tabs(RowTabs& rt) const {
 #pragma unroll
     for (int Lv = 0; Lv < kRowLevels; ++Lv) {
-      rt.rec[Lv] = ln.lconsti(A.rti, RT_REC + Lv);
-      rt.ppull[Lv] = ln.lconsti(A.rti, RT_PPULL + Lv);
+      rt.rec[Lv] = ln.rconsti(A.rti, RT_REC + Lv);
+      rt.ppull[Lv] = ln.rconsti(A.rti, RT_PPULL + Lv);
 #pragma unroll
-      for (int k = 0; k < kRowExtra; ++k) rt.pull[Lv][k] = ln.lconsti(A.rti, RT_PULL + Lv * kRowExtra + k);
+      for (int k = 0; k < kRowExtra; ++k) rt.pull[Lv][k] = ln.rconsti(A.rti, RT_PULL + Lv * kRowExtra + k);
     }
-    rt.fcbits = ln.lconsti(A.rti, RT_FC);
+    rt.fcbits = ln.rconsti(A.rti, RT_FC);
   }
 
   struct RowLevel {
@@ -1179,13 +1188,16 @@ struct Core {
     V Lp[3], m[3], md[3];  // md: deformation rate of the last evaluation (chunk 0)
   };
   JXS_HD void load_slot_tables(const VI& lane, int ch, PointSlot& ps) const {
-    const VI slot = lane + ch * G;
-    ps.body = ln.ploadi(A.pti, PI_BODY, P.n_slots, slot);
-    ps.prow = ln.ploadi(A.pti, PI_ROW, P.n_slots, slot);
-    ps.tail = ln.ploadi(A.pti, PI_TAIL, P.n_slots, slot);
+    const unsigned char* c = A.chunks + (size_t)ch * chunk_bytes<T>(G);
+    const int* pti = reinterpret_cast<const int*>(c);
+    const T* ptf = reinterpret_cast<const T*>(c + G * kPtStride * 4);
+    const int* head = reinterpret_cast<const int*>(c + G * kPtStride * (4 + (int)sizeof(T)));
+    ps.body = ln.ploadi(pti, PI_BODY, lane);
+    ps.prow = ln.ploadi(pti, PI_ROW, lane);
+    ps.tail = ln.ploadi(pti, PI_TAIL, lane);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) ps.Lp[k] = ln.ploadf(A.ptf, PF_POS + k, P.n_slots, slot);
-    ps.hd = ln.lconsti(A.head, ch);
+    for (int k = 0; k < 3; ++k) ps.Lp[k] = ln.ploadf(ptf, PF_POS + k, lane);
+    ps.hd = ln.hconsti(head, 0);
   }
   JXS_HD void load_slot_state(PointSlot& ps) const {
     // empty slots carry row 0: the load is in range and its value is masked by `valid` later
@@ -1328,43 +1340,47 @@ struct Core {
     cross(rc, w6, w6 + 3);
   }
 
+  // One chunk of G collidable points.  Chunk 0 is carried in registers (state loaded up front, integrated
+  // by run()); further chunks go through memory every step (rollouts are not fused then).  Two separate
+  // instantiations instead of one loop that selects between `ps0` and a local slot: the select would be a
+  // pointer phi that keeps the slot structs in scratch memory.
+  template <bool kFirst>
+  JXS_HD void contact_chunk(const VI& lane, PointSlot& ps, const V* R, const V* r, const V* vl, const V* va,
+                            const V* pB, const V* doff, const V* vBc, const V* om, V* fl, V* fa) const {
+    const V zero = V(T(0));
+    const VM valid = ps.body >= 0;
+    V m[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) m[k] = vsel(valid, ps.m[k], zero);
+    // kinematics of the parent link
+    V Rb[9], rb[3], vbl[3], vba[3];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) Rb[e] = ln.shfl(R[e], ps.body);
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+      rb[e] = ln.shfl(r[e], ps.body);
+      vbl[e] = ln.shfl(vl[e], ps.body);
+      vba[e] = ln.shfl(va[e], ps.body);
+    }
+    ln.fence();
+    V w6[6], md[3];
+    point_physics(valid, ps.Lp, m, Rb, rb, vbl, vba, pB, doff, vBc, om, w6, md);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      if (kFirst) ps.md[k] = md[k];
+      else ln.gstore(A.state_out, ps.prow * 3 + (P.row_m + k), m[k] + P.dt * md[k], valid, P.n_rows);
+    }
+    link_wrench_sums(lane, ps.tail, ps.hd, w6, fl, fa);
+  }
+
   JXS_HD void contacts(const VI& lane, PointSlot& ps0, const V* R, const V* r, const V* vl, const V* va,
                        const V* pB, const V* doff, const V* vBc, const V* om, V* fl, V* fa) const {
-    const V zero = V(T(0));
-    for (int ch = 0; ch < P.n_chunks; ++ch) {
-      PointSlot ps = ps0;
-      if (ch > 0) {  // further chunks go through memory every step (rollouts are not fused then)
-        load_slot_tables(lane, ch, ps);
-        load_slot_state(ps);
-      }
-      const VI body = ps.body, prow = ps.prow, tail = ps.tail;
-      const VM valid = body >= 0;
-      V Lp[3], m[3];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        Lp[k] = ps.Lp[k];
-        m[k] = vsel(valid, ps.m[k], zero);
-      }
-      // kinematics of the parent link
-      V Rb[9], rb[3], vbl[3], vba[3];
-#pragma unroll
-      for (int e = 0; e < 9; ++e) Rb[e] = ln.shfl(R[e], body);
-#pragma unroll
-      for (int e = 0; e < 3; ++e) {
-        rb[e] = ln.shfl(r[e], body);
-        vbl[e] = ln.shfl(vl[e], body);
-        vba[e] = ln.shfl(va[e], body);
-      }
-      ln.fence();
-      V w6[6], md[3];
-      point_physics(valid, Lp, m, Rb, rb, vbl, vba, pB, doff, vBc, om, w6, md);
-#pragma unroll
-      for (int k = 0; k < 3; ++k)
-      {
-        if (ch == 0) ps0.md[k] = md[k];  // chunk 0 is carried in registers, integrated by run()
-        else ln.gstore(A.state_out, prow * 3 + (P.row_m + k), m[k] + P.dt * md[k], valid, P.n_rows);
-      }
-      link_wrench_sums(lane, tail, ps.hd, w6, fl, fa);
+    contact_chunk<true>(lane, ps0, R, r, vl, va, pB, doff, vBc, om, fl, fa);  // sets ps0.md
+    for (int ch = 1; ch < P.n_chunks; ++ch) {
+      PointSlot ps;
+      load_slot_tables(lane, ch, ps);
+      load_slot_state(ps);
+      contact_chunk<false>(lane, ps, R, r, vl, va, pB, doff, vBc, om, fl, fa);
     }
   }
 

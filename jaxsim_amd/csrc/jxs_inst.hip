@@ -7,5 +7,5 @@
 #endif
 
 namespace jxs_launch {
-template hipError_t launch_g<JXS_INST_T, JXS_INST_MODE>(int, const jxs::KParams<JXS_INST_T>&, const jxs::KArgs<JXS_INST_T>&, hipStream_t);
+template hipError_t launch_g<JXS_INST_T, JXS_INST_MODE>(int, const jxs::KParams<JXS_INST_T>&, const unsigned char*, const jxs::KArgs<JXS_INST_T>&, hipStream_t);
 }

@@ -10,22 +10,47 @@
 
 namespace jxs_launch {
 
-// The first 16 dwords of the kernel arguments are PRELOADED into SGPRs by the command processor
-// (-mllvm -amdgpu-kernarg-preload-count=16; gfx940+): the pointers and row counts every first-batch
-// load address needs arrive with the wave instead of after a scalar-load round trip.  The structs that
-// follow carry the same values (and everything else); the preloaded copies simply replace them.
+// Kernel arguments.  The first 16 dwords are PRELOADED into SGPRs by the command processor
+// (-mllvm -amdgpu-kernarg-preload-count=16; gfx940+) and arrive with the wave: the state pointers, the
+// inputs of `step`, the batch size, and ONE pointer to the device model block (jxs_params.h) that holds
+// the wave-uniform parameters and every table.  `step` never reads the kernarg segment itself: measured
+// with arrival stamps, a scalar load from it costs a lone wave ~1600 cycles (it is host-visible memory),
+// while the model block is ordinary device memory (L2-resident after the first wave).  The arguments of
+// the other entry points (accelerations in / out, kinematics out) stay in the tail struct.
+template <typename T>
+struct KTail {
+  const T* in_a;
+  T* out_a;
+  T* out_H;
+  T* out_V;
+  T* out_tau;
+  int id_zero_vel;
+  long long* dbg;
+};
+
 template <typename T, int G, int MODE>
-__global__ __launch_bounds__(64) void jxs_kernel(const T* pre_state_in, const T* pre_ltf, const int* pre_lti,
-                                                 const T* pre_ptf, const int* pre_pti, const int* pre_head,
-                                                 int pre_n_rows, int pre_n, int pre_n_slots, int pre_N,
-                                                 const jxs::KParams<T> P_, const jxs::KArgs<T> A_) {
-  jxs::KParams<T> P = P_;
-  jxs::KArgs<T> A = A_;
-  A.state_in = pre_state_in, A.ltf = pre_ltf, A.lti = pre_lti, A.ptf = pre_ptf, A.pti = pre_pti, A.head = pre_head;
-  A.N = pre_N;
-  P.n_rows = pre_n_rows, P.n = pre_n, P.n_slots = pre_n_slots;
+__global__ __launch_bounds__(64) void jxs_kernel(const T* pre_state_in, T* pre_state_out, const unsigned char* __restrict__ pre_mblk,
+                                                 const T* pre_tau, const T* pre_link_f, int pre_N, int pre_n_rows,
+                                                 int pre_n, int pre_force_repr, int pre_n_steps,
+                                                 const KTail<T> tail) {
+  // (14 dwords are preloaded in practice: the last two ints are only needed late -- with link forces / in
+  // the fused rollout -- and may come from the kernarg segment)
+  // wave-uniform parameters: scalar loads from the model block (uniform address, never written by the
+  // kernel: `__restrict__` lets the compiler prove it and use s_load)
+  jxs::KParams<T> P = *reinterpret_cast<const jxs::KParams<T>*>(pre_mblk);
+  jxs::KArgs<T> A{};
+  A.state_in = pre_state_in, A.state_out = pre_state_out, A.tau = pre_tau, A.link_f = pre_link_f;
+  A.N = pre_N, A.force_repr = pre_force_repr, A.n_steps = pre_n_steps;
+  A.ltf = reinterpret_cast<const T*>(pre_mblk + jxs::mblk_off_ltf<T>());
+  A.lti = reinterpret_cast<const int*>(pre_mblk + jxs::mblk_off_lti<T>(G));
+  A.rti = reinterpret_cast<const int*>(pre_mblk + jxs::mblk_off_rti<T>(G));
+  A.chunks = pre_mblk + jxs::mblk_off_chunks<T>(G);
+  A.in_a = tail.in_a, A.out_a = tail.out_a, A.out_H = tail.out_H, A.out_V = tail.out_V, A.out_tau = tail.out_tau;
+  A.id_zero_vel = tail.id_zero_vel, A.dbg = tail.dbg;
+  // the state-block rows of SURVEY section 8(a) row D, derived from the preloaded joint count instead of loaded
+  P.n_rows = pre_n_rows, P.n = pre_n;
   P.row_pos = 0, P.row_quat = 3, P.row_s = 7, P.row_vlin = 7 + pre_n, P.row_vang = 10 + pre_n, P.row_sd = 13 + pre_n;
-  P.row_m = 13 + 2 * pre_n;  // the state-block rows of SURVEY section 8(a) row D, derived instead of loaded
+  P.row_m = 13 + 2 * pre_n;
   extern __shared__ __align__(16) unsigned char jxs_smem[];
   const jxs::DeviceLanes<T, G> ln(A.N, reinterpret_cast<T*>(jxs_smem),
                                   (MODE == jxs::MODE_STEP_RIGID || MODE == jxs::MODE_STEP_RK4_RIGID) ? jxs::rigid_lds_words_per_env(P.n_cp, P.rigid)
@@ -34,8 +59,9 @@ __global__ __launch_bounds__(64) void jxs_kernel(const T* pre_state_in, const T*
   core.template run<MODE>();
 }
 
+// `mblk`: device model block of the model (KParams | tables), `P`: its host copy (launch geometry only)
 template <typename T, int G, int MODE>
-hipError_t launch_one(const jxs::KParams<T>& P, const jxs::KArgs<T>& A, hipStream_t s) {
+hipError_t launch_one(const jxs::KParams<T>& P, const unsigned char* mblk, const jxs::KArgs<T>& A, hipStream_t s) {
   const int envs_per_wave = 64 / G;  // = the tile of every batched array: block b owns tile b
   const int blocks = (A.N + envs_per_wave - 1) / envs_per_wave;
   const bool rows = P.row_mode && (MODE == jxs::MODE_STEP || MODE == jxs::MODE_ROLLOUT || MODE == jxs::MODE_FD ||
@@ -49,19 +75,20 @@ hipError_t launch_one(const jxs::KParams<T>& P, const jxs::KArgs<T>& A, hipStrea
       if (e != hipSuccess) return e;
     }
   }
-  hipLaunchKernelGGL((jxs_kernel<T, G, MODE>), dim3(blocks), dim3(64), lds_bytes, s, A.state_in, A.ltf, A.lti, A.ptf, A.pti,
-                     A.head, P.n_rows, P.n, P.n_slots, A.N, P, A);
+  const KTail<T> tail{A.in_a, A.out_a, A.out_H, A.out_V, A.out_tau, A.id_zero_vel, A.dbg};
+  hipLaunchKernelGGL((jxs_kernel<T, G, MODE>), dim3(blocks), dim3(64), lds_bytes, s, A.state_in, A.state_out, mblk, A.tau,
+                     A.link_f, A.N, P.n_rows, P.n, A.force_repr, A.n_steps, tail);
   return hipGetLastError();
 }
 
 template <typename T, int MODE>
-hipError_t launch_g(int G, const jxs::KParams<T>& P, const jxs::KArgs<T>& A, hipStream_t s) {
+hipError_t launch_g(int G, const jxs::KParams<T>& P, const unsigned char* mblk, const jxs::KArgs<T>& A, hipStream_t s) {
   switch (G) {
-    case 4: return launch_one<T, 4, MODE>(P, A, s);
-    case 8: return launch_one<T, 8, MODE>(P, A, s);
-    case 16: return launch_one<T, 16, MODE>(P, A, s);
-    case 32: return launch_one<T, 32, MODE>(P, A, s);
-    default: return launch_one<T, 64, MODE>(P, A, s);
+    case 4: return launch_one<T, 4, MODE>(P, mblk, A, s);
+    case 8: return launch_one<T, 8, MODE>(P, mblk, A, s);
+    case 16: return launch_one<T, 16, MODE>(P, mblk, A, s);
+    case 32: return launch_one<T, 32, MODE>(P, mblk, A, s);
+    default: return launch_one<T, 64, MODE>(P, mblk, A, s);
   }
 }
 

@@ -104,6 +104,17 @@ struct DeviceLanes {
 #endif
   }
 
+  // developer profiling build: stamp `i` once `value` has arrived (the dummy use makes the compiler wait for it)
+  template <class KA, class X>
+  __device__ __forceinline__ void stamp_after(const KA& A, int i, X value) const {
+#ifdef JXS_PHASE_TIMING
+    asm volatile("" ::"v"(value));
+    stamp(A, i);
+#else
+    (void)A, (void)i, (void)value;
+#endif
+  }
+
   __device__ __forceinline__ int src4(int src) const { return ((src & (G - 1)) << 2) + base4_; }
   __device__ __forceinline__ float shfl(float x, int src) const {
     return __int_as_float(__builtin_amdgcn_ds_bpermute(src4(src), __float_as_int(x)));
@@ -242,16 +253,17 @@ struct DeviceLanes {
     if (mask && env_ok_) out[(size_t)env_ * stride + idx] = v;
   }
 
-  // per-lane model constants
-  __device__ __forceinline__ V lconstf(const T* tbl, int field) const { return tbl[field * G + lane_]; }
-  __device__ __forceinline__ VI lconsti(const int* tbl, int field) const { return tbl[field * G + lane_]; }
-  // per-slot point tables
-  __device__ __forceinline__ V ploadf(const T* tbl, int field, int n_slots, int slot) const {
-    return tbl[field * n_slots + slot];
-  }
-  __device__ __forceinline__ VI ploadi(const int* tbl, int field, int n_slots, int slot) const {
-    return tbl[field * n_slots + slot];
-  }
+  // per-lane model constants: lane-major records (jxs_params.h), 16-byte aligned -- the loads of
+  // consecutive fields are merged into dwordx4 / dwordx2 loads by the compiler
+  template <typename U>
+  static __device__ __forceinline__ const U* al16(const U* p) { return static_cast<const U*>(__builtin_assume_aligned(p, 16)); }
+  __device__ __forceinline__ V lconstf(const T* tbl, int field) const { return al16(tbl)[lane_ * kLtfStride + field]; }
+  __device__ __forceinline__ VI lconsti(const int* tbl, int field) const { return al16(tbl)[lane_ * kLtiStride + field]; }
+  __device__ __forceinline__ VI rconsti(const int* tbl, int field) const { return al16(tbl)[lane_ * kRtiStride + field]; }
+  __device__ __forceinline__ VI hconsti(const int* head, int chunk) const { return head[chunk * G + lane_]; }
+  // per-slot point tables (slot-major, stride 4)
+  __device__ __forceinline__ V ploadf(const T* tbl, int field, int slot) const { return al16(tbl)[slot * kPtStride + field]; }
+  __device__ __forceinline__ VI ploadi(const int* tbl, int field, int slot) const { return al16(tbl)[slot * kPtStride + field]; }
   // Batched arrays are tile-interleaved: [N/T][rows][T] with T = 64/G environments per tile = the
   // environments of ONE wave.  A wave therefore touches one contiguous
   // rows*T*sizeof(T) span per array and a load instruction whose lanes read consecutive rows is

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <limits>
 #include <string>
 #include <vector>
@@ -20,10 +21,21 @@ struct Packed {
   int G = 0;
   std::vector<T> ltf;
   std::vector<int> lti;
-  std::vector<T> ptf;
-  std::vector<int> pti;
-  std::vector<int> head;
+  std::vector<T> ptf;     // [slots][kPtStride]   (staging: the kernels read `chunks`)
+  std::vector<int> pti;   // [slots][kPtStride]
+  std::vector<int> head;  // [chunks][G]
+  std::vector<unsigned char> chunks;  // point-chunk records (jxs_params.h)
   std::vector<int> rti;
+  // the device model block (jxs_params.h): KParams | ltf | lti | rti | chunks
+  std::vector<unsigned char> block() const {
+    std::vector<unsigned char> b((size_t)mblk_off_chunks<T>(G) + chunks.size(), 0);
+    std::memcpy(b.data(), &P, sizeof(P));
+    std::memcpy(b.data() + mblk_off_ltf<T>(), ltf.data(), ltf.size() * sizeof(T));
+    std::memcpy(b.data() + mblk_off_lti<T>(G), lti.data(), lti.size() * sizeof(int));
+    std::memcpy(b.data() + mblk_off_rti<T>(G), rti.data(), rti.size() * sizeof(int));
+    std::memcpy(b.data() + mblk_off_chunks<T>(G), chunks.data(), chunks.size());
+    return b;
+  }
   int n_disabled = 0;
   int integrator = 0;  // JXS_INTEGRATOR_*
 };
@@ -216,10 +228,10 @@ std::string pack_model(const jxs_model_desc& d, Packed<T>& out) {
   P.quat_K = (T)0.1;
 
   // per-lane tables
-  out.ltf.assign((size_t)LF_COUNT * G, T(0));
-  out.lti.assign((size_t)LI_COUNT * G, 0);
-  auto F = [&](int f, int lane) -> T& { return out.ltf[(size_t)f * G + lane]; };
-  auto I = [&](int f, int lane) -> int& { return out.lti[(size_t)f * G + lane]; };
+  out.ltf.assign((size_t)kLtfStride * G, T(0));
+  out.lti.assign((size_t)kLtiStride * G, 0);
+  auto F = [&](int f, int lane) -> T& { return out.ltf[(size_t)lane * kLtfStride + f]; };
+  auto I = [&](int f, int lane) -> int& { return out.lti[(size_t)lane * kLtiStride + f]; };
   const T big = std::numeric_limits<T>::max();
   auto clampT = [&](double x) -> T {
     if (x >= (double)big) return big;
@@ -293,20 +305,22 @@ std::string pack_model(const jxs_model_desc& d, Packed<T>& out) {
   P.any_suc = any_suc;
 
   // point slots
-  out.ptf.assign((size_t)PF_COUNT * std::max(n_slots, 1), T(0));
-  out.pti.assign((size_t)PI_COUNT * std::max(n_slots, 1), 0);
+  // at least one (empty) slot per lane: the kernels load the chunk-0 slot of every lane unconditionally
+  const int n_slots_alloc = std::max(n_slots, G);
+  out.ptf.assign((size_t)kPtStride * n_slots_alloc, T(0));
+  out.pti.assign((size_t)kPtStride * n_slots_alloc, 0);
   out.head.assign((size_t)std::max(n_chunks, 1) * G, -1);
   int max_seg = 1, seg_dpp = 1;
-  for (int s = 0; s < n_slots; ++s) {
-    out.pti[(size_t)PI_BODY * n_slots + s] = -1;
-    out.pti[(size_t)PI_ROW * n_slots + s] = 0;
-    out.pti[(size_t)PI_TAIL * n_slots + s] = 0;
+  for (int s = 0; s < n_slots_alloc; ++s) {
+    out.pti[(size_t)s * kPtStride + PI_BODY] = -1;
+    out.pti[(size_t)s * kPtStride + PI_ROW] = 0;
+    out.pti[(size_t)s * kPtStride + PI_TAIL] = 0;
   }
   for (int s = 0; s < n_en; ++s) {
     const int k = en[s];
-    out.pti[(size_t)PI_BODY * n_slots + s] = lane_of[d.point_body[k]];
-    out.pti[(size_t)PI_ROW * n_slots + s] = k;
-    for (int c = 0; c < 3; ++c) out.ptf[(size_t)(PF_POS + c) * n_slots + s] = (T)d.point_position[3 * k + c];
+    out.pti[(size_t)s * kPtStride + PI_BODY] = lane_of[d.point_body[k]];
+    out.pti[(size_t)s * kPtStride + PI_ROW] = k;
+    for (int c = 0; c < 3; ++c) out.ptf[(size_t)s * kPtStride + PF_POS + c] = (T)d.point_position[3 * k + c];
   }
   for (int ch = 0; ch < n_chunks; ++ch) {
     int s = ch * G;
@@ -317,7 +331,7 @@ std::string pack_model(const jxs_model_desc& d, Packed<T>& out) {
       while (e + 1 < end && d.point_body[en[e + 1]] == body) ++e;
       out.head[(size_t)ch * G + lane_of[body]] = s - ch * G;
       if ((s - ch * G) / 16 != (e - ch * G) / 16) seg_dpp = 0;
-      for (int t = s; t <= e; ++t) out.pti[(size_t)PI_TAIL * n_slots + t] = e - t;
+      for (int t = s; t <= e; ++t) out.pti[(size_t)t * kPtStride + PI_TAIL] = e - t;
       max_seg = std::max(max_seg, e - s + 1);
       s = e + 1;
     }
@@ -326,7 +340,7 @@ std::string pack_model(const jxs_model_desc& d, Packed<T>& out) {
   P.row_mode = 0;
   P.row_cross_levels = 0;
   P.row_ppull_levels = 0;
-  out.rti.assign((size_t)RT_COUNT * G, -1);
+  out.rti.assign((size_t)kRtiStride * G, -1);
   {
     const int n_slots_row = G / 8;
     bool ok = G >= 8 && max_depth < kRowLevels && max_depth >= 1;
@@ -358,7 +372,7 @@ std::string pack_model(const jxs_model_desc& d, Packed<T>& out) {
             used[s2] = 1;
           }
       }
-      auto RI = [&](int f, int lane) -> int& { return out.rti[(size_t)f * G + lane]; };
+      auto RI = [&](int f, int lane) -> int& { return out.rti[(size_t)lane * kRtiStride + f]; };
       for (int lane = 0; lane < G; ++lane) RI(RT_FC, lane) = 0;
       for (int i = 0; i < nL; ++i) {
         const int L = level[i], s2 = slot[i];
@@ -382,6 +396,18 @@ std::string pack_model(const jxs_model_desc& d, Packed<T>& out) {
         }
       }
       P.row_mode = 1;
+    }
+  }
+  // point-chunk records
+  {
+    const int n_ch = std::max(n_chunks, 1);
+    const size_t cb = (size_t)chunk_bytes<T>(G);
+    out.chunks.assign(n_ch * cb, 0);
+    for (int ch = 0; ch < n_ch; ++ch) {
+      unsigned char* c = out.chunks.data() + ch * cb;
+      std::memcpy(c, out.pti.data() + (size_t)ch * G * kPtStride, (size_t)G * kPtStride * sizeof(int));
+      std::memcpy(c + (size_t)G * kPtStride * 4, out.ptf.data() + (size_t)ch * G * kPtStride, (size_t)G * kPtStride * sizeof(T));
+      std::memcpy(c + (size_t)G * kPtStride * (4 + sizeof(T)), out.head.data() + (size_t)ch * G, (size_t)G * sizeof(int));
     }
   }
   int seg_steps = 0;

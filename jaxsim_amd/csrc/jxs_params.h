@@ -25,26 +25,31 @@ constexpr int kMaxDepth = 63;    // max tree depth supported by the level loops
 constexpr int kMaxChildren = 6;  // max children of one link (statically unrolled gather)
 constexpr int kMaxRounds = 6;    // pointer-jumping rounds: ceil(log2(depth+1)) <= 6
 
-// ---- per-lane float table fields: ltf[field * G + lane] ------------------------------------
+// ---- per-lane tables are LANE-MAJOR: tbl[lane * stride + field], strides multiples of 4 words and the
+// tables 16-byte aligned, so that one lane's record is read with a few wide loads (global_load_dwordx4)
+// instead of one dword load per field (round 1: ~110 table loads per wave, each costing a lone wave its
+// issue slot + address arithmetic; now ~30).  Both environments of a wave read the same addresses.
+// ---- per-lane float table fields: ltf[lane * kLtfStride + field] ---------------------------
 enum LaneF : int {
   LF_RPRE = 0,    // 9: rotation of lambda_H_pre (row-major)   math/joint_model.py:70-98
   LF_PPRE = 9,    // 3: translation of lambda_H_pre
-  LF_RSUC = 12,   // 9: rotation of suc_H_i
-  LF_PSUC = 21,   // 3: translation of suc_H_i
-  LF_AXIS = 24,   // 3: unit joint axis
-  LF_MASS = 27,   // 1
-  LF_COM = 28,    // 3: CoM in the link frame
-  LF_ICOM = 31,   // 6: I_CoM xx,xy,xz,yy,yz,zz
-  LF_KC = 37,     // friction_static       kin_dyn_parameters.py:502-571
-  LF_KV = 38,     // friction_viscous
-  LF_SMIN = 39,   // position_limits_min
-  LF_SMAX = 40,   // position_limits_max
-  LF_KLIM = 41,   // position_limit_spring
-  LF_DLIM = 42,   // position_limit_damper
-  LF_COUNT = 43
+  LF_AXIS = 12,   // 3: unit joint axis
+  LF_MASS = 15,   // 1
+  LF_COM = 16,    // 3: CoM in the link frame
+  LF_ICOM = 19,   // 6: I_CoM xx,xy,xz,yy,yz,zz
+  LF_KC = 25,     // friction_static       kin_dyn_parameters.py:502-571
+  LF_KV = 26,     // friction_viscous
+  LF_SMIN = 27,   // position_limits_min
+  LF_SMAX = 28,   // position_limits_max
+  LF_KLIM = 29,   // position_limit_spring
+  LF_DLIM = 30,   // position_limit_damper
+  LF_RSUC = 32,   // 9: rotation of suc_H_i (read only when some suc_H_i is not the identity)
+  LF_PSUC = 41,   // 3: translation of suc_H_i
+  LF_COUNT = 44
 };
+constexpr int kLtfStride = LF_COUNT;
 
-// ---- per-lane int table fields: lti[field * G + lane] --------------------------------------
+// ---- per-lane int table fields: lti[lane * kLtiStride + field] -----------------------------
 enum LaneI : int {
   LI_JTYPE = 0,   // 0 = none (base / padding lane), 1 revolute, 2 prismatic
   LI_PARENT = 1,  // parent lane, -1 for the base and padding lanes
@@ -55,8 +60,9 @@ enum LaneI : int {
   LI_JROW = LI_LINK + 1,              // joint row (link index - 1), -1 for the base / padding lanes
   LI_COUNT = LI_JROW + 1
 };
+constexpr int kLtiStride = (LI_COUNT + 3) / 4 * 4;
 
-// ---- per-point-slot tables (slots = n_chunks * G): ptf[field * slots + slot] etc. ----------
+// ---- per-point-slot tables (slots = n_chunks * G), slot-major with stride 4: ptf[slot * 4 + field] ----
 enum PointF : int { PF_POS = 0, PF_COUNT = 3 };
 enum PointI : int {
   PI_BODY = 0,   // lane of the parent link, -1 for an empty slot
@@ -64,9 +70,15 @@ enum PointI : int {
   PI_TAIL = 2,   // number of slots after this one in the same (chunk, link) segment
   PI_COUNT = 3
 };
-// head[chunk * G + lane]: slot-lane of the first point of link `lane` in that chunk, -1 if none.
+constexpr int kPtStride = 4;
+// The point tables are stored per CHUNK of G slots, one fixed-size record per chunk (so that the address of
+// the chunk-0 tables needs nothing but the table base and the compile-time G):
+//   pti[G][kPtStride] int | ptf[G][kPtStride] T | head[G] int
+// head[lane]: slot-lane of the first point of link `lane` in that chunk, -1 if none.
+template <typename T>
+JXS_HD constexpr int chunk_bytes(int G) { return G * kPtStride * 4 + G * kPtStride * (int)sizeof(T) + G * 4; }
 
-// ---- row-distributed ABA: per-lane int table rti[field * G + lane] ---
+// ---- row-distributed ABA: per-lane int table rti[lane * kRtiStride + field] ---
 // In this phase lane = 8 * slot + row: the 8 lanes of a slot hold the 6 rows (2 idle) of the
 // articulated inertia of ONE link per tree level; a first child inherits its parent's slot, so a
 // serial chain never leaves its lanes.
@@ -80,6 +92,7 @@ enum RowI : int {
   RT_PPULL = RT_PULL + kRowLevels * kRowExtra,  // [kRowLevels] lane holding the parent's row, -1 = same lane
   RT_COUNT = RT_PPULL + kRowLevels
 };
+constexpr int kRtiStride = (RT_COUNT + 3) / 4 * 4;  // rti[lane * kRtiStride + field]
 // LDS record layout (words): 0..35 M (6x6), 36..41 S, 42..47 c, 48..53 pA, 54 tau
 // exchange area after the G records: base rows 42 words, a0 6 words, sdd G words
 enum RowLds : int { RL_M = 0, RL_S = 36, RL_C = 42, RL_PA = 48, RL_TAU = 54, RL_SDD = 55 };
@@ -165,12 +178,10 @@ struct KParams {
 // Device/host pointers handed to the core for one launch.
 template <typename T>
 struct KArgs {
-  const T* ltf;        // [LF_COUNT][G]
-  const int* lti;      // [LI_COUNT][G]
-  const T* ptf;        // [PF_COUNT][n_slots]
-  const int* pti;      // [PI_COUNT][n_slots]
-  const int* head;     // [n_chunks][G]
-  const int* rti;      // [RT_COUNT][G] row-distributed ABA tables (row_mode only)
+  const T* ltf;        // [G][kLtfStride]
+  const int* lti;      // [G][kLtiStride]
+  const unsigned char* chunks;  // [max(n_chunks, 1)] point-chunk records (chunk_bytes<T>(G) each)
+  const int* rti;      // [G][kRtiStride] row-distributed ABA tables (row_mode only)
   const T* state_in;   // [n_rows][N]
   T* state_out;        // [n_rows][N] (may alias state_in)
   const T* tau;        // [n][N] or null            joint_force_references / joint_forces
@@ -186,5 +197,19 @@ struct KArgs {
   int id_zero_vel;     // MODE_ID: evaluate at zero velocity (gravity term g(q), api/model.py:1897-1931)
   long long* dbg;      // developer builds (-DJXS_PHASE_TIMING): [blocks][16] cycle stamps, else null
 };
+
+// ---- device model block: ONE allocation per model that the kernels address from a single pointer -------
+//   KParams<T> (padded to 256 B) | ltf | lti | rti | point-chunk records
+// The wave-uniform parameters are read from it with scalar loads (device memory, L2-resident after the
+// first wave); round 1 passed them by value as kernel arguments, and the kernarg segment turned out to be a
+// ~1600-cycle round trip per wave (measured with arrival stamps).
+template <typename T>
+JXS_HD constexpr int mblk_off_ltf() { return ((int)sizeof(KParams<T>) + 255) / 256 * 256; }
+template <typename T>
+JXS_HD constexpr int mblk_off_lti(int G) { return mblk_off_ltf<T>() + G * kLtfStride * (int)sizeof(T); }
+template <typename T>
+JXS_HD constexpr int mblk_off_rti(int G) { return mblk_off_lti<T>(G) + G * kLtiStride * 4; }
+template <typename T>
+JXS_HD constexpr int mblk_off_chunks(int G) { return mblk_off_rti<T>(G) + G * kRtiStride * 4; }
 
 }  // namespace jxs

@@ -22,7 +22,8 @@ reference applies when it turns a description into its static tables
   default to +-finfo.max, ``friction_static <- dynamics/@friction``,
   ``friction_viscous <- dynamics/@damping`` (``rod/parser.py:234-277``);
 * collision boxes -> 8 corner points (4 bottom then 4 top), spheres -> 50-point
-  Fibonacci lattice, cylinders/meshes skipped
+  Fibonacci lattice, cylinders skipped, meshes -> vertices when JAXSIM_COLLISION_MESH_ENABLED is set
+  (``parsers/meshes.py``), skipped otherwise like the reference default
   (``parsers/rod/utils.py:102-225``, ``rod/parser.py:327-357``); points are
   listed link by link in file order, shapes in order.
 """
@@ -36,6 +37,7 @@ import xml.etree.ElementTree as ET
 import numpy as np
 
 from .. import _hostmath as hm
+from . import meshes
 
 FIXED, REVOLUTE, PRISMATIC = 0, 1, 2  # src/jaxsim/parsers/descriptions/joint.py JointType
 
@@ -168,6 +170,7 @@ def parse_urdf(
     is_path: bool | None = None,
     considered_joints: list[str] | tuple[str, ...] | None = None,
     locked_joint_positions: dict[str, float] | None = None,
+    mesh_method=None,
 ) -> ModelDescription:
     """Parse a URDF (or SDF, see ``parse_sdf``) string or path into a reduced (fixed joints lumped)
     description.
@@ -178,16 +181,19 @@ def parse_urdf(
     if is_path is None:
         is_path = not urdf.lstrip().startswith("<")
     root = ET.parse(urdf).getroot() if is_path else ET.fromstring(urdf)
+    # mesh collisions (JAXSIM_COLLISION_MESH_ENABLED, parsers/meshes.py): relative mesh paths are resolved
+    # against the directory of the description file; `mesh_method` selects the points (default: all vertices)
+    base_dir = os.path.dirname(os.path.abspath(urdf)) if is_path else os.getcwd()
     if root.tag == "sdf":
-        raw = _read_sdf(root)
+        raw = _read_sdf(root, base_dir=base_dir, mesh_method=mesh_method)
     elif root.tag == "robot":
-        raw = _read_urdf(root)
+        raw = _read_urdf(root, base_dir=base_dir, mesh_method=mesh_method)
     else:
         raise ValueError("not a URDF <robot> or SDF <sdf> document")
     return _assemble(*raw, considered_joints=considered_joints, locked_joint_positions=locked_joint_positions)
 
 
-def _read_urdf(root):
+def _read_urdf(root, base_dir=None, mesh_method=None):
     """Raw links / joints / collision points of a URDF ``<robot>``."""
     name = root.get("name", "model")
     # ---- raw links / joints / collisions --------------------------------------------
@@ -208,8 +214,12 @@ def _read_urdf(root):
                 pts = _box_points(_floats(geom.find("box").get("size"), 3), H)
             elif geom.find("sphere") is not None:
                 pts = _sphere_points(float(geom.find("sphere").get("radius")), H)
+            elif geom.find("mesh") is not None and meshes.mesh_collisions_enabled():
+                me_ = geom.find("mesh")
+                scale = _floats(me_.get("scale"), 3) if me_.get("scale") else np.ones(3)
+                pts = meshes.mesh_collision_points(me_.get("filename"), scale, H, base_dir=base_dir, method=mesh_method)
             else:
-                continue  # cylinder / mesh: skipped like the reference default
+                continue  # cylinder: skipped; mesh: skipped unless JAXSIM_COLLISION_MESH_ENABLED (rod/parser.py:333-348)
             raw_points += [CollidablePoint(parent_link=lname, position=p) for p in pts]
 
     fmax = float(np.finfo(float).max)
@@ -377,7 +387,7 @@ def _sdf_pose(elem):
     return hm.transform_from_xyz_rpy(v[:3], v[3:]), (pe.get("relative_to") or None)
 
 
-def _read_sdf(root, model_name: str | None = None):
+def _read_sdf(root, model_name: str | None = None, base_dir=None, mesh_method=None):
     """Raw links / joints / collision points of the first (or the named) ``<model>`` of an SDF document,
     converted to the URDF frame convention like the reference does
     (``sdf_model.switch_frame_convention(rod.FrameConvention.Urdf)``, ``rod/parser.py:76-84``): the
@@ -448,8 +458,13 @@ def _read_sdf(root, model_name: str | None = None):
                 pts = _box_points(_floats(geom.find("box").find("size").text, 3), H)
             elif geom.find("sphere") is not None:
                 pts = _sphere_points(float(geom.find("sphere").find("radius").text), H)
+            elif geom.find("mesh") is not None and meshes.mesh_collisions_enabled():
+                me_ = geom.find("mesh")
+                sc = me_.find("scale")
+                scale = _floats(sc.text, 3) if sc is not None else np.ones(3)
+                pts = meshes.mesh_collision_points(me_.find("uri").text.strip(), scale, H, base_dir=base_dir, method=mesh_method)
             else:
-                continue  # cylinder / mesh: skipped like the reference default
+                continue  # cylinder: skipped; mesh: skipped unless JAXSIM_COLLISION_MESH_ENABLED (rod/parser.py:333-348)
             raw_points += [CollidablePoint(parent_link=lname, position=p) for p in pts]
     for fe in me.findall("frame"):
         att = fe.get("attached_to")

@@ -22,9 +22,7 @@ template <typename T, int G>
 void run_group(const jxs::Packed<T>& pk, jxs::KArgs<T> a, int mode) {
   a.ltf = pk.ltf.data();
   a.lti = pk.lti.data();
-  a.ptf = pk.ptf.data();
-  a.pti = pk.pti.data();
-  a.head = pk.head.data();
+  a.chunks = pk.chunks.data();
   a.rti = pk.rti.data();
   for (int env = 0; env < a.N; ++env) {
     jxs::HostLanes<T, G> ln(a.N, env, (size_t)std::max(jxs::rigid_lds_words_per_env(pk.P.n_cp, pk.P.rigid), jxs::lds_words_per_env(G)));

@@ -171,6 +171,8 @@ struct HostLanes {
   void fence() const {}
   template <class KA>
   void stamp(const KA&, int) const {}
+  template <class KA, class X>
+  void stamp_after(const KA&, int, const X&) const {}
 
   template <typename U>
   Vec<U, G> shfl(const Vec<U, G>& x, const VI& src) const {
@@ -227,22 +229,32 @@ struct HostLanes {
   }
   V lconstf(const T* tbl, int field) const {
     V r;
-    for (int i = 0; i < G; ++i) r.v[i] = tbl[field * G + i];
+    for (int i = 0; i < G; ++i) r.v[i] = tbl[i * kLtfStride + field];
     return r;
   }
   VI lconsti(const int* tbl, int field) const {
     VI r;
-    for (int i = 0; i < G; ++i) r.v[i] = tbl[field * G + i];
+    for (int i = 0; i < G; ++i) r.v[i] = tbl[i * kLtiStride + field];
     return r;
   }
-  V ploadf(const T* tbl, int field, int n_slots, const VI& slot) const {
-    V r;
-    for (int i = 0; i < G; ++i) r.v[i] = tbl[field * n_slots + slot.v[i]];
-    return r;
-  }
-  VI ploadi(const int* tbl, int field, int n_slots, const VI& slot) const {
+  VI rconsti(const int* tbl, int field) const {
     VI r;
-    for (int i = 0; i < G; ++i) r.v[i] = tbl[field * n_slots + slot.v[i]];
+    for (int i = 0; i < G; ++i) r.v[i] = tbl[i * kRtiStride + field];
+    return r;
+  }
+  VI hconsti(const int* head, int chunk) const {
+    VI r;
+    for (int i = 0; i < G; ++i) r.v[i] = head[chunk * G + i];
+    return r;
+  }
+  V ploadf(const T* tbl, int field, const VI& slot) const {
+    V r;
+    for (int i = 0; i < G; ++i) r.v[i] = tbl[slot.v[i] * kPtStride + field];
+    return r;
+  }
+  VI ploadi(const int* tbl, int field, const VI& slot) const {
+    VI r;
+    for (int i = 0; i < G; ++i) r.v[i] = tbl[slot.v[i] * kPtStride + field];
     return r;
   }
   // tile-interleaved arrays: [N/TILE][rows][TILE], TILE = 64/G (see jxs_lanes_device.h)

@@ -1037,13 +1037,15 @@ def test_bench_model_step_matches_oracle_full_size_gpu():
 
 
 # ---- RigidContacts: the device against the reference's UN-reduced QP statement ------------------------
-@pytest.mark.parametrize("key", ["anymal4", "box4", "icub8"])
+@pytest.mark.parametrize("key", ["anymal4", "anymal16", "chain9f6", "icub8"])
 def test_rigid_step_matches_unreduced_statement_gpu(models, key):
     """`test_rigid_step_matches_oracle_gpu` compares with the oracle switched to the kernel's reduced QP
     statement.  Here the oracle solves the reference's own statement (inactive points squeezed to zero
     between their constraints, rbda/contacts/rigid.py:331-362, 476-500) and both sides run at
     solver_tol = 1e-10: the minimiser of the strictly convex QP is unique, so the device is tied to the
-    reference's statement, not only to the oracle's variant of it."""
+    reference's statement, not only to the oracle's variant of it.  (`box4` is left out: four coplanar
+    points on one body make the un-reduced Hessian singular up to the 1e-6 shift, and the oracle's own
+    interior-point restatement loses positive definiteness before it reaches 1e-10 there.)"""
     from oracle import refrigid
 
     assert refrigid.REDUCED_QP is False

@@ -35,5 +35,8 @@ print(f"N={N}: mean cycles per phase over {blocks} waves (s_memtime ticks)")
 for n, m, mx in zip(names, d.mean(axis=0), d.max(axis=0)):
     print(f"  {n:24s} {m:9.0f}  (max {mx})")
 print(f"  {'total':24s} {(out[:, 10] - out[:, 0]).mean():9.0f}")
+if out[:, 11].any():
+    for i, n in ((11, "index tables arrived"), (12, "base state rows arrived"), (13, "point tables arrived"), (14, "joint state rows arrived")):
+        print(f"  since wave start: {n:28s} {(out[:, i] - out[:, 0]).mean():9.0f}  (max {(out[:, i] - out[:, 0]).max()})")
 span = out[:, 10].max() - out[:, 0].min()
 print(f"  first start -> last end: {span} ticks")
