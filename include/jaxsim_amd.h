@@ -199,6 +199,12 @@ int jxs_validate_state(jxs_model* model, const void* state, int N, int* counts3,
  * "tau = g(q); step(tau)" (BASELINE.json config 5) stays on the device.                     */
 int jxs_gravity_torques(jxs_model* model, const void* state, void* out_tau, int N, void* stream);
 
+/* free_floating_mass_matrix (src/jaxsim/api/model.py:1553-1590, rbda/crba.py:10-170): the composite-rigid-body
+ * algorithm, one launch.  out_M = [(6+n)*(6+n)][N], row-major (row r, column c at row index r*(6+n)+c), in
+ * MIXED velocity representation (base block about the base position, world axes); the Body / Inertial forms
+ * are the 6x6 block congruence of api/model.py:1529-1551 applied by the caller.                  */
+int jxs_mass_matrix(jxs_model* model, const void* state, void* out_M, int N, void* stream);
+
 /* The cached kinematics of JaxSimModelData.replace (src/jaxsim/api/data.py:405-523,
  * rbda/forward_kinematics.py:12-113): link transforms [nL*12][N] (rows of [R|p]) and
  * inertial-fixed link velocities [nL*6][N]; either output may be NULL.                  */

@@ -256,26 +256,49 @@ def gravity_compensation_torques(model: JaxSimModel, data: JaxSimModelData, out:
     return out
 
 
-def free_floating_mass_matrix(model: JaxSimModel, data: JaxSimModelData):
-    """``M(q)`` in the active velocity representation (``src/jaxsim/api/model.py:1553-1590``).
+def _mixed_to_repr_block(data: JaxSimModelData) -> np.ndarray:
+    """[N, 6, 6] matrices X with  v_mixed = X v_repr  for the base velocity in ``data.velocity_representation``
+    (the inverse-transpose-free form of ``_transform_M_block``, ``src/jaxsim/api/model.py:1529-1551``)."""
+    N = data.batch_size
+    H = data._base_transform_batched()
+    X = np.zeros((N, 6, 6))
+    rep = data.velocity_representation
+    if rep == VelRepr.Mixed:
+        X[:] = np.eye(6)
+    elif rep == VelRepr.Body:
+        X[:, :3, :3] = H[:, :3, :3]
+        X[:, 3:, 3:] = H[:, :3, :3]
+    else:  # inertial-fixed: v_mixed,lin = v_lin + w x p_B
+        p = H[:, :3, 3]
+        X[:, :3, :3] = np.eye(3)
+        X[:, 3:, 3:] = np.eye(3)
+        X[:, 0, 4], X[:, 0, 5] = p[:, 2], -p[:, 1]
+        X[:, 1, 3], X[:, 1, 5] = -p[:, 2], p[:, 0]
+        X[:, 2, 3], X[:, 2, 4] = p[:, 1], -p[:, 0]
+    return X
 
-    The reference runs CRBA; here the columns come from ONE inverse-dynamics launch over a virtual
-    batch of ``N * (7 + n)`` environments at zero velocity: ``M e_i = ID(q, 0, e_i) - ID(q, 0, 0)``
-    (the RNEA kernel is the only device code involved)."""
+
+def free_floating_mass_matrix(model: JaxSimModel, data: JaxSimModelData):
+    """``M(q)`` in the active velocity representation (``src/jaxsim/api/model.py:1553-1590``): ONE launch of
+    the composite-rigid-body kernel (``jxs_mass_matrix``, ``rbda/crba.py:10-170``), which returns the matrix
+    in Mixed representation; Body / Inertial are the block congruence ``diag(X, I)^T M diag(X, I)``."""
+    dm = runtime.device_model(model, data.dtype)
     N, n = data.batch_size, model.dofs()
     nv = 6 + n
-    z = _zero_velocity_replicas(model, data, nv + 1)
-    acc = np.zeros((nv + 1, N, nv))
-    for k in range(nv):
-        acc[k, :, k] = 1.0
-    acc = acc.reshape((nv + 1) * N, nv)
-    fB, tau = inverse_dynamics(model, z, joint_accelerations=acc[:, 6:], base_acceleration=acc[:, :6])
-    cols = np.concatenate([np.asarray(fB, dtype=np.float64), np.asarray(tau, dtype=np.float64).reshape((nv + 1) * N, n)], axis=-1)
-    cols = cols.reshape(nv + 1, N, nv)
-    M = np.transpose(cols[:nv] - cols[nv:], (1, 2, 0))  # [N, row, column]
-    M = 0.5 * (M + np.transpose(M, (0, 2, 1)))
-    if not model.floating_base():
-        pass  # the reference returns the full (6+n) matrix for fixed-base models too
+    out = DeviceArray(nv * nv, N, data.dtype, tile=data._state.tile)
+    _lib.check(
+        _lib.load().jxs_mass_matrix(dm.handle, C.c_void_p(data._state.ptr), C.c_void_p(out.ptr), N, runtime._sp()),
+        "jxs_mass_matrix",
+    )
+    M = out.to_host().T.astype(np.float64).reshape(N, nv, nv)
+    if data.velocity_representation != VelRepr.Mixed:
+        X = _mixed_to_repr_block(data)
+        Xt = np.transpose(X, (0, 2, 1))
+        M = M.copy()
+        Mbb, Mbj = M[:, :6, :6].copy(), M[:, :6, 6:].copy()
+        M[:, :6, :6] = Xt @ Mbb @ X
+        M[:, :6, 6:] = Xt @ Mbj
+        M[:, 6:, :6] = np.transpose(M[:, :6, 6:], (0, 2, 1))
     return data._out(M.astype(data.dtype))
 
 

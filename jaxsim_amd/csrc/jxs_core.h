@@ -549,6 +549,11 @@ struct Core {
     const V c6[6] = {cl[0], cl[1], cl[2], ca[0], ca[1], ca[2]};
     ln.stamp(A, 6);  // inertia + bias
 
+    if (MODE == MODE_CRBA) {
+      crba(lane, level, child, jrow, is_joint, is_root, MA, S6);
+      return;
+    }
+
     V sdd = V(T(0));
     V acl[3], aca[3];  // base spatial acceleration in C incl. gravity (valid in every lane)
     if (P.row_mode && (kStep || MODE == MODE_FD) && !kRigid) {
@@ -1477,6 +1482,91 @@ struct Core {
     for (int k = 0; k < 3; ++k) {
       ln.gstore(A.out_a, zl + k, f6[k], is_root, 6 + P.n);
       ln.gstore(A.out_a, zl + (3 + k), f6[3 + k] + t[k], is_root, 6 + P.n);
+    }
+  }
+
+  // ==========================================================================================
+  // Composite-rigid-body algorithm (rbda/crba.py:10-170) in frame C.  The composite inertias are plain
+  // subtree sums (all neighbour transforms are the identity), F_i = Ic_i S_i, and
+  //     M[6+i, 6+j] = S_j . F_i   for every ancestor-or-self j of i,   M[0:6, 6+i] = F_i,   M[0:6, 0:6] = Ic_0.
+  // Frame C = origin at the base position with world-aligned axes, which IS the Mixed velocity representation
+  // of the base (api/common.py:39-47): the kernel writes M in Mixed representation, the host applies the 6x6
+  // congruence of api/model.py:1529-1590 (`_transform_M_block`) for Body / Inertial.  The output
+  // out_a[(6+n)^2][N] is zeroed by the caller; only the structurally non-zero entries are written.
+  JXS_HD void crba(const VI& lane, const VI& level, const VI* child, const VI& jrow, const VM& is_joint,
+                   const VM& is_root, const V* M_link, const V* S6) const {
+    V Ic[21];
+#pragma unroll
+    for (int e = 0; e < 21; ++e) Ic[e] = M_link[e];
+    // composite inertias, leaves to base: parents at level Lv-1 add their children (all at level Lv, final)
+    for (int Lv = P.max_depth; Lv >= 1; --Lv) {
+      const VM is_par = level == (Lv - 1);
+      const int nch = P.maxch(Lv);
+      if (nch >= 1) {
+        const V okf = vsel(is_par && (child[0] >= 0), V(T(1)), V(T(0)));
+        V t9[9];
+        ln.fmac9_from_next(Ic, Ic, okf);
+        ln.fmac9_from_next(Ic + 9, Ic + 9, okf);
+#pragma unroll
+        for (int e = 0; e < 3; ++e) t9[e] = Ic[18 + e];
+#pragma unroll
+        for (int e = 3; e < 9; ++e) t9[e] = V(T(0));
+        V a9[9];
+#pragma unroll
+        for (int e = 0; e < 9; ++e) a9[e] = t9[e];
+        ln.fmac9_from_next(a9, t9, okf);
+#pragma unroll
+        for (int e = 0; e < 3; ++e) Ic[18 + e] = a9[e];
+      }
+#pragma unroll
+      for (int k = 1; k < kMaxChildren; ++k) {
+        if (k < nch) {
+          const V okf = vsel(is_par && (child[k] >= 0), V(T(1)), V(T(0)));
+          V g[21];
+#pragma unroll
+          for (int e = 0; e < 21; ++e) g[e] = ln.shfl(Ic[e], child[k]);
+          ln.fence();
+#pragma unroll
+          for (int e = 0; e < 21; ++e) Ic[e] = Ic[e] + okf * g[e];
+        }
+      }
+    }
+    V F[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      V acc = Ic[sidx(i, 0)] * S6[0];
+#pragma unroll
+      for (int j = 1; j < 6; ++j) acc = acc + Ic[sidx(i, j)] * S6[j];
+      F[i] = acc;
+    }
+    const int nv = 6 + P.n, rows = nv * nv;
+    const VI sub = ln.lconsti(A.lti, LI_SUBTREE);
+    // base block: the composite inertia of the whole tree
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int j = 0; j < 6; ++j) ln.gstore(A.out_a, lane * 0 + (i * nv + j), Ic[sidx(i, j)], is_root, rows);
+    // one pass per link lane k: every lane that is an ancestor-or-self joint of k writes its entry (and the
+    // mirrored one), the base lane writes the coupling column F_k
+    for (int k = 1; k < P.nL; ++k) {
+      const VI src = lane * 0 + k;
+      V Fk[6];
+#pragma unroll
+      for (int e = 0; e < 6; ++e) Fk[e] = ln.shfl(F[e], src);
+      const VI ck = ln.shfl(jrow, src) + 6;  // column of joint k
+      ln.fence();
+      V v = S6[0] * Fk[0];
+#pragma unroll
+      for (int e = 1; e < 6; ++e) v = v + S6[e] * Fk[e];
+      const VM anc = is_joint && (lane <= src) && (src < lane + sub);
+      const VI rj = jrow + 6;
+      ln.gstore(A.out_a, rj * nv + ck, v, anc, rows);
+      ln.gstore(A.out_a, ck * nv + rj, v, anc, rows);
+#pragma unroll
+      for (int e = 0; e < 6; ++e) {
+        ln.gstore(A.out_a, ck + e * nv, Fk[e], is_root, rows);
+        ln.gstore(A.out_a, ck * nv + e, Fk[e], is_root, rows);
+      }
     }
   }
 

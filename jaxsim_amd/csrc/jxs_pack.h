@@ -176,6 +176,8 @@ std::string pack_model(const jxs_model_desc& d, Packed<T>& out) {
       for (int k = (int)children[i].size() - 1; k >= 0; --k) stack.push_back(children[i][k]);
     }
   }
+  std::vector<int> subtree(nL, 1);
+  for (int i = nL - 1; i >= 1; --i) subtree[d.parent[i]] += subtree[i];  // BFS indices: children after parents
   P.nonadj_levels = 0;
   for (int i = 1; i < nL; ++i)
     if (lane_of[d.parent[i]] != lane_of[i] - 1) P.nonadj_levels |= 1ull << level[i];
@@ -258,6 +260,7 @@ std::string pack_model(const jxs_model_desc& d, Packed<T>& out) {
     const int i = link_of[lane];
     I(LI_LINK, lane) = i;
     I(LI_LEVEL, lane) = level[i];
+    I(LI_SUBTREE, lane) = subtree[i];
     F(LF_MASS, lane) = (T)d.link_mass[i];
     for (int k = 0; k < 3; ++k) F(LF_COM + k, lane) = (T)d.link_com[3 * i + k];
     const double* Ii = d.link_inertia + 9 * i;

@@ -58,7 +58,9 @@ enum LaneI : int {
   LI_CHILD = LI_JUMP + kMaxRounds,  // kMaxChildren entries: child lanes, -1 if none (child 0 = lane+1)
   LI_LINK = LI_CHILD + kMaxChildren,  // reference link index of this lane, -1 for padding lanes
   LI_JROW = LI_LINK + 1,              // joint row (link index - 1), -1 for the base / padding lanes
-  LI_COUNT = LI_JROW + 1
+  LI_SUBTREE = LI_JROW + 1,           // links in the subtree of this lane's link (itself included): in the
+                                      // depth-first lane order the subtree of lane j is lanes [j, j + size)
+  LI_COUNT = LI_SUBTREE + 1
 };
 constexpr int kLtiStride = (LI_COUNT + 3) / 4 * 4;
 
@@ -115,8 +117,10 @@ enum Mode : int {
   MODE_ROLLOUT = 4,  // MODE_STEP repeated KArgs::n_steps times in one launch (state in registers)
   MODE_STEP_RK4 = 5,  // js.model.step with IntegratorType.RungeKutta4  api/integrators.py:91-167
   MODE_STEP_RIGID = 6,  // js.model.step with the RigidContacts / RelaxedRigidContacts model  rbda/contacts/rigid.py:176-539
-  MODE_STEP_RK4_RIGID = 7  // RungeKutta4 with RigidContacts / RelaxedRigidContacts (contact forces solved at every stage)
+  MODE_STEP_RK4_RIGID = 7,  // RungeKutta4 with RigidContacts / RelaxedRigidContacts (contact forces solved at every stage)
+  MODE_CRBA = 8  // free_floating_mass_matrix: composite-rigid-body algorithm  rbda/crba.py:10-170, api/model.py:1553-1590
 };
+constexpr int kNumModes = 9;
 
 enum ForceRepr : int { REPR_INERTIAL = 0, REPR_BODY = 1, REPR_MIXED = 2 };  // api/common.py:39-47
 

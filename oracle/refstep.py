@@ -966,8 +966,22 @@ def free_floating_bias_forces(model, data: OracleData):
 
 
 def free_floating_mass_matrix(model, data: OracleData):
-    """Body-fixed mass matrix (``model.py:1529-1590`` Body branch)."""
-    return crba(model, joint_positions=data.joint_positions)
+    """``free_floating_mass_matrix`` (``model.py:1529-1590``): CRBA in body-fixed representation, moved to the
+    representation of ``data`` by ``_transform_M_block`` with ``B_X_W`` (Inertial) or ``B_X_BW`` (Mixed)."""
+    M_body = crba(model, joint_positions=data.joint_positions)
+    rep = data.velocity_representation
+    if rep == VelRepr.Body:
+        return M_body
+    H = data.base_transform.copy()
+    if rep == VelRepr.Mixed:
+        H[:, :3, 3] = 0.0  # BW_H_B
+    X = rm.adjoint_from_transform(H, inverse=True)
+    Xt = np.swapaxes(X, -1, -2)
+    M = M_body.copy()
+    M[:, :6, :6] = Xt @ M_body[:, :6, :6] @ X
+    M[:, :6, 6:] = Xt @ M_body[:, :6, 6:]
+    M[:, 6:, :6] = M_body[:, 6:, :6] @ X
+    return M
 
 
 # =============================================================================================

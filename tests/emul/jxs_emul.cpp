@@ -35,6 +35,7 @@ void run_group(const jxs::Packed<T>& pk, jxs::KArgs<T> a, int mode) {
       case jxs::MODE_STEP_RK4: core.template run<jxs::MODE_STEP_RK4>(); break;
       case jxs::MODE_STEP_RIGID: core.template run<jxs::MODE_STEP_RIGID>(); break;
       case jxs::MODE_STEP_RK4_RIGID: core.template run<jxs::MODE_STEP_RK4_RIGID>(); break;
+      case jxs::MODE_CRBA: core.template run<jxs::MODE_CRBA>(); break;
       default: core.template run<jxs::MODE_KIN>(); break;
     }
   }

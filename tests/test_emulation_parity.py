@@ -755,3 +755,22 @@ def test_actuation_limits_and_torque_speed_curve(models, name, dtype):
     plain = helpers.with_params(models(name), actuation_params=ja.ActuationParams())
     off = oracle.step(plain, helpers.upcast(d), joint_force_references=tau.astype(np.float64))
     assert helpers.rel_err(helpers.odata_to_block(model, off), helpers.odata_to_block(model, ref)) > 10 * helpers.tol_of(dtype) + 0.02
+
+
+@pytest.mark.parametrize("name", ["pendulum", "cartpole", "chain5", "chain9f", "anymal", "icub"])
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-11), (np.float32, 2e-5)])
+def test_crba_kernel_matches_oracle(models, name, dtype, tol):
+    """MODE_CRBA (composite-rigid-body kernel, rbda/crba.py:10-170): the mass matrix in Mixed representation
+    against the oracle's CRBA (body representation) moved to Mixed by the block congruence of
+    api/model.py:1529-1590, fixed- and floating-base models."""
+    from oracle import refrigid
+
+    model = models(name)
+    N = 4
+    d = models.random_data(name, N, seed=41, dtype=dtype)
+    nv = 6 + model.dofs()
+    out = eb.run(model, eb.MODE_CRBA, helpers.odata_to_block(model, d)).T.reshape(N, nv, nv)
+    ref = refrigid.free_floating_mass_matrix_mixed(model, helpers.upcast(d))
+    scale = max(1.0, np.abs(ref).max())
+    assert np.abs(out - ref).max() / scale < tol
+    np.testing.assert_array_equal(out, np.transpose(out, (0, 2, 1)))  # mirrored entries are the same numbers

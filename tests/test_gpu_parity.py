@@ -748,19 +748,29 @@ def test_gpu_golden_rigid(models, name):
     assert helpers.rel_err(out.state_block(), g["step"]) < 1e-7
 
 
-@pytest.mark.parametrize("name", ["chain9f", "anymal", "icub"])
+@pytest.mark.parametrize("name", ["pendulum", "cartpole", "chain9f", "anymal", "icub"])
 def test_free_floating_mass_matrix(models, name):
-    """``js.model.free_floating_mass_matrix`` (reference: CRBA, api/model.py:1553-1590; README usage) --
-    here RNEA columns over a virtual batch -- against the oracle's CRBA in Body and Mixed representation."""
+    """``js.model.free_floating_mass_matrix`` (api/model.py:1553-1590) = ONE launch of the composite-rigid-body
+    kernel (``jxs_mass_matrix``, rbda/crba.py:10-170) against the oracle's CRBA in the three velocity
+    representations, fixed- and floating-base models; and M nudot = ID(nudot) - ID(0) ties it to the RNEA kernel."""
     from oracle import refrigid
 
     model = models(name)
-    for rep in (VelRepr.Body, VelRepr.Mixed):
+    for rep in (VelRepr.Body, VelRepr.Mixed, VelRepr.Inertial):
         d = models.random_data(name, 5, seed=41, rep=rep)
-        M = js.model.free_floating_mass_matrix(model, to_gpu(model, d))
-        ref = oracle.crba(model, joint_positions=d.joint_positions) if rep == VelRepr.Body else refrigid.free_floating_mass_matrix_mixed(model, d)
+        g = to_gpu(model, d)
+        M = js.model.free_floating_mass_matrix(model, g)
+        ref = oracle.free_floating_mass_matrix(model, d)
         assert M.shape == ref.shape
         assert helpers.rel_err(M, ref) < 1e-9
+        if rep == VelRepr.Mixed:
+            assert helpers.rel_err(M, refrigid.free_floating_mass_matrix_mixed(model, d)) < 1e-9
+    # fp32
+    d = models.random_data(name, 64, seed=42, dtype=np.float32)
+    M32 = js.model.free_floating_mass_matrix(model, to_gpu(model, d))
+    assert M32.dtype == np.float32
+    ref = oracle.free_floating_mass_matrix(model, helpers.upcast(d))
+    assert np.abs(M32 - ref).max() / max(1.0, np.abs(ref).max()) < 2e-5
 
 
 def test_reference_readme_flow(models):
