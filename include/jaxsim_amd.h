@@ -205,6 +205,13 @@ int jxs_gravity_torques(jxs_model* model, const void* state, void* out_tau, int 
  * are the 6x6 block congruence of api/model.py:1529-1551 applied by the caller.                  */
 int jxs_mass_matrix(jxs_model* model, const void* state, void* out_M, int N, void* stream);
 
+/* jacobian_full_doubly_left + jacobian_derivative_full_doubly_left (src/jaxsim/rbda/jacobian.py:128-339), one
+ * launch: out_J = [2*6*(6+n)][N] = B_J_full_WX_B (6 x (6+n), row-major) followed by B_Jdot_full_WX_B, both with
+ * input and output in the base frame ("doubly left"); out_B_H_L = [nL*12][N] rows of [R|p] of every link
+ * relative to the base, or NULL.  The link Jacobians / their derivatives in any pair of representations are
+ * the column masks and 6x6 transforms of api/model.py:925-1228 applied by the caller.             */
+int jxs_jacobian_full(jxs_model* model, const void* state, void* out_J, void* out_B_H_L, int N, void* stream);
+
 /* The cached kinematics of JaxSimModelData.replace (src/jaxsim/api/data.py:405-523,
  * rbda/forward_kinematics.py:12-113): link transforms [nL*12][N] (rows of [R|p]) and
  * inertial-fixed link velocities [nL*6][N]; either output may be NULL.                  */

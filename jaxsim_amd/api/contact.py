@@ -134,3 +134,57 @@ def jacobian(model: JaxSimModel, data, *, output_vel_repr=None):
     H = np.broadcast_to(W_H_C[:, :, None], cols.shape[:3] + (4, 4))
     O = _inertial_to_other(cols.reshape(-1, 6), out_rep, H.reshape(-1, 4, 4), False).reshape(cols.shape)
     return data._out(np.moveaxis(O, 2, -1).astype(data.dtype).reshape(W_J.shape[:2] + (6, nv)))
+
+
+def jacobian_derivative(model: JaxSimModel, data, *, output_vel_repr=None):
+    """Derivative of the free-floating Jacobians of the enabled collidable points, ``[n_cp, 6, 6+n]``
+    (``src/jaxsim/api/contact.py:353-511``): ``O_Jdot_WC_I = O_Xdot_W W_J T + O_X_W W_Jdot T + O_X_W W_J Tdot`` with
+    the inertial / inertial link Jacobians and their derivatives (one launch of the Jacobian kernel each)."""
+    from ..model import VelRepr
+    from . import model as _m
+
+    out_rep = data.velocity_representation if output_vel_repr is None else VelRepr(output_vel_repr)
+    body, L_p = _enabled(model)
+    N, n = data.batch_size, model.dofs()
+    W_H_B = data._base_transform_batched()
+    rep = data.velocity_representation
+    # ---- input representation (:401-436)
+    if rep == VelRepr.Inertial:
+        X, Xd = np.broadcast_to(np.eye(6), (N, 6, 6)), np.zeros((N, 6, 6))
+    elif rep == VelRepr.Body:
+        X = _m._adjoint(W_H_B)
+        Xd = X @ _m._vx_matrix(np.asarray(data._base_velocity_batched(VelRepr.Body), np.float64))
+    else:
+        W_H_BW = W_H_B.copy()
+        W_H_BW[:, :3, :3] = np.eye(3)
+        X = _m._adjoint(W_H_BW)
+        v = np.asarray(data._base_velocity_batched(VelRepr.Mixed), np.float64).copy()
+        v[:, 3:] = 0.0
+        Xd = X @ _m._vx_matrix(v)
+    T, Td = _m._block_T(X, n)[:, None], _m._block_T(Xd, n, identity=False)[:, None]
+    # ---- link Jacobians and derivatives, inertial in / inertial out (:438-449)
+    with data.switch_velocity_representation(VelRepr.Inertial):
+        W_J = np.asarray(_m.generalized_free_floating_jacobian(model, data), np.float64)
+        W_Jd = np.asarray(_m.generalized_free_floating_jacobian_derivative(model, data), np.float64)
+    W_J = W_J.reshape((N,) + W_J.shape[-3:])[:, body]
+    W_Jd = W_Jd.reshape((N,) + W_Jd.shape[-3:])[:, body]
+    # ---- output representation (:455-490)
+    nc = len(body)
+    if out_rep == VelRepr.Inertial:
+        O_X_W, O_Xd_W = np.broadcast_to(np.eye(6), (N, nc, 6, 6)), np.zeros((N, nc, 6, 6))
+    else:
+        W_H_C = np.asarray(transforms(model, data), np.float64).reshape(N, nc, 4, 4)
+        W_v_WL = np.asarray(data._kinematics()[1], np.float64).reshape(N, -1, 6)[:, body]
+        if out_rep == VelRepr.Body:
+            O_X_W = _m._adjoint(W_H_C, inverse=True)
+            O_Xd_W = -O_X_W @ _m._vx_matrix(W_v_WL)
+        else:
+            W_H_CW = W_H_C.copy()
+            W_H_CW[..., :3, :3] = np.eye(3)
+            O_X_W = _m._adjoint(W_H_CW, inverse=True)
+            CW_v = np.einsum("ncij,ncj->nci", O_X_W, W_v_WL)
+            W_v_W_CW = np.zeros_like(CW_v)
+            W_v_W_CW[..., :3] = CW_v[..., :3]
+            O_Xd_W = -O_X_W @ _m._vx_matrix(W_v_W_CW)
+    Jd = O_Xd_W @ W_J @ T + O_X_W @ W_Jd @ T + O_X_W @ W_J @ Td
+    return data._out(Jd.astype(data.dtype))

@@ -337,37 +337,170 @@ def free_floating_mass_matrix_inverse(model: JaxSimModel, data: JaxSimModelData)
     return data._out(Mi.astype(data.dtype))
 
 
+def _adjoint(H: np.ndarray, inverse: bool = False) -> np.ndarray:
+    """Batched ``Adjoint.from_transform`` (``src/jaxsim/math/adjoint.py:46-107``): ``[[R, S(p) R], [0, R]]``."""
+    R, p = H[..., :3, :3], H[..., :3, 3]
+    if inverse:  # (R, p)^-1 = (R^T, -R^T p)
+        R = np.swapaxes(R, -1, -2)
+        p = -np.einsum("...ij,...j->...i", R, p)
+    Sp = np.zeros(R.shape)
+    Sp[..., 0, 1], Sp[..., 0, 2] = -p[..., 2], p[..., 1]
+    Sp[..., 1, 0], Sp[..., 1, 2] = p[..., 2], -p[..., 0]
+    Sp[..., 2, 0], Sp[..., 2, 1] = -p[..., 1], p[..., 0]
+    X = np.zeros(R.shape[:-2] + (6, 6))
+    X[..., :3, :3] = R
+    X[..., :3, 3:] = Sp @ R
+    X[..., 3:, 3:] = R
+    return X
+
+
+def _vx_matrix(v6: np.ndarray) -> np.ndarray:
+    """Batched ``Cross.vx`` (``src/jaxsim/math/cross.py:14-43``): ``[[S(w), S(v)], [0, S(w)]]``."""
+    def S(a):
+        out = np.zeros(a.shape[:-1] + (3, 3))
+        out[..., 0, 1], out[..., 0, 2] = -a[..., 2], a[..., 1]
+        out[..., 1, 0], out[..., 1, 2] = a[..., 2], -a[..., 0]
+        out[..., 2, 0], out[..., 2, 1] = -a[..., 1], a[..., 0]
+        return out
+
+    X = np.zeros(v6.shape[:-1] + (6, 6))
+    X[..., :3, :3] = S(v6[..., 3:])
+    X[..., :3, 3:] = S(v6[..., :3])
+    X[..., 3:, 3:] = S(v6[..., 3:])
+    return X
+
+
+def _support_mask(model: JaxSimModel) -> np.ndarray:
+    """``hstack([ones(5), kappa_bool])`` per link (``src/jaxsim/api/model.py:975-981``): ``[nL, 6+n]``."""
+    kdp = model.kin_dyn_parameters
+    nL = kdp.number_of_links()
+    mask = np.zeros((nL, 6 + nL - 1))
+    mask[:, :6] = 1.0
+    for L in range(nL):
+        j = L
+        while j > 0:
+            mask[L, 6 + j - 1] = 1.0
+            j = int(kdp.parent_array[j])
+    return mask
+
+
+def jacobian_full_doubly_left(model: JaxSimModel, data: JaxSimModelData):
+    """``jaxsim.rbda.jacobian_full_doubly_left`` + ``jacobian_derivative_full_doubly_left``
+    (``src/jaxsim/rbda/jacobian.py:128-339``) in ONE launch of the Jacobian kernel (``jxs_jacobian_full``):
+    ``(B_J_full [N,6,6+n], B_Jdot_full [N,6,6+n], B_H_L [N,nL,4,4])`` as float64 host arrays."""
+    dm = runtime.device_model(model, data.dtype)
+    N, n, nL = data.batch_size, model.dofs(), model.number_of_links()
+    nv = 6 + n
+    out = DeviceArray(12 * nv, N, data.dtype, tile=data._state.tile)
+    outH = DeviceArray(12 * nL, N, data.dtype, tile=data._state.tile)
+    _lib.check(
+        _lib.load().jxs_jacobian_full(dm.handle, C.c_void_p(data._state.ptr), C.c_void_p(out.ptr), C.c_void_p(outH.ptr), N, runtime._sp()),
+        "jxs_jacobian_full",
+    )
+    JJ = out.to_host().T.astype(np.float64)
+    H = np.zeros((N, nL, 4, 4))
+    H[:, :, :3, :] = outH.to_host().T.astype(np.float64).reshape(N, nL, 3, 4)
+    H[:, :, 3, 3] = 1.0
+    return JJ[:, : 6 * nv].reshape(N, 6, nv), JJ[:, 6 * nv :].reshape(N, 6, nv), H
+
+
+def _block_T(X: np.ndarray, n: int, identity: bool = True) -> np.ndarray:
+    T = np.zeros(X.shape[:-2] + (6 + n, 6 + n))
+    T[..., :6, :6] = X
+    if identity:
+        T[..., 6:, 6:] = np.eye(n)
+    return T
+
+
 def generalized_free_floating_jacobian(model: JaxSimModel, data: JaxSimModelData, *, output_vel_repr=None):
     """Free-floating Jacobians of all links, ``[nL, 6, 6+n]`` (``src/jaxsim/api/model.py:925-1045``): the
     generalized velocity is expressed in ``data.velocity_representation``, the link velocity in
-    ``output_vel_repr`` (default: the same).  Column i is the link velocity field of the unit generalized
-    velocity e_i, evaluated by the cached-kinematics kernel over a virtual batch of 6+n replicas."""
-    from ..state import StateLayout
+    ``output_vel_repr`` (default: the same).  One launch of the Jacobian kernel; the column masks and the
+    6x6 input / output transforms are applied on the host like the reference applies them after its
+    ``rbda`` call."""
+    out_rep = data.velocity_representation if output_vel_repr is None else VelRepr(output_vel_repr)
+    N, n = data.batch_size, model.dofs()
+    B_J_full, _, B_H_L = jacobian_full_doubly_left(model, data)
+    W_H_B = data._base_transform_batched()
+    rep = data.velocity_representation
+    if rep == VelRepr.Inertial:
+        B_X_I = _adjoint(W_H_B, inverse=True)
+    elif rep == VelRepr.Body:
+        B_X_I = np.broadcast_to(np.eye(6), (N, 6, 6))
+    else:
+        BW_H_B = W_H_B.copy()
+        BW_H_B[:, :3, 3] = 0.0
+        B_X_I = _adjoint(BW_H_B, inverse=True)
+    B_J_full_I = B_J_full @ _block_T(B_X_I, n)
+    B_J_WL_I = _support_mask(model)[None, :, None, :] * B_J_full_I[:, None]  # [N, nL, 6, nv]
+    if out_rep == VelRepr.Inertial:
+        O_X_B = _adjoint(W_H_B)[:, None]
+    elif out_rep == VelRepr.Body:
+        O_X_B = _adjoint(B_H_L, inverse=True)
+    else:
+        LW_H_L = W_H_B[:, None] @ B_H_L
+        LW_H_L[..., :3, 3] = 0.0
+        O_X_B = _adjoint(LW_H_L @ np.linalg.inv(B_H_L))
+    return data._out((O_X_B @ B_J_WL_I).astype(data.dtype))
 
+
+def generalized_free_floating_jacobian_derivative(model: JaxSimModel, data: JaxSimModelData, *, output_vel_repr=None):
+    """Time derivative of the free-floating Jacobians of all links, ``[nL, 6, 6+n]``
+    (``src/jaxsim/api/model.py:1046-1228``): ``O_Jdot = O_Xdot_B B_J T + O_X_B B_Jdot T + O_X_B B_J Tdot`` with the
+    doubly-left Jacobian and its derivative from one launch of the Jacobian kernel."""
     out_rep = data.velocity_representation if output_vel_repr is None else VelRepr(output_vel_repr)
     N, n, nL = data.batch_size, model.dofs(), model.number_of_links()
-    nv = 6 + n
-    L = StateLayout.of(model)
-    z = _zero_velocity_replicas(model, data, nv)
-    # unit generalized velocities in the active representation -> the inertial-fixed state rows
-    nu = np.zeros((nv, N, nv))
-    for k in range(nv):
-        nu[k, :, k] = 1.0
-    H_B = np.tile(data._base_transform_batched(), (nv, 1, 1))
-    W_v = _other_to_inertial(nu.reshape(-1, nv)[:, :6], data.velocity_representation, H_B, False)
-    blk = z.state_block().astype(np.float64)
-    blk[L.row_vlin : L.row_vlin + 3] = W_v[:, :3].T
-    blk[L.row_vang : L.row_vang + 3] = W_v[:, 3:].T
-    blk[L.row_sd : L.row_sd + n] = nu.reshape(-1, nv)[:, 6:].T
-    z = JaxSimModelData.from_state_block(model, blk.astype(data.dtype), data.velocity_representation)
-    W_v_WL = np.asarray(z._link_velocities, np.float64).reshape(nv, N, nL, 6)
-    W_H_L = np.asarray(z._link_transforms, np.float64).reshape(nv, N, nL, 4, 4)[0]
-    cols = W_v_WL
-    if out_rep != VelRepr.Inertial:
-        H = np.broadcast_to(W_H_L, (nv,) + W_H_L.shape).reshape(-1, 4, 4)
-        cols = _inertial_to_other(W_v_WL.reshape(-1, 6), out_rep, H, False).reshape(nv, N, nL, 6)
-    J = np.transpose(cols, (1, 2, 3, 0))  # [N, nL, 6, nv]
-    return data._out(J.astype(data.dtype))
+    B_J_full, B_Jd_full, B_H_L = jacobian_full_doubly_left(model, data)
+    mask = _support_mask(model)[None, :, None, :]
+    B_Jd_WL_B = mask * B_Jd_full[:, None]
+    B_J_WL_B = mask * B_J_full[:, None]
+    W_H_B = data._base_transform_batched()
+    rep = data.velocity_representation
+    B_v_WB = np.asarray(data._base_velocity_batched(VelRepr.Body), np.float64)
+    # ---- input representation: T and its derivative (:1104-1146)
+    if rep == VelRepr.Inertial:
+        B_X_W = _adjoint(W_H_B, inverse=True)
+        W_v_WB = np.asarray(data._base_velocity_batched(VelRepr.Inertial), np.float64)
+        X, Xd = B_X_W, -B_X_W @ _vx_matrix(W_v_WB)
+    elif rep == VelRepr.Body:
+        X, Xd = np.broadcast_to(np.eye(6), (N, 6, 6)), np.zeros((N, 6, 6))
+    else:
+        BW_H_B = W_H_B.copy()
+        BW_H_B[:, :3, 3] = 0.0
+        B_X_BW = _adjoint(BW_H_B, inverse=True)
+        BW_v_WB = np.asarray(data._base_velocity_batched(VelRepr.Mixed), np.float64)
+        BW_v_BW_B = BW_v_WB.copy()
+        BW_v_BW_B[:, :3] = 0.0  # BW_v_WB - BW_v_W_BW, the latter being the linear part
+        X, Xd = B_X_BW, -B_X_BW @ _vx_matrix(BW_v_BW_B)
+    T, Td = _block_T(X, n)[:, None], _block_T(Xd, n, identity=False)[:, None]
+    # ---- output representation: O_X_B and its derivative (:1148-1214)
+    if out_rep == VelRepr.Inertial:
+        W_X_B = _adjoint(W_H_B)
+        O_X_B, O_Xd_B = W_X_B[:, None], (W_X_B @ _vx_matrix(B_v_WB))[:, None]
+    elif out_rep == VelRepr.Body:
+        L_X_B = _adjoint(B_H_L, inverse=True)
+        B_X_L = _adjoint(B_H_L)
+        nu_B = np.concatenate([B_v_WB, np.asarray(data._fields()["joint_velocities"], np.float64).reshape(N, n)], -1)
+        L_v_WL = np.einsum("nlij,nj->nli", L_X_B @ B_J_WL_B, nu_B)
+        O_X_B = L_X_B
+        O_Xd_B = -L_X_B @ _vx_matrix(np.einsum("nlij,nlj->nli", B_X_L, L_v_WL) - B_v_WB[:, None])
+    else:
+        W_H_L = W_H_B[:, None] @ B_H_L
+        LW_H_L = W_H_L.copy()
+        LW_H_L[..., :3, 3] = 0.0
+        LW_H_B = LW_H_L @ np.linalg.inv(B_H_L)
+        LW_X_B = _adjoint(LW_H_B)
+        B_X_LW = _adjoint(LW_H_B, inverse=True)
+        nu_B = np.concatenate([B_v_WB, np.asarray(data._fields()["joint_velocities"], np.float64).reshape(N, n)], -1)
+        LW_v_WL = np.einsum("nlij,nj->nli", LW_X_B @ B_J_WL_B, nu_B)
+        LW_v_W_LW = LW_v_WL.copy()
+        LW_v_W_LW[..., 3:] = 0.0
+        LW_v_LW_L = LW_v_WL - LW_v_W_LW
+        LW_v_B_LW = LW_v_WL - np.einsum("nlij,nj->nli", LW_X_B, B_v_WB) - LW_v_LW_L
+        O_X_B = LW_X_B
+        O_Xd_B = -LW_X_B @ _vx_matrix(np.einsum("nlij,nlj->nli", B_X_LW, LW_v_B_LW))
+    Jd = O_Xd_B @ B_J_WL_B @ T + O_X_B @ B_Jd_WL_B @ T + O_X_B @ B_J_WL_B @ Td
+    return data._out(Jd.astype(data.dtype))
 
 
 def free_floating_bias_forces(model: JaxSimModel, data: JaxSimModelData):

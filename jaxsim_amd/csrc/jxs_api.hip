@@ -57,6 +57,7 @@ hipError_t launch_mode(int mode, int G, const jxs::KParams<T>& P, const unsigned
     case jxs::MODE_STEP_RIGID: return launch_g<T, jxs::MODE_STEP_RIGID>(G, P, mblk, A, s);
     case jxs::MODE_STEP_RK4_RIGID: return launch_g<T, jxs::MODE_STEP_RK4_RIGID>(G, P, mblk, A, s);
     case jxs::MODE_CRBA: return launch_g<T, jxs::MODE_CRBA>(G, P, mblk, A, s);
+    case jxs::MODE_JAC: return launch_g<T, jxs::MODE_JAC>(G, P, mblk, A, s);
     default: return launch_g<T, jxs::MODE_KIN>(G, P, mblk, A, s);
   }
 }
@@ -544,6 +545,17 @@ int jxs_mass_matrix(jxs_model* model, const void* state, void* out_M, int N, voi
   // only the structurally non-zero entries are written by the kernel
   JXS_HIP(hipMemsetAsync(out_M, 0, elems * (model->dtype == JXS_F64 ? 8 : 4), static_cast<hipStream_t>(stream)));
   return run_any(model, jxs::MODE_CRBA, state, nullptr, nullptr, nullptr, 0, nullptr, out_M, nullptr, nullptr, N, 1, stream);
+}
+int jxs_jacobian_full(jxs_model* model, const void* state, void* out_J, void* out_B_H_L, int N, void* stream) {
+  if (out_J == nullptr) return fail(JXS_EINVAL, "null out_J");
+  if (model == nullptr) return fail(JXS_EINVAL, "null model");
+  if (N <= 0) return fail(JXS_EINVAL, "N must be positive");
+  jxs_layout lay;
+  jxs_model_layout(model, &lay);
+  const size_t nv = 6 + (size_t)lay.n_joints;
+  const size_t elems = (size_t)((N + lay.tile - 1) / lay.tile) * lay.tile * 12 * nv;
+  JXS_HIP(hipMemsetAsync(out_J, 0, elems * (model->dtype == JXS_F64 ? 8 : 4), static_cast<hipStream_t>(stream)));
+  return run_any(model, jxs::MODE_JAC, state, nullptr, nullptr, nullptr, 0, nullptr, out_J, out_B_H_L, nullptr, N, 1, stream);
 }
 int jxs_refresh_kinematics(jxs_model* model, const void* state, void* out_link_transforms, void* out_link_velocities,
                            int N, void* stream) {

@@ -374,6 +374,10 @@ struct Core {
       store_kinematics(lnk, level, R, r, vl, va, pB, doff, vBc, om);
       return;
     }
+    if (MODE == MODE_JAC) {
+      jacobians(lane, lnk, level, jrow, is_joint, is_root, R0, R, r, Sl, Sa, vl, va, vBc, om);
+      return;
+    }
 
     // ---- external link wrenches in C -----------------------------------------------------
     V fl[3] = {V(T(0)), V(T(0)), V(T(0))}, fa[3] = {V(T(0)), V(T(0)), V(T(0))};
@@ -1566,6 +1570,76 @@ struct Core {
       for (int e = 0; e < 6; ++e) {
         ln.gstore(A.out_a, ck + e * nv, Fk[e], is_root, rows);
         ln.gstore(A.out_a, ck * nv + e, Fk[e], is_root, rows);
+      }
+    }
+  }
+
+  // ==========================================================================================
+  // Doubly-left full Jacobian `B_J_full_WX_B` [6][6+n], its derivative `B_Jdot_full_WX_B` and the link
+  // poses `B_H_L` relative to the base (rbda/jacobian.py:128-339): everything the Jacobian API of the
+  // reference is assembled from (api/model.py:925-1228, api/contact.py:214-511).  Column 6+j of the full
+  // Jacobian is B_X_j S_j = the motion subspace of joint j in the base frame, the first six columns are the
+  // identity; column 6+j of the derivative is  B_v_{B,j} x (B_X_j S_j)  with the velocity of link j RELATIVE to
+  // the base (joint velocities only).  Frame C has its origin at the base position, so a rotation by R0^T is
+  // all that separates it from the base frame B.  out_a = [2*6*(6+n)][N] (J then Jdot, zeroed by the caller),
+  // out_H = [nL*12][N].
+  JXS_HD void jacobians(const VI& lane, const VI& lnk, const VI& level, const VI& jrow, const VM& is_joint,
+                        const VM& is_root, const V* R0, const V* R, const V* r, const V* Sl, const V* Sa,
+                        const V* vl, const V* va, const V* vBc, const V* om) const {
+    const VI zl = lane * 0;
+    const int nv = 6 + P.n, rows = 12 * nv;
+    // velocity field of the base (the link velocities of a fixed-base model start from zero, see run())
+    V v0l[3], v0a[3];
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+      v0l[e] = P.floating ? vBc[e] : V(T(0));
+      v0a[e] = P.floating ? om[e] : V(T(0));
+    }
+    auto to_base = [&](const V* x, V* o) {  // o = R0^T x
+      o[0] = R0[0] * x[0] + R0[3] * x[1] + R0[6] * x[2];
+      o[1] = R0[1] * x[0] + R0[4] * x[1] + R0[7] * x[2];
+      o[2] = R0[2] * x[0] + R0[5] * x[1] + R0[8] * x[2];
+    };
+    V sl[3], sa[3], wl[3], wa[3], t[3];
+    to_base(Sl, sl);
+    to_base(Sa, sa);
+#pragma unroll
+    for (int e = 0; e < 3; ++e) t[e] = vl[e] - v0l[e];
+    to_base(t, wl);
+#pragma unroll
+    for (int e = 0; e < 3; ++e) t[e] = va[e] - v0a[e];
+    to_base(t, wa);
+    // Jdot column = crm(w) s = [wa x sl + wl x sa ; wa x sa]   (math/cross.py:14-43)
+    V dl[3], da[3], t0[3], t1[3];
+    cross(wa, sl, t0);
+    cross(wl, sa, t1);
+    cross(wa, sa, da);
+#pragma unroll
+    for (int e = 0; e < 3; ++e) dl[e] = t0[e] + t1[e];
+    const VI col = jrow + 6;
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+      ln.gstore(A.out_a, col + e * nv, sl[e], is_joint, rows);
+      ln.gstore(A.out_a, col + (3 + e) * nv, sa[e], is_joint, rows);
+      ln.gstore(A.out_a, col + (6 + e) * nv, dl[e], is_joint, rows);
+      ln.gstore(A.out_a, col + (9 + e) * nv, da[e], is_joint, rows);
+    }
+#pragma unroll
+    for (int e = 0; e < 6; ++e) ln.gstore(A.out_a, zl + (e * nv + e), V(T(1)), is_root, rows);
+    if (A.out_H != nullptr) {
+      // B_H_L = [R0^T R | R0^T r]
+      const VM is_link = level >= 0;
+      V c0[3] = {R[0], R[3], R[6]}, c1[3] = {R[1], R[4], R[7]}, c2[3] = {R[2], R[5], R[8]}, b0[3], b1[3], b2[3], bp[3];
+      to_base(c0, b0);
+      to_base(c1, b1);
+      to_base(c2, b2);
+      to_base(r, bp);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        ln.gstore(A.out_H, lnk * 12 + (4 * i + 0), b0[i], is_link, P.nL * 12);
+        ln.gstore(A.out_H, lnk * 12 + (4 * i + 1), b1[i], is_link, P.nL * 12);
+        ln.gstore(A.out_H, lnk * 12 + (4 * i + 2), b2[i], is_link, P.nL * 12);
+        ln.gstore(A.out_H, lnk * 12 + (4 * i + 3), bp[i], is_link, P.nL * 12);
       }
     }
   }

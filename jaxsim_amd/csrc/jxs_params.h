@@ -118,9 +118,10 @@ enum Mode : int {
   MODE_STEP_RK4 = 5,  // js.model.step with IntegratorType.RungeKutta4  api/integrators.py:91-167
   MODE_STEP_RIGID = 6,  // js.model.step with the RigidContacts / RelaxedRigidContacts model  rbda/contacts/rigid.py:176-539
   MODE_STEP_RK4_RIGID = 7,  // RungeKutta4 with RigidContacts / RelaxedRigidContacts (contact forces solved at every stage)
-  MODE_CRBA = 8  // free_floating_mass_matrix: composite-rigid-body algorithm  rbda/crba.py:10-170, api/model.py:1553-1590
+  MODE_CRBA = 8,  // free_floating_mass_matrix: composite-rigid-body algorithm  rbda/crba.py:10-170, api/model.py:1553-1590
+  MODE_JAC = 9    // doubly-left full Jacobian and its derivative  rbda/jacobian.py:128-339
 };
-constexpr int kNumModes = 9;
+constexpr int kNumModes = 10;
 
 enum ForceRepr : int { REPR_INERTIAL = 0, REPR_BODY = 1, REPR_MIXED = 2 };  // api/common.py:39-47
 

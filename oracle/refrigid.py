@@ -130,12 +130,12 @@ def _mixed_base_frame(data):
     return W_H_BW, BW_H_B
 
 
-def generalized_free_floating_jacobian_inertial_output(model, data: rs.OracleData, input_repr):
-    """``generalized_free_floating_jacobian(..., output_vel_repr=Inertial)`` (model.py:925-1045) with
-    the generalized velocity expressed in ``input_repr``: ``W_J_WL_I`` [N,nL,6,6+n]."""
+def generalized_free_floating_jacobian(model, data: rs.OracleData, input_repr, output_repr):
+    """``generalized_free_floating_jacobian`` (model.py:925-1045): the generalized velocity in ``input_repr``,
+    the link velocities in ``output_repr``: ``O_J_WL_I`` [N,nL,6,6+n]."""
     n = model.kin_dyn_parameters.number_of_joints()
     dtype = data.dtype
-    B_J_full, _ = jacobian_full_doubly_left(model, data.joint_positions)
+    B_J_full, B_H_L = jacobian_full_doubly_left(model, data.joint_positions)
     W_H_B = data.base_transform
     if input_repr == VelRepr.Inertial:
         B_X_I = rm.adjoint_from_transform(W_H_B, inverse=True)
@@ -146,8 +146,19 @@ def generalized_free_floating_jacobian_inertial_output(model, data: rs.OracleDat
         B_X_I = rm.adjoint_from_transform(BW_H_B, inverse=True)
     B_J_full_I = B_J_full @ _block_diag_T(B_X_I, n)
     B_J_WL_I = _support_mask(model, dtype)[None, :, None, :] * B_J_full_I[:, None]
-    W_X_B = rm.adjoint_from_transform(W_H_B)
-    return W_X_B[:, None] @ B_J_WL_I
+    if output_repr == VelRepr.Inertial:  # :999-1006
+        return rm.adjoint_from_transform(W_H_B)[:, None] @ B_J_WL_I
+    if output_repr == VelRepr.Body:  # :1008-1015
+        return rm.adjoint_from_transform(B_H_L, inverse=True) @ B_J_WL_I
+    LW_H_L = W_H_B[:, None] @ B_H_L  # :1017-1037
+    LW_H_L[..., :3, 3] = 0
+    LW_H_B = LW_H_L @ rm.transform_inverse(B_H_L)
+    return rm.adjoint_from_transform(LW_H_B) @ B_J_WL_I
+
+
+def generalized_free_floating_jacobian_inertial_output(model, data: rs.OracleData, input_repr):
+    """``generalized_free_floating_jacobian(..., output_vel_repr=Inertial)``: ``W_J_WL_I`` [N,nL,6,6+n]."""
+    return generalized_free_floating_jacobian(model, data, input_repr, VelRepr.Inertial)
 
 
 def generalized_free_floating_jacobian_derivative_inertial(model, data: rs.OracleData):

@@ -774,3 +774,24 @@ def test_crba_kernel_matches_oracle(models, name, dtype, tol):
     scale = max(1.0, np.abs(ref).max())
     assert np.abs(out - ref).max() / scale < tol
     np.testing.assert_array_equal(out, np.transpose(out, (0, 2, 1)))  # mirrored entries are the same numbers
+
+
+@pytest.mark.parametrize("name", ["cartpole", "chain5", "chain9f", "anymal", "icub"])
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-11), (np.float32, 2e-5)])
+def test_jacobian_kernel_matches_oracle(models, name, dtype, tol):
+    """MODE_JAC: doubly-left full Jacobian, its derivative and B_H_L (rbda/jacobian.py:128-339)."""
+    from oracle import refrigid
+
+    model = models(name)
+    N = 4
+    d = models.random_data(name, N, seed=43, dtype=dtype)
+    nv, nL = 6 + model.dofs(), model.number_of_links()
+    JJ, BH = eb.run(model, eb.MODE_JAC, helpers.odata_to_block(model, d))
+    J = JJ[: 6 * nv].T.reshape(N, 6, nv)
+    Jd = JJ[6 * nv :].T.reshape(N, 6, nv)
+    du = helpers.upcast(d)
+    J_ref, BH_ref = refrigid.jacobian_full_doubly_left(model, du.joint_positions)
+    Jd_ref = refrigid.jacobian_derivative_full_doubly_left(model, du.joint_positions, du.joint_velocities)
+    assert helpers.rel_err(J, J_ref) < tol
+    assert helpers.rel_err(Jd, Jd_ref) < tol
+    assert helpers.rel_err(BH.T.reshape(N, nL, 3, 4), BH_ref[:, :, :3, :]) < tol

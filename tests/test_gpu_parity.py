@@ -1067,3 +1067,96 @@ def test_rigid_step_matches_unreduced_statement_gpu(models, key):
     ref = oracle.step(model, d, link_forces=f, joint_force_references=tau)
     out = js.model.step(model, to_gpu(model, d), link_forces=f, joint_force_references=tau)
     assert helpers.rel_err(out.state_block(), helpers.odata_to_block(model, ref)) < 1e-7
+
+
+# ---- Jacobian kernel + host assembly (rbda/jacobian.py:128-339, api/model.py:925-1228) ---------------------
+REPS = [VelRepr.Inertial, VelRepr.Body, VelRepr.Mixed]
+
+
+@pytest.mark.parametrize("name", ["cartpole", "chain9f", "anymal", "icub"])
+def test_jacobian_full_kernel_gpu(models, name):
+    from oracle import refrigid
+
+    model = models(name)
+    for dtype, tol in ((np.float64, 1e-11), (np.float32, 2e-5)):
+        d = models.random_data(name, 37, seed=43, dtype=dtype)
+        J, Jd, BH = js.model.jacobian_full_doubly_left(model, to_gpu(model, d))
+        du = helpers.upcast(d)
+        J_ref, BH_ref = refrigid.jacobian_full_doubly_left(model, du.joint_positions)
+        Jd_ref = refrigid.jacobian_derivative_full_doubly_left(model, du.joint_positions, du.joint_velocities)
+        assert helpers.rel_err(J, J_ref) < tol and helpers.rel_err(Jd, Jd_ref) < tol and helpers.rel_err(BH, BH_ref) < tol
+
+
+@pytest.mark.parametrize("in_rep", REPS)
+@pytest.mark.parametrize("out_rep", REPS)
+def test_link_jacobians_all_representations_gpu(models, in_rep, out_rep):
+    """``generalized_free_floating_jacobian`` for every (input, output) representation pair against the oracle's
+    restatement, and O_v_WL = O_J nu against the cached link velocities moved to the output representation."""
+    from oracle import refrigid
+
+    model = models("icub")
+    d = models.random_data("icub", 6, seed=51, rep=in_rep)
+    g = to_gpu(model, d)
+    J = js.model.generalized_free_floating_jacobian(model, g, output_vel_repr=REP[out_rep])
+    ref = refrigid.generalized_free_floating_jacobian(model, d, in_rep, out_rep)
+    assert J.shape == ref.shape and helpers.rel_err(J, ref) < 1e-10
+    nu = d.generalized_velocity(in_rep)
+    v = np.einsum("nlij,nj->nli", J, nu)
+    W_v = d.link_velocities  # inertial-fixed
+    H = d.link_transforms
+    expect = oracle.refstep.inertial_to_other_representation(W_v, out_rep, H, is_force=False)
+    assert helpers.rel_err(v, expect) < 1e-10
+
+
+def _advance(model, d, eps):
+    """The configuration a time eps later along the motion the state's velocities define (first order in the
+    positions is enough for a central difference): joints, base position, base orientation."""
+    w, v = d.base_angular_velocity, d.base_linear_velocity  # inertial-fixed
+    p = d.base_position + eps * (v + np.cross(w, d.base_position))
+    R = oracle.refmath.so3_from_quaternion(d.base_quaternion)
+    dR = oracle.refmath.rotation_from_axis_angle(eps * w)
+    Rn = dR @ R
+    # rotation matrix -> quaternion (w x y z), via the largest-trace branch (angles here are generic)
+    tr = np.trace(Rn, axis1=-2, axis2=-1)
+    qw = 0.5 * np.sqrt(1.0 + tr)
+    q = np.stack([qw, (Rn[:, 2, 1] - Rn[:, 1, 2]) / (4 * qw), (Rn[:, 0, 2] - Rn[:, 2, 0]) / (4 * qw), (Rn[:, 1, 0] - Rn[:, 0, 1]) / (4 * qw)], -1)
+    return oracle.OracleData.build(model, base_position=p, base_quaternion=q, joint_positions=d.joint_positions + eps * d.joint_velocities,
+                                   velocity_representation=d.velocity_representation)  # fmt: skip
+
+
+@pytest.mark.parametrize("in_rep", REPS)
+@pytest.mark.parametrize("out_rep", REPS)
+def test_link_jacobian_derivative_all_representations_gpu(models, in_rep, out_rep):
+    """``generalized_free_floating_jacobian_derivative`` (api/model.py:1046-1228) for every representation pair
+    against a central finite difference of the ORACLE's Jacobian along the motion, and the inertial / inertial
+    pair against the oracle's restatement of the derivative itself."""
+    from oracle import refrigid
+
+    model = models("anymal")
+    N = 4
+    d = models.random_data("anymal", N, seed=53, rep=in_rep)
+    assert np.all(1.0 + np.trace(oracle.refmath.so3_from_quaternion(d.base_quaternion), axis1=-2, axis2=-1) > 0.2)
+    Jd = js.model.generalized_free_floating_jacobian_derivative(model, to_gpu(model, d), output_vel_repr=REP[out_rep])
+    eps = 1e-6
+    Jp = refrigid.generalized_free_floating_jacobian(model, _advance(model, d, +eps), in_rep, out_rep)
+    Jm = refrigid.generalized_free_floating_jacobian(model, _advance(model, d, -eps), in_rep, out_rep)
+    fd = (Jp - Jm) / (2 * eps)
+    assert Jd.shape == fd.shape and helpers.rel_err(Jd, fd) < 2e-7
+    if in_rep == VelRepr.Inertial and out_rep == VelRepr.Inertial:
+        assert helpers.rel_err(Jd, refrigid.generalized_free_floating_jacobian_derivative_inertial(model, d)) < 1e-10
+
+
+def test_contact_jacobian_derivative_gpu(models):
+    """``js.contact.jacobian_derivative`` (api/contact.py:353-511), mixed in / mixed out, against the oracle's
+    restatement; and Jdot nu + J nudot = acceleration of the contact points' velocity (finite differences of the
+    oracle's point velocities along a step)."""
+    from oracle import refrigid
+
+    model = helpers.enable_points(models("anymal"), helpers.ANYMAL_FEET_16)
+    d = models.random_data("anymal", 5, seed=57)
+    g = to_gpu(model, d)
+    Jd = js.contact.jacobian_derivative(model, g)
+    ref = refrigid.contact_jacobian_derivative_mixed(model, d)
+    assert Jd.shape == ref.shape and helpers.rel_err(Jd, ref) < 1e-10
+    J = js.contact.jacobian(model, g)
+    assert helpers.rel_err(J, refrigid.contact_jacobian_mixed(model, d)) < 1e-10
