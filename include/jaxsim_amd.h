@@ -205,6 +205,12 @@ int jxs_gravity_torques(jxs_model* model, const void* state, void* out_tau, int 
  * are the 6x6 block congruence of api/model.py:1529-1551 applied by the caller.                  */
 int jxs_mass_matrix(jxs_model* model, const void* state, void* out_M, int N, void* stream);
 
+/* free_floating_mass_matrix_inverse (src/jaxsim/api/model.py:1593-1631, rbda/mass_inverse.py:11-233): the columns
+ * are the responses of the articulated-body factorisation to unit generalized forces, one launch.  Same
+ * layout and representation (MIXED) as jxs_mass_matrix; the six base rows / columns of a fixed-base model are
+ * zero (a fixed base does not accelerate).                                                       */
+int jxs_mass_matrix_inverse(jxs_model* model, const void* state, void* out_Minv, int N, void* stream);
+
 /* jacobian_full_doubly_left + jacobian_derivative_full_doubly_left (src/jaxsim/rbda/jacobian.py:128-339), one
  * launch: out_J = [2*6*(6+n)][N] = B_J_full_WX_B (6 x (6+n), row-major) followed by B_Jdot_full_WX_B, both with
  * input and output in the base frame ("doubly left"); out_B_H_L = [nL*12][N] rows of [R|p] of every link

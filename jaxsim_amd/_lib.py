@@ -218,6 +218,7 @@ def _declare(lib):
         "jxs_refresh_kinematics": [vp, vp, vp, vp, C.c_int, vp],
         "jxs_mass_matrix": [vp, vp, vp, C.c_int, vp],
         "jxs_jacobian_full": [vp, vp, vp, vp, C.c_int, vp],
+        "jxs_mass_matrix_inverse": [vp, vp, vp, C.c_int, vp],
         "jxs_comm_unique_id": [C.c_char * 128],
         "jxs_comm_init": [C.POINTER(vp), C.c_char * 128, C.c_int, C.c_int],
         "jxs_comm_destroy": [vp],

@@ -302,38 +302,28 @@ def free_floating_mass_matrix(model: JaxSimModel, data: JaxSimModelData):
     return data._out(M.astype(data.dtype))
 
 
-def _zero_velocity_replicas(model: JaxSimModel, data: JaxSimModelData, copies: int) -> JaxSimModelData:
-    """``copies`` replicas of the batch at zero velocity: environment e of replica k sits at k * N + e."""
-    from ..state import StateLayout
-
-    n = model.dofs()
-    blk = data.state_block().astype(np.float64)
-    L = StateLayout.of(model)
-    blk[L.row_vlin : L.row_vlin + 3] = 0
-    blk[L.row_vang : L.row_vang + 3] = 0
-    blk[L.row_sd : L.row_sd + n] = 0
-    return JaxSimModelData.from_state_block(model, np.tile(blk, (1, copies)).astype(data.dtype), data.velocity_representation)
-
-
 def free_floating_mass_matrix_inverse(model: JaxSimModel, data: JaxSimModelData):
-    """``M(q)^-1`` in the active velocity representation (``src/jaxsim/api/model.py:1593-1631``; the
-    reference runs its ``mass_inverse`` recursion).  Columns from ONE forward-dynamics launch over a
-    virtual batch at zero velocity: ``M^-1 e_i = FD(q, 0, e_i) - FD(q, 0, 0)`` with the unit generalized
-    forces applied as a base-link wrench (active representation) or a joint torque."""
-    N, n, nL = data.batch_size, model.dofs(), model.number_of_links()
+    """``M(q)^-1`` in the active velocity representation (``src/jaxsim/api/model.py:1593-1631``; the reference
+    runs its ``mass_inverse`` recursion, ``rbda/mass_inverse.py:11-233``): ONE launch of ``jxs_mass_matrix_inverse``
+    (columns = responses of the articulated-body factorisation to unit generalized forces, Mixed
+    representation), then the block congruence ``diag(X^-1, I) M^-1 diag(X^-1, I)^T`` for Body / Inertial."""
+    dm = runtime.device_model(model, data.dtype)
+    N, n = data.batch_size, model.dofs()
     nv = 6 + n
-    z = _zero_velocity_replicas(model, data, nv + 1)
-    tau = np.zeros((nv + 1, N, n))
-    f = np.zeros((nv + 1, N, nL, 6))
-    for k in range(6):
-        f[k, :, 0, k] = 1.0
-    for k in range(n):
-        tau[6 + k, :, k] = 1.0
-    vd, sdd = forward_dynamics_aba(model, z, joint_forces=tau.reshape(-1, n), link_forces=f.reshape(-1, nL, 6))
-    acc = np.concatenate([np.asarray(vd, np.float64), np.asarray(sdd, np.float64).reshape((nv + 1) * N, n)], -1)
-    acc = acc.reshape(nv + 1, N, nv)
-    Mi = np.transpose(acc[:nv] - acc[nv:], (1, 2, 0))
+    out = DeviceArray(nv * nv, N, data.dtype, tile=data._state.tile)
+    _lib.check(
+        _lib.load().jxs_mass_matrix_inverse(dm.handle, C.c_void_p(data._state.ptr), C.c_void_p(out.ptr), N, runtime._sp()),
+        "jxs_mass_matrix_inverse",
+    )
+    Mi = out.to_host().T.astype(np.float64).reshape(N, nv, nv)
     Mi = 0.5 * (Mi + np.transpose(Mi, (0, 2, 1)))
+    if data.velocity_representation != VelRepr.Mixed:
+        Xi = np.linalg.inv(_mixed_to_repr_block(data))
+        Xit = np.transpose(Xi, (0, 2, 1))
+        Mbb, Mbj = Mi[:, :6, :6].copy(), Mi[:, :6, 6:].copy()
+        Mi[:, :6, :6] = Xi @ Mbb @ Xit
+        Mi[:, :6, 6:] = Xi @ Mbj
+        Mi[:, 6:, :6] = np.transpose(Mi[:, :6, 6:], (0, 2, 1))
     return data._out(Mi.astype(data.dtype))
 
 

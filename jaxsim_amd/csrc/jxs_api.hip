@@ -58,6 +58,7 @@ hipError_t launch_mode(int mode, int G, const jxs::KParams<T>& P, const unsigned
     case jxs::MODE_STEP_RK4_RIGID: return launch_g<T, jxs::MODE_STEP_RK4_RIGID>(G, P, mblk, A, s);
     case jxs::MODE_CRBA: return launch_g<T, jxs::MODE_CRBA>(G, P, mblk, A, s);
     case jxs::MODE_JAC: return launch_g<T, jxs::MODE_JAC>(G, P, mblk, A, s);
+    case jxs::MODE_MINV: return launch_g<T, jxs::MODE_MINV>(G, P, mblk, A, s);
     default: return launch_g<T, jxs::MODE_KIN>(G, P, mblk, A, s);
   }
 }
@@ -545,6 +546,17 @@ int jxs_mass_matrix(jxs_model* model, const void* state, void* out_M, int N, voi
   // only the structurally non-zero entries are written by the kernel
   JXS_HIP(hipMemsetAsync(out_M, 0, elems * (model->dtype == JXS_F64 ? 8 : 4), static_cast<hipStream_t>(stream)));
   return run_any(model, jxs::MODE_CRBA, state, nullptr, nullptr, nullptr, 0, nullptr, out_M, nullptr, nullptr, N, 1, stream);
+}
+int jxs_mass_matrix_inverse(jxs_model* model, const void* state, void* out_Minv, int N, void* stream) {
+  if (out_Minv == nullptr) return fail(JXS_EINVAL, "null out_Minv");
+  if (model == nullptr) return fail(JXS_EINVAL, "null model");
+  if (N <= 0) return fail(JXS_EINVAL, "N must be positive");
+  jxs_layout lay;
+  jxs_model_layout(model, &lay);
+  const size_t nv = 6 + (size_t)lay.n_joints;
+  const size_t elems = (size_t)((N + lay.tile - 1) / lay.tile) * lay.tile * nv * nv;
+  JXS_HIP(hipMemsetAsync(out_Minv, 0, elems * (model->dtype == JXS_F64 ? 8 : 4), static_cast<hipStream_t>(stream)));
+  return run_any(model, jxs::MODE_MINV, state, nullptr, nullptr, nullptr, 0, nullptr, out_Minv, nullptr, nullptr, N, 1, stream);
 }
 int jxs_jacobian_full(jxs_model* model, const void* state, void* out_J, void* out_B_H_L, int N, void* stream) {
   if (out_J == nullptr) return fail(JXS_EINVAL, "null out_J");

@@ -661,6 +661,11 @@ struct Core {
       }
       ln.stamp(A, 7);  // pass 2
 
+      if (MODE == MODE_MINV) {
+        mass_inverse(lane, level, parent, child, jrow, is_joint, is_root, MA, U, S6, inv_d);
+        return;
+      }
+
       // Pass 3 (rbda/aba.py:240-267): base acceleration, then top-down.
       V a6[6];
       if (P.floating) {
@@ -1570,6 +1575,46 @@ struct Core {
       for (int e = 0; e < 6; ++e) {
         ln.gstore(A.out_a, ck + e * nv, Fk[e], is_root, rows);
         ln.gstore(A.out_a, ck * nv + e, Fk[e], is_root, rows);
+      }
+    }
+  }
+
+  // ==========================================================================================
+  // Inverse of the free-floating mass matrix (rbda/mass_inverse.py:11-233; api/model.py:1593-1631).  The
+  // reference runs a dedicated propagation; here column c of M^-1 is the response of the articulated-body
+  // factorisation (pass 2 above: U, 1/d, the LDL^T of the articulated base inertia) to the unit generalized
+  // force e_c -- a unit wrench on the base link for c < 6, a unit joint torque otherwise -- three columns per
+  // sweep.  Like the mass-matrix kernel the result is in MIXED representation (frame C); out_a = [(6+n)^2][N].
+  JXS_HD void mass_inverse(const VI& lane, const VI& level, const VI& parent, const VI* child, const VI& jrow,
+                           const VM& is_joint, const VM& is_root, const V* MA, const V* U, const V* S6,
+                           const V& inv_d) const {
+    TreeFac tf;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) tf.U[k] = U[k], tf.S6[k] = S6[k];
+    tf.inv_d = inv_d;
+    if (P.floating) ldl6_factor(MA, tf);
+    const int nv = 6 + P.n, rows = nv * nv;
+    const VI zl = lane * 0;
+    const V zero = V(T(0)), one = V(T(1));
+    for (int c0 = 0; c0 < nv; c0 += 3) {
+      V pAr[3][6], ar[3][6], sddr[3], taur[3];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const int c = c0 + r;  // wave-uniform column index
+#pragma unroll
+        for (int i = 0; i < 6; ++i) pAr[r][i] = vsel(is_root && (zl + c == i), -one, zero);  // pA = -wrench
+        taur[r] = vsel(is_joint && (jrow + 6 == zl + c), one, zero);
+      }
+      response<3>(lane, level, parent, child, tf, pAr, ar, sddr, taur);
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const int c = c0 + r;
+        if (c < nv) {
+          // a fixed base does not accelerate (rbda/aba.py:284-292): its six rows stay zero
+#pragma unroll
+          for (int i = 0; i < 6; ++i) ln.gstore(A.out_a, zl + (i * nv + c), ar[r][i], is_root && (P.floating != 0), rows);
+          ln.gstore(A.out_a, (jrow + 6) * nv + c, sddr[r], is_joint, rows);
+        }
       }
     }
   }

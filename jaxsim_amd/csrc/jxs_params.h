@@ -119,9 +119,10 @@ enum Mode : int {
   MODE_STEP_RIGID = 6,  // js.model.step with the RigidContacts / RelaxedRigidContacts model  rbda/contacts/rigid.py:176-539
   MODE_STEP_RK4_RIGID = 7,  // RungeKutta4 with RigidContacts / RelaxedRigidContacts (contact forces solved at every stage)
   MODE_CRBA = 8,  // free_floating_mass_matrix: composite-rigid-body algorithm  rbda/crba.py:10-170, api/model.py:1553-1590
-  MODE_JAC = 9    // doubly-left full Jacobian and its derivative  rbda/jacobian.py:128-339
+  MODE_JAC = 9,   // doubly-left full Jacobian and its derivative  rbda/jacobian.py:128-339
+  MODE_MINV = 10  // free_floating_mass_matrix_inverse  rbda/mass_inverse.py:11-233, api/model.py:1593-1631
 };
-constexpr int kNumModes = 10;
+constexpr int kNumModes = 11;
 
 enum ForceRepr : int { REPR_INERTIAL = 0, REPR_BODY = 1, REPR_MIXED = 2 };  // api/common.py:39-47
 

@@ -20,7 +20,7 @@ _HERE = pathlib.Path(__file__).resolve().parent
 _SRC = _HERE / "emul" / "jxs_emul.cpp"
 _SO = _HERE / "emul" / "libjxs_emul.so"
 _ROOT = _HERE.parent
-MODE_STEP, MODE_FD, MODE_ID, MODE_KIN, MODE_CRBA, MODE_JAC = 0, 1, 2, 3, 8, 9
+MODE_STEP, MODE_FD, MODE_ID, MODE_KIN, MODE_CRBA, MODE_JAC, MODE_MINV = 0, 1, 2, 3, 8, 9, 10
 
 
 def build(force: bool = False) -> pathlib.Path:
@@ -81,7 +81,7 @@ def run(model, mode, state, *, tau=None, link_forces=None, force_repr=0, in_acc=
 
     st, tau, link_forces, in_acc = up(state), up(tau), up(link_forces), up(in_acc)
     state_out = st.copy() if mode == MODE_STEP else None
-    out_a = alloc(6 + n) if mode in (MODE_FD, MODE_ID) else (alloc((6 + n) ** 2) if mode == MODE_CRBA else None)
+    out_a = alloc(6 + n) if mode in (MODE_FD, MODE_ID) else (alloc((6 + n) ** 2) if mode in (MODE_CRBA, MODE_MINV) else None)
     if mode == MODE_JAC:
         out_a = alloc(12 * (6 + n))
     out_H = alloc(nL * 12) if mode in (MODE_KIN, MODE_JAC) else None
@@ -96,7 +96,7 @@ def run(model, mode, state, *, tau=None, link_forces=None, force_repr=0, in_acc=
         return untile_block(state_out, rows_state, N, tile)
     if mode == MODE_KIN:
         return untile_block(out_H, nL * 12, N, tile), untile_block(out_V, nL * 6, N, tile)
-    if mode == MODE_CRBA:
+    if mode in (MODE_CRBA, MODE_MINV):
         return untile_block(out_a, (6 + n) ** 2, N, tile)
     if mode == MODE_JAC:
         return untile_block(out_a, 12 * (6 + n), N, tile), untile_block(out_H, nL * 12, N, tile)

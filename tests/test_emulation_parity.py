@@ -795,3 +795,27 @@ def test_jacobian_kernel_matches_oracle(models, name, dtype, tol):
     assert helpers.rel_err(J, J_ref) < tol
     assert helpers.rel_err(Jd, Jd_ref) < tol
     assert helpers.rel_err(BH.T.reshape(N, nL, 3, 4), BH_ref[:, :, :3, :]) < tol
+
+
+@pytest.mark.parametrize("name", ["cartpole", "chain5", "chain9f", "anymal", "icub"])
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-9), (np.float32, 3e-4)])
+def test_mass_inverse_kernel_matches_oracle(models, name, dtype, tol):
+    """MODE_MINV (rbda/mass_inverse.py:11-233): M^-1 in Mixed representation against the inverse of the oracle's
+    CRBA matrix; a fixed base does not accelerate, so its six rows and columns are zero and the joint block is
+    the inverse of the joint block of M."""
+    from oracle import refrigid
+
+    model = models(name)
+    N = 4
+    d = models.random_data(name, N, seed=45, dtype=dtype)
+    nv = 6 + model.dofs()
+    out = eb.run(model, eb.MODE_MINV, helpers.odata_to_block(model, d)).T.reshape(N, nv, nv).astype(np.float64)
+    du = helpers.upcast(d)
+    if model.floating_base():
+        ref = refrigid.free_floating_mass_matrix_inverse_mixed(model, du)
+    else:
+        M = refrigid.free_floating_mass_matrix_mixed(model, du)
+        ref = np.zeros_like(M)
+        ref[:, 6:, 6:] = np.linalg.inv(M[:, 6:, 6:])
+    scale = np.abs(ref).max()
+    assert np.abs(out - ref).max() / scale < tol
