@@ -193,6 +193,13 @@ int jxs_tile_to_env_major(const void* src, void* dst, int rows, int N, int tile,
  * not normalised (jnp.allclose(q.q, 1)), [2] = environments with any non-finite state entry.      */
 int jxs_validate_state(jxs_model* model, const void* state, int N, int* counts3, void* stream);
 
+/* RigidContacts only.  A contact-force QP or an impact solve whose result is not finite (fp32 on a numerically
+ * singular stance) is DISCARDED -- that environment takes the step without contact forces / without the
+ * velocity reset instead of poisoning its state -- where the reference would propagate NaN
+ * (src/jaxsim/rbda/contacts/rigid.py:331-379).  The discards are counted per model: counts2[0] = contact-force
+ * solves, counts2[1] = impact solves, in environments, since the last reset.  Synchronous.          */
+int jxs_solver_fault_counts(jxs_model* model, int* counts2, int reset, void* stream);
+
 /* Gravity compensation torques: the joint part of free_floating_gravity_forces
  * (src/jaxsim/api/model.py:1897-1931: RNEA at zero velocity, zero acceleration, no external forces),
  * written as [n][N] -- the layout jxs_step reads `tau` in, so a controller loop

@@ -68,6 +68,26 @@ def _check_quaternion(model, data: JaxSimModelData, *, normalized: bool) -> None
         raise ValueError("A RBDA received a quaternion that is not normalized.")
 
 
+def solver_fault_counts(model: JaxSimModel, dtype=np.float64, *, reset: bool = False) -> tuple[int, int]:
+    """RigidContacts: environments whose contact-force QP / impact solve was discarded (non-finite result) by
+    the steps of this model since the last reset -- ``(contact_force_solves, impact_solves)``.  The reference
+    would carry the NaN into the state (``rbda/contacts/rigid.py:331-379``); here the environment takes that
+    step without contact forces, and the event is counted instead of being silent."""
+    dm = runtime.device_model(model, np.dtype(dtype))
+    counts = (C.c_int * 2)()
+    _lib.check(_lib.load().jxs_solver_fault_counts(dm.handle, counts, int(bool(reset)), runtime._sp()), "jxs_solver_fault_counts")
+    return int(counts[0]), int(counts[1])
+
+
+def _check_solver_faults(model, data: JaxSimModelData) -> None:
+    """With ``JAXSIM_ENABLE_EXCEPTIONS`` a discarded solve raises like the reference's NaN checks would."""
+    if not _exceptions_enabled() or type(model.contact_model).__name__ != "RigidContacts":
+        return
+    qp, imp = solver_fault_counts(model, data.dtype, reset=True)
+    if qp or imp:
+        raise ValueError(f"RigidContacts: {qp} contact-force solve(s) and {imp} impact solve(s) were not finite and were discarded")
+
+
 def _ptr(d: DeviceArray | None):
     return None if d is None else C.c_void_p(d.ptr)
 
@@ -124,6 +144,7 @@ def step(
         ),
         "jxs_step",
     )  # fmt: skip
+    _check_solver_faults(model, data)
     if inplace:
         # the buffer of `data` now holds the new state: its lazily downloaded fields and cached
         # kinematics describe the old one

@@ -68,18 +68,25 @@ template <typename T>
 struct ModelT {
   jxs::Packed<T> pk;
   unsigned char* mblk = nullptr;
+  int* faults = nullptr;  // [2] discarded contact-force / impact solves since the last reset (rigid contact models)
 
-  ~ModelT() { (void)hipFree(mblk); }
+  ~ModelT() {
+    (void)hipFree(mblk);
+    (void)hipFree(faults);
+  }
 
   hipError_t upload_all() {
     const std::vector<unsigned char> b = pk.block();
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&mblk), b.size());
     if (e != hipSuccess) return e;
-    return hipMemcpy(mblk, b.data(), b.size(), hipMemcpyHostToDevice);
+    if ((e = hipMemcpy(mblk, b.data(), b.size(), hipMemcpyHostToDevice)) != hipSuccess) return e;
+    if ((e = hipMalloc(reinterpret_cast<void**>(&faults), 2 * sizeof(int))) != hipSuccess) return e;
+    return hipMemset(faults, 0, 2 * sizeof(int));
   }
   jxs::KArgs<T> args(int N) const {
     jxs::KArgs<T> a{};
     a.N = N;
+    a.faults = faults;
     return a;
   }
 };
@@ -534,6 +541,15 @@ int jxs_gravity_torques(jxs_model* model, const void* state, void* out_tau, int 
   if (out_tau == nullptr) return fail(JXS_EINVAL, "null out_tau");
   return run_any(model, jxs::MODE_ID, state, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, N, 1, stream,
                  out_tau);
+}
+int jxs_solver_fault_counts(jxs_model* model, int* counts2, int reset, void* stream) {
+  if (model == nullptr || counts2 == nullptr) return fail(JXS_EINVAL, "null argument");
+  int* d = model->dtype == JXS_F64 ? model->f64->faults : model->f32->faults;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  JXS_HIP(hipMemcpyAsync(counts2, d, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+  if (reset) JXS_HIP(hipMemsetAsync(d, 0, 2 * sizeof(int), s));
+  JXS_HIP(hipStreamSynchronize(s));
+  return JXS_OK;
 }
 int jxs_mass_matrix(jxs_model* model, const void* state, void* out_M, int N, void* stream) {
   if (out_M == nullptr) return fail(JXS_EINVAL, "null out_M");

@@ -139,10 +139,10 @@ struct Core {
     V s = ln.gload(A.state_in, jrow_c + P.row_s, P.n_rows);
     V sd = ln.gload(A.state_in, jrow_c + P.row_sd, P.n_rows);
     ln.fence();
-    ln.stamp_after(A, 11, jrow);   // profiling build: index tables arrived
-    ln.stamp_after(A, 12, q[3]);   // base rows of the state arrived
-    ln.stamp_after(A, 13, ps0.hd); // point-slot tables arrived
-    ln.stamp_after(A, 14, sd);     // joint rows of the state arrived (dependent on the index table)
+    ln.stamp_after(A, 20, jrow);   // profiling build: index tables arrived
+    ln.stamp_after(A, 21, q[3]);   // base rows of the state arrived
+    ln.stamp_after(A, 22, ps0.hd); // point-slot tables arrived
+    ln.stamp_after(A, 23, sd);     // joint rows of the state arrived (dependent on the index table)
     // Stage B: loads that need the rest of the argument block.
     if (MODE == MODE_ID && A.id_zero_vel) {
       sd = V(T(0));

@@ -26,10 +26,15 @@ struct KTail {
   T* out_tau;
   int id_zero_vel;
   long long* dbg;
+  int* faults;
 };
 
-template <typename T, int G, int MODE>
-__global__ __launch_bounds__(64) void jxs_kernel(const T* pre_state_in, T* pre_state_out, const unsigned char* __restrict__ pre_mblk,
+// OCC2 (rigid contact modes only): compiled for two waves per SIMD (at most 256 registers; a few values go
+// to scratch).  Measured on the quadruped with one point per foot: -2 % at 4096 environments (one wave per
+// SIMD either way), +26 % at 16384, +58 % at 65536 -- the launcher picks it when the grid has more waves than
+// the chip has SIMDs and the LDS footprint of the contact problem lets a second wave in.
+template <typename T, int G, int MODE, bool OCC2 = false>
+__global__ __launch_bounds__(64, OCC2 ? 2 : 1) void jxs_kernel(const T* pre_state_in, T* pre_state_out, const unsigned char* __restrict__ pre_mblk,
                                                  const T* pre_tau, const T* pre_link_f, int pre_N, int pre_n_rows,
                                                  int pre_n, int pre_force_repr, int pre_n_steps,
                                                  const KTail<T> tail) {
@@ -46,7 +51,7 @@ __global__ __launch_bounds__(64) void jxs_kernel(const T* pre_state_in, T* pre_s
   A.rti = reinterpret_cast<const int*>(pre_mblk + jxs::mblk_off_rti<T>(G));
   A.chunks = pre_mblk + jxs::mblk_off_chunks<T>(G);
   A.in_a = tail.in_a, A.out_a = tail.out_a, A.out_H = tail.out_H, A.out_V = tail.out_V, A.out_tau = tail.out_tau;
-  A.id_zero_vel = tail.id_zero_vel, A.dbg = tail.dbg;
+  A.id_zero_vel = tail.id_zero_vel, A.dbg = tail.dbg, A.faults = tail.faults;
   // the state-block rows of SURVEY section 8(a) row D, derived from the preloaded joint count instead of loaded
   P.n_rows = pre_n_rows, P.n = pre_n;
   P.row_pos = 0, P.row_quat = 3, P.row_s = 7, P.row_vlin = 7 + pre_n, P.row_vang = 10 + pre_n, P.row_sd = 13 + pre_n;
@@ -67,6 +72,7 @@ hipError_t launch_one(const jxs::KParams<T>& P, const unsigned char* mblk, const
   const bool rows = P.row_mode && (MODE == jxs::MODE_STEP || MODE == jxs::MODE_ROLLOUT || MODE == jxs::MODE_FD ||
                                    MODE == jxs::MODE_STEP_RK4);
   size_t lds_bytes = rows ? sizeof(T) * (size_t)envs_per_wave * jxs::lds_words_per_env(G) : 0;
+  const KTail<T> tail{A.in_a, A.out_a, A.out_H, A.out_V, A.out_tau, A.id_zero_vel, A.dbg, A.faults};
   if (MODE == jxs::MODE_STEP_RIGID || MODE == jxs::MODE_STEP_RK4_RIGID) {
     lds_bytes = sizeof(T) * (size_t)envs_per_wave * jxs::rigid_lds_words_per_env(P.n_cp, P.rigid);
     if (lds_bytes > 64 * 1024) {  // beyond the default dynamic-LDS window (gfx950 has 160 KiB per CU)
@@ -74,8 +80,15 @@ hipError_t launch_one(const jxs::KParams<T>& P, const unsigned char* mblk, const
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
       if (e != hipSuccess) return e;
     }
+    // two waves per SIMD pay off once there are more waves than SIMDs (256 CUs x 4) and eight of them fit
+    // the LDS of a CU (160 KiB)
+    constexpr bool kHasOcc2 = (MODE == jxs::MODE_STEP_RIGID || MODE == jxs::MODE_STEP_RK4_RIGID) && sizeof(T) == 4;
+    if (kHasOcc2 && blocks > 1024 && lds_bytes * 8 <= 160 * 1024 && P.n_cp <= 8) {
+      hipLaunchKernelGGL((jxs_kernel<T, G, MODE, kHasOcc2>), dim3(blocks), dim3(64), lds_bytes, s, A.state_in, A.state_out, mblk,
+                         A.tau, A.link_f, A.N, P.n_rows, P.n, A.force_repr, A.n_steps, tail);
+      return hipGetLastError();
+    }
   }
-  const KTail<T> tail{A.in_a, A.out_a, A.out_H, A.out_V, A.out_tau, A.id_zero_vel, A.dbg};
   hipLaunchKernelGGL((jxs_kernel<T, G, MODE>), dim3(blocks), dim3(64), lds_bytes, s, A.state_in, A.state_out, mblk, A.tau,
                      A.link_f, A.N, P.n_rows, P.n, A.force_repr, A.n_steps, tail);
   return hipGetLastError();

@@ -96,7 +96,7 @@ struct DeviceLanes {
   __device__ __forceinline__ void stamp(const KA& A, int i) const {
 #ifdef JXS_PHASE_TIMING
     __builtin_amdgcn_sched_barrier(0);
-    if (A.dbg != nullptr && threadIdx.x == 0) A.dbg[(size_t)blockIdx.x * 16 + i] = (long long)__builtin_readcyclecounter();
+    if (A.dbg != nullptr && threadIdx.x == 0) A.dbg[(size_t)blockIdx.x * kDbgSlots + i] = (long long)__builtin_readcyclecounter();
     __builtin_amdgcn_sched_barrier(0);
 #else
     (void)A;
@@ -104,6 +104,19 @@ struct DeviceLanes {
 #endif
   }
 
+  // developer profiling build: slot `i` = max over the lanes / calls of `value` (iteration counts)
+  template <class KA>
+  __device__ __forceinline__ void debug_max(const KA& A, int i, int value) const {
+#ifdef JXS_PHASE_TIMING
+    if (A.dbg != nullptr) atomicMax(reinterpret_cast<unsigned long long*>(&A.dbg[(size_t)blockIdx.x * kDbgSlots + i]), (unsigned long long)value);
+#else
+    (void)A, (void)i, (void)value;
+#endif
+  }
+  // One count per ENVIRONMENT whose solve was discarded (jxs_solver_fault_counts): lane 0 of the group adds.
+  __device__ __forceinline__ void count_fault(int* counters, int which, bool faulty) const {
+    if (counters != nullptr && faulty && lane_ == 0 && env_ok_) atomicAdd(&counters[which], 1);
+  }
   // developer profiling build: stamp `i` once `value` has arrived (the dummy use makes the compiler wait for it)
   template <class KA, class X>
   __device__ __forceinline__ void stamp_after(const KA& A, int i, X value) const {

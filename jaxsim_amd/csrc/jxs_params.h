@@ -107,6 +107,7 @@ JXS_HD constexpr int rigid_lds_words_per_env(int n_cp, int rigid = 1) {
 }
 constexpr int kQpMaxIter = 30;    // interior-point iterations (oracle/refrigid.py QP_MAX_ITER)
 constexpr int kRigidMaxPoints = 32;
+constexpr int kDbgSlots = 32;      // developer profiling build: cycle stamps / counters per workgroup
 constexpr int kImpactCgIters = 5;  // preconditioned CG iterations of the impact solve (jxs_rigid.inc)
 
 enum Mode : int {
@@ -201,7 +202,8 @@ struct KArgs {
   int n_steps;         // MODE_STEP: consecutive steps fused in this launch (state carried in registers)
   T* out_tau;          // MODE_ID, optional: joint torques only, [n][N] (the layout `tau` is read in)
   int id_zero_vel;     // MODE_ID: evaluate at zero velocity (gravity term g(q), api/model.py:1897-1931)
-  long long* dbg;      // developer builds (-DJXS_PHASE_TIMING): [blocks][16] cycle stamps, else null
+  long long* dbg;      // developer builds (-DJXS_PHASE_TIMING): [blocks][kDbgSlots] cycle stamps, else null
+  int* faults;         // [2] environments whose QP contact-force solve / impact solve was discarded (non-finite), or null
 };
 
 // ---- device model block: ONE allocation per model that the kernels address from a single pointer -------

@@ -173,6 +173,11 @@ struct HostLanes {
   void stamp(const KA&, int) const {}
   template <class KA, class X>
   void stamp_after(const KA&, int, const X&) const {}
+  template <class KA>
+  void debug_max(const KA&, int, int) const {}
+  void count_fault(int* counters, int which, const VM& faulty) const {
+    if (counters != nullptr && faulty.v[0]) counters[which] += 1;
+  }
 
   template <typename U>
   Vec<U, G> shfl(const Vec<U, G>& x, const VI& src) const {

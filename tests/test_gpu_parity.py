@@ -1160,3 +1160,31 @@ def test_contact_jacobian_derivative_gpu(models):
     assert Jd.shape == ref.shape and helpers.rel_err(Jd, ref) < 1e-10
     J = js.contact.jacobian(model, g)
     assert helpers.rel_err(J, refrigid.contact_jacobian_mixed(model, d)) < 1e-10
+
+
+def test_discarded_rigid_solves_are_counted_gpu(models):
+    """A non-finite QP / impact solve is discarded AND counted (jxs_solver_fault_counts): well-posed steps
+    report zero; a state with a NaN joint velocity makes the solves of that environment non-finite, which
+    shows up in the counters (and raises when JAXSIM_ENABLE_EXCEPTIONS is set) instead of passing silently."""
+    import os
+
+    model = helpers.rigid_model(models("anymal"), helpers.ANYMAL_FEET_4, K=1e4, D=1e2)
+    d = helpers.standing_data(model, 12, seed=3)
+    g = to_gpu(model, d)
+    js.model.solver_fault_counts(model, np.float64, reset=True)
+    js.model.step(model, g)
+    assert js.model.solver_fault_counts(model, np.float64) == (0, 0)
+    blk = helpers.odata_to_block(model, d)
+    n = model.dofs()
+    blk[13 + n + 2, 5] = np.nan  # one joint velocity of environment 5
+    bad = js.data.JaxSimModelData.from_state_block(model, blk)
+    js.model.step(model, bad)
+    qp, imp = js.model.solver_fault_counts(model, np.float64, reset=True)
+    assert qp >= 1 and qp + imp <= 2, (qp, imp)
+    assert js.model.solver_fault_counts(model, np.float64) == (0, 0)
+    os.environ["JAXSIM_ENABLE_EXCEPTIONS"] = "1"
+    try:
+        with pytest.raises(ValueError, match="discarded"):
+            js.model.step(model, bad)
+    finally:
+        os.environ.pop("JAXSIM_ENABLE_EXCEPTIONS")

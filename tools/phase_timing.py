@@ -18,15 +18,15 @@ lib = _lib.load()
 dm = runtime.device_model(model, np.float32)
 blocks = (N + 1) // 2
 buf = C.c_void_p()
-lib.jxs_malloc(C.byref(buf), blocks * 16 * 8)
-lib.jxs_memset(buf, 0, blocks * 16 * 8, None)
+lib.jxs_malloc(C.byref(buf), blocks * 32 * 8)
+lib.jxs_memset(buf, 0, blocks * 32 * 8, None)
 lib.jxs_debug_set_stamp_buffer.argtypes = [C.c_void_p]
 lib.jxs_debug_set_stamp_buffer(buf)
 ptr = C.c_void_p(data._state.ptr)
 for _ in range(20):
     lib.jxs_step(dm.handle, ptr, ptr, None, None, 2, N, None)
 runtime.synchronize()
-out = np.zeros((blocks, 16), dtype=np.int64)
+out = np.zeros((blocks, 32), dtype=np.int64)
 lib.jxs_memcpy_d2h(out.ctypes.data_as(C.c_void_p), buf, out.nbytes, None)
 d = np.diff(out[:, :11], axis=1)
 names = ["loads arrive", "actuation+local xform", "FK (pointer jumping)", "velocities", "contacts", "inertia+bias",
@@ -35,8 +35,8 @@ print(f"N={N}: mean cycles per phase over {blocks} waves (s_memtime ticks)")
 for n, m, mx in zip(names, d.mean(axis=0), d.max(axis=0)):
     print(f"  {n:24s} {m:9.0f}  (max {mx})")
 print(f"  {'total':24s} {(out[:, 10] - out[:, 0]).mean():9.0f}")
-if out[:, 11].any():
-    for i, n in ((11, "index tables arrived"), (12, "base state rows arrived"), (13, "point tables arrived"), (14, "joint state rows arrived")):
+if out[:, 20].any():
+    for i, n in ((20, "index tables arrived"), (21, "base state rows arrived"), (22, "point tables arrived"), (23, "joint state rows arrived")):
         print(f"  since wave start: {n:28s} {(out[:, i] - out[:, 0]).mean():9.0f}  (max {(out[:, i] - out[:, 0]).max()})")
 span = out[:, 10].max() - out[:, 0].min()
 print(f"  first start -> last end: {span} ticks")

@@ -34,16 +34,16 @@ lib = _lib.load()
 dm = runtime.device_model(model, np.float32)
 blocks = (N + dm.layout.tile - 1) // dm.layout.tile
 buf = C.c_void_p()
-lib.jxs_malloc(C.byref(buf), blocks * 16 * 8)
+lib.jxs_malloc(C.byref(buf), blocks * 32 * 8)
 lib.jxs_debug_set_stamp_buffer.argtypes = [C.c_void_p]
 ptr = C.c_void_p(data._state.ptr)
 for _ in range(60):
     lib.jxs_step(dm.handle, ptr, ptr, None, None, 2, N, None)
-lib.jxs_memset(buf, 0, blocks * 16 * 8, None)
+lib.jxs_memset(buf, 0, blocks * 32 * 8, None)
 lib.jxs_debug_set_stamp_buffer(buf)
 lib.jxs_step(dm.handle, ptr, ptr, None, None, 2, N, None)
 runtime.synchronize()
-out = np.zeros((blocks, 16), dtype=np.int64)
+out = np.zeros((blocks, 32), dtype=np.int64)
 lib.jxs_memcpy_d2h(out.ctypes.data_as(C.c_void_p), buf, out.nbytes, None)
 if kind == "relaxed":
     has = (out[:, 11] > 0) & (out[:, 13] > 0)
@@ -57,7 +57,7 @@ if kind == "relaxed":
     print("  refinement            %9.0f" % (o[:, 13] - o[:, 15]).mean())
     print("  everything else       %9.0f" % (tot - (o[:, 13] - o[:, 11])).mean())
     sys.exit(0)
-has = (out[:, 11] > 0) & (out[:, 14] > 0)
+has = (out[:, 13] > out[:, 12]) & (out[:, 15] > out[:, 14]) & (out[:, 14] > out[:, 13])
 print(f"points={pts} N={N}: {blocks} waves, {has.sum()} with contacts in both stages")
 o = out[has]
 tot = o[:, 10] - o[:, 0]
@@ -66,6 +66,10 @@ print("  stage0 delassus       %9.0f" % (o[:, 12] - o[:, 11]).mean())
 print("  stage0 QP             %9.0f (max %d)" % ((o[:, 13] - o[:, 12]).mean(), (o[:, 13] - o[:, 12]).max()))
 print("  stage1 delassus+impact%9.0f" % (o[:, 15] - o[:, 14]).mean())
 print("  everything else       %9.0f" % (tot - (o[:, 13] - o[:, 11]) - (o[:, 15] - o[:, 14])).mean())
+print("  QP iterations (max over the wave): mean %.1f  p90 %d  max %d" % (o[:, 16].mean(), np.percentile(o[:, 16], 90), o[:, 16].max()))
+print("  impact CG iterations:              mean %.1f  max %d" % (o[:, 17].mean(), o[:, 17].max()))
+worst = np.argsort(-tot)[:5]
+print("  slowest waves: total / QP / impact / QP iterations:", [(int(tot[i]), int(o[i, 13] - o[i, 12]), int(o[i, 15] - o[i, 14]), int(o[i, 16])) for i in worst])
 free = out[~has & (out[:, 10] > 0)]
 if len(free):
     print("  waves without contact: total %9.0f" % (free[:, 10] - free[:, 0]).mean())
