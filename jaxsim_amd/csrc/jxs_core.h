@@ -69,6 +69,43 @@ struct Core {
     return (i <= j) ? (i * 6 - (i * (i - 1)) / 2 + (j - i)) : (j * 6 - (j * (j - 1)) / 2 + (i - j));
   }
 
+  // Reference-point change of an articulated inertia and its bias force, both world-aligned: from a point
+  // O_c to O_p with d = O_c - O_p.  M' = X^T M X, p' = X^T p with X = [[I, -S(d)], [0, I]] (motion about O_p
+  // -> motion about O_c).  Blocks M = [[A, B], [B^T, D]]:
+  //   A' = A,   B' = B - A S(d),   D' = D + S(d) B' + (S(d) B)^T,   p' = [f; n + d x f].
+  static JXS_HD void xlate_inertia(V* M, V* p, const V* d) {
+    V Y[3][3], Bn[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {  // Y_i = A_i x d  (row i of A S(d))
+      const V a0 = M[sidx(i, 0)], a1 = M[sidx(i, 1)], a2 = M[sidx(i, 2)];
+      Y[i][0] = a1 * d[2] - a2 * d[1];
+      Y[i][1] = a2 * d[0] - a0 * d[2];
+      Y[i][2] = a0 * d[1] - a1 * d[0];
+    }
+    // W = S(d) B and W' = S(d) B': entry [i][j] = (d x column j)_i
+    auto sx = [&](const V (*Bm)[3], int i, int j) {
+      const int i1 = (i + 1) % 3, i2 = (i + 2) % 3;
+      return d[i1] * Bm[i2][j] - d[i2] * Bm[i1][j];
+    };
+    V Bo[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) Bo[i][j] = M[sidx(i, 3 + j)], Bn[i][j] = Bo[i][j] - Y[i][j];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = i; j < 3; ++j) M[sidx(3 + i, 3 + j)] = M[sidx(3 + i, 3 + j)] + sx(Bn, i, j) + sx(Bo, j, i);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) M[sidx(i, 3 + j)] = Bn[i][j];
+    V t[3];
+    cross(d, p, t);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) p[3 + k] = p[3 + k] + t[k];
+  }
+
   // ==========================================================================================
   template <int MODE>
   JXS_HD void run() {
@@ -135,6 +172,10 @@ struct Core {
     // hold at least one (empty) slot per lane, so the load is legal whatever the contact model
     PointSlot ps0;
     if (kStep) load_slot_tables(lane, 0, ps0);
+    // tables of the row-distributed ABA passes: always present in the model block, loaded whatever the layout
+    // the model ends up using (the flag that decides lives in the parameter block, one scalar load away)
+    RowTabs rt;
+    if ((kStep || MODE == MODE_FD) && !kRigid) load_row_tabs(rt);
     const VI jrow_c = vsel(jrow >= 0, jrow, lane * 0);
     V s = ln.gload(A.state_in, jrow_c + P.row_s, P.n_rows);
     V sd = ln.gload(A.state_in, jrow_c + P.row_sd, P.n_rows);
@@ -156,9 +197,7 @@ struct Core {
 #pragma unroll
       for (int k = 0; k < 6; ++k) f6in[k] = ln.gload(A.link_f, lrow + k, P.nL * 6);
     }
-    RowTabs rt;
     const bool with_rows = P.row_mode && (kStep || MODE == MODE_FD) && !kRigid;
-    if (with_rows) load_row_tabs(rt);
     const bool with_contacts = (kStep && !kRigid) && P.n_chunks > 0;  // soft contacts (state m)
 
     const VM is_joint = jtype != 0;
@@ -319,6 +358,21 @@ struct Core {
     }
     ln.stamp(A, 3);  // forward kinematics
 
+    // Anchored ABA (see "G: articulated-body algorithm" below): origin of the leaf link of this lane's
+    // first-child chain, and of the parent's chain -- fetched here so that the shuffles complete behind the
+    // velocity and contact phases.
+    constexpr bool kAnchMode = (kStep && !kRigid) || MODE == MODE_FD;
+    const bool anch = kAnchMode && P.anchored != 0;
+    V ra[3] = {V(T(0)), V(T(0)), V(T(0))}, dpl[3] = {V(T(0)), V(T(0)), V(T(0))};
+    if (anch) {
+      const VI anchor = ln.lconsti(A.lti, LI_ANCHOR), panchor = ln.lconsti(A.lti, LI_PANCHOR);
+      V rq[3];
+#pragma unroll
+      for (int e = 0; e < 3; ++e) ra[e] = ln.shfl(r[e], anchor), rq[e] = ln.shfl(r[e], panchor);
+#pragma unroll
+      for (int e = 0; e < 3; ++e) dpl[e] = ra[e] - rq[e];
+    }
+
     // Base velocity in C: [v_W + w x p_B ; w] (= mixed velocity).  ABA keeps v_0 = 0 for a
     // fixed base (rbda/aba.py:109-121) while the cached link velocities still start from the
     // stored base velocity (rbda/forward_kinematics.py:69-70): `vBx` carries that difference.
@@ -434,13 +488,23 @@ struct Core {
       }
     }
 
+    // anchored ABA: from here on the link wrench sums (fl, fa) are referred to the lane's anchor -- the
+    // external wrench is shifted once, the contact moments below are formed about the anchor directly
+    // (lever = centimetres instead of the distance to the base: (r_C - ra) x f instead of r_C x f - ra x f)
+    if (anch && A.link_f != nullptr) {
+      V t[3];
+      cross(ra, fl, t);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) fa[k] = fa[k] - t[k];
+    }
+
     // ---- J,K,L,I: soft contacts ----------------------------------------------------------
     if (with_contacts && with_rows && P.n_chunks == 1) {
       // The kinematics of the parent links reach the point lanes through the LDS scratch of the
       // row-distributed layout (18 writes + 18 reads, one round trip) instead of 18 ds_bpermute:
       // measured 9.70 -> 9.56 us per step (ds_bpermute issues every ~22 cycles for a lone wave).
       const int KIN = lds_kin_offset(G);
-      const VI kb = lane * 18 + KIN;
+      const VI kb = lane * kKinRec + KIN;
 #pragma unroll
       for (int e = 0; e < 9; ++e) ln.lds_write(kb + e, R[e]);
 #pragma unroll
@@ -448,25 +512,29 @@ struct Core {
         ln.lds_write(kb + (9 + e), r[e]);
         ln.lds_write(kb + (12 + e), vl[e]);
         ln.lds_write(kb + (15 + e), va[e]);
+        ln.lds_write(kb + (18 + e), ra[e]);
       }
       ln.lds_sync();
       const VM valid = ps0.body >= 0;
-      V m[3], Rb[9], rb[3], vbl[3], vba[3];
+      V m[3], Rb[9], rb[3], vbl[3], vba[3], rab[3];
 #pragma unroll
       for (int k = 0; k < 3; ++k) m[k] = vsel(valid, ps0.m[k], V(T(0)));
-      const VI kr = vsel(valid, ps0.body, lane * 0) * 18 + KIN;
+      const VI kr = vsel(valid, ps0.body, lane * 0) * kKinRec + KIN;
 #pragma unroll
       for (int e = 0; e < 9; ++e) Rb[e] = ln.lds_read(kr + e);
 #pragma unroll
-      for (int e = 0; e < 3; ++e) rb[e] = ln.lds_read(kr + (9 + e)), vbl[e] = ln.lds_read(kr + (12 + e)), vba[e] = ln.lds_read(kr + (15 + e));
+      for (int e = 0; e < 3; ++e) {
+        rb[e] = ln.lds_read(kr + (9 + e)), vbl[e] = ln.lds_read(kr + (12 + e)), vba[e] = ln.lds_read(kr + (15 + e));
+        rab[e] = ln.lds_read(kr + (18 + e));
+      }
       ln.lds_sync();
       V w6[6], mdl[3];
-      point_physics(valid, ps0.Lp, m, Rb, rb, vbl, vba, pB, doff, vBc, om, w6, mdl);
+      point_physics(valid, ps0.Lp, m, Rb, rb, vbl, vba, rab, pB, doff, vBc, om, w6, mdl);
 #pragma unroll
       for (int k = 0; k < 3; ++k) ps0.md[k] = mdl[k];
       link_wrench_sums(lane, ps0.tail, ps0.hd, w6, fl, fa);
     } else
-    if (with_contacts) contacts(lane, ps0, R, r, vl, va, pB, doff, vBc, om, fl, fa);  // sets ps0.md
+    if (with_contacts) contacts(lane, ps0, R, r, vl, va, ra, pB, doff, vBc, om, fl, fa);  // sets ps0.md
     ln.stamp(A, 5);  // contacts
 
     // ---- link inertia in C and bias force --------------------------------------------------
@@ -520,12 +588,36 @@ struct Core {
     }
 
     // ---- G: articulated-body algorithm ------------------------------------------------------
+    // Anchored ABA.  With one reference point for the whole tree (the origin of C) the articulated inertias
+    // of the light distal links carry parallel-axis terms m |r|^2 of a lever r ~ 1 m that must cancel in
+    // d = S^T MA S; in fp32 that costs a median step error of 8e-6 where the reference formulation (link
+    // coordinates) has 1e-7 (tools/fp32_error.py).  Moving the origin of C to the feet helps the ankles and hurts
+    // the arms by the same factor (measured), so every FIRST-CHILD CHAIN gets its own reference point: the
+    // origin of its leaf link (`ra`, relative to the origin of C).  Along a chain nothing changes -- parents
+    // still simply add -- and only where a non-first child joins its parent (a branching link) the inertia
+    // is re-referred by `dpl` = anchor(child chain) - anchor(parent chain) (xlate_inertia).  Motion vectors
+    // shift as [lin - ra x ang; ang], force vectors as [f; n - ra x f].
+    if (anch) {
+      V t[3];
+      cross(ra, Sa, t);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) Sl[k] = Sl[k] - t[k];
+      cross(ra, ca, t);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) cl[k] = cl[k] - t[k], cw[k] = cw[k] - ra[k];
+    }
     // pA_i = v x* M v - f_i          (rbda/aba.py:109-121,157-160)
     V pA[6];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       pA[k] = bl[k] - fl[k];
       pA[3 + k] = ba[k] - fa[k];
+    }
+    if (anch) {  // the bias force moves to the anchor; (fl, fa) are referred to it already
+      V t[3];
+      cross(ra, bl, t);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) pA[3 + k] = pA[3 + k] - t[k];
     }
     // MA_i = M_i (upper triangle of the symmetric 6x6)
     V MA[21];
@@ -562,7 +654,17 @@ struct Core {
     V acl[3], aca[3];  // base spatial acceleration in C incl. gravity (valid in every lane)
     if (P.row_mode && (kStep || MODE == MODE_FD) && !kRigid) {
       V a0[6];
-      aba_rows(lane, rt, MA, pA, S6, c6, tau, sdd, a0);
+      aba_rows(lane, rt, MA, pA, S6, c6, tau, anch, dpl, sdd, a0);
+      if (anch && P.floating) {  // from the base chain's anchor back to the origin of C: a_lin - alpha x ra_0
+        V ra0[3], t[3];
+        const VI zero_lane = lane * 0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) ra0[k] = ln.shfl(ra[k], zero_lane);
+        ln.fence();
+        cross(a0 + 3, ra0, t);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) a0[k] = a0[k] - t[k];
+      }
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         acl[k] = P.floating ? a0[k] : V(T(0));
@@ -595,7 +697,7 @@ struct Core {
           sp = sp + pA[i] * S6[i];
         }
         u = tau - sp;
-        inv_d = vsel(is_joint, vrcp(d), V(T(0)));  // finite everywhere: base / padding lanes have d = 0
+        inv_d = vsel(is_joint, vrcp_acc(d), V(T(0)));  // finite everywhere: base / padding lanes have d = 0
         if (Lv < first_level) break;
         // Ma = MA - U U^T / d ;  pa = pA + Ma c + U u / d
         V Ma[21], pa[6], Ud[6];
@@ -646,12 +748,17 @@ struct Core {
             const V okf = vsel(is_par && (child[k] >= 0), V(T(1)), V(T(0)));
             // issue all 27 shuffles back to back, wait once, then consume (Ma/pa are finite in
             // every lane, see inv_d above, so masking by multiplication is safe)
-            V gM[21], gp[6];
+            V gM[21], gp[6], gd[3];
   #pragma unroll
             for (int e = 0; e < 21; ++e) gM[e] = ln.shfl(Ma[e], child[k]);
   #pragma unroll
             for (int e = 0; e < 6; ++e) gp[e] = ln.shfl(pa[e], child[k]);
+            if (anch) {
+  #pragma unroll
+              for (int e = 0; e < 3; ++e) gd[e] = ln.shfl(dpl[e], child[k]);
+            }
             ln.fence();
+            if (anch) xlate_inertia(gM, gp, gd);  // the child's chain has its own reference point
   #pragma unroll
             for (int e = 0; e < 21; ++e) MA[e] = MA[e] + okf * gM[e];
   #pragma unroll
@@ -690,6 +797,12 @@ struct Core {
           for (int k = 0; k < 6; ++k) ap[k] = vsel(par_adjacent, ap[k], aq[k]);
         }
         const VM act = level == Lv;
+        if (anch) {  // a(own anchor) = a(parent's anchor) + alpha x dpl   (dpl = 0 along a chain)
+          V t[3];
+          cross(ap + 3, dpl, t);
+  #pragma unroll
+          for (int k = 0; k < 3; ++k) ap[k] = ap[k] + t[k];
+        }
         V ai[6];
   #pragma unroll
         for (int k = 0; k < 6; ++k) ai[k] = ap[k] + c6[k];
@@ -710,6 +823,15 @@ struct Core {
         for (int k = 0; k < 3; ++k) {
           acl[k] = P.floating ? ln.shfl(a6[k], zero_lane) : V(T(0));
           aca[k] = P.floating ? ln.shfl(a6[3 + k], zero_lane) : V(T(0));
+        }
+        if (anch && P.floating) {  // from the base chain's anchor back to the origin of C: a_lin - alpha x ra_0
+          V ra0[3], t[3];
+  #pragma unroll
+          for (int k = 0; k < 3; ++k) ra0[k] = ln.shfl(ra[k], zero_lane);
+          ln.fence();
+          cross(aca, ra0, t);
+  #pragma unroll
+          for (int k = 0; k < 3; ++k) acl[k] = acl[k] - t[k];
         }
         if (P.floating) acl[2] = acl[2] + P.g;
       }
@@ -962,7 +1084,7 @@ struct Core {
 #pragma unroll
       for (int k = 0; k < j; ++k) dj = dj - Lm[j][k] * Lm[j][k] * Dd[k];
       Dd[j] = dj;
-      Di[j] = vrcp(dj);
+      Di[j] = vrcp_acc(dj);
 #pragma unroll
       for (int i = j + 1; i < 6; ++i) {
         V lij = MA[sidx(i, j)];
@@ -1034,7 +1156,7 @@ struct Core {
   }
 
   JXS_HD void aba_rows(const VI& lane, const RowTabs& rt, const V* MA, const V* pA, const V* S6, const V* c6,
-                       const V& tau, V& sdd, V* a0) const {
+                       const V& tau, const bool anch, const V* dpl, V& sdd, V* a0) const {
     const V zero = V(T(0));
     const VI rec_me = lane * kRowRec;
     // ---- link lanes publish their record -------------------------------------------------
@@ -1050,12 +1172,28 @@ struct Core {
     }
     ln.lds_write(rec_me + RL_TAU, tau);
     ln.lds_write(rec_me + RL_SDD, zero);
+    if (anch) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) ln.lds_write(rec_me + (RL_DP + k), dpl[k]);
+    }
     const int XB = G * kRowRec;  // base rows: [XB + 7 r + j], j < 6 inertia row, j = 6 bias force
 
     const VI row = lane & 7;
     const VM rowok = row < 6;
     const VI row6 = vsel(rowok, row, lane * 0);
     const int max_depth = P.max_depth;
+    // anchored chains: where a non-first child joins its parent, the child's slot re-refers its rows by
+    // d = anchor(child chain) - anchor(parent chain) before they are pulled (xlate_inertia in row form):
+    //   every row:   row[3:6] -= row[0:3] x d
+    //   angular row j (lane row 3 + j):  row += d_{j+1} LIN_{j+2} - d_{j+2} LIN_{j+1}   (LIN_k = linear row k)
+    // The two linear rows an angular lane needs sit in the same slot: two shuffle sources per lane.
+    const VM is_ang = (row >= 3) && rowok, is_lin = row < 3;
+    const VI jj = vsel(is_ang, row - 3, row);              // index within the linear / angular triple
+    const VI j1 = vsel(jj == 2, lane * 0, jj + 1);          // (j + 1) % 3
+    const VI j2 = vsel(jj == 0, lane * 0 + 2, jj - 1);      // (j + 2) % 3
+    const VI slot0 = lane - row;                            // first lane of this slot
+    const VI xsrc1 = slot0 + j1, xsrc2 = slot0 + j2;        // linear rows (j+1)%3, (j+2)%3 of this slot
+    auto pick3 = [&](const V* d3, const VI& idx) { return vsel(idx == 0, d3[0], vsel(idx == 1, d3[1], d3[2])); };
 
     // ---- pass 2, leaves to base (rbda/aba.py:184-224) -------------------------------------
     // Wave-uniform flags are pinned in SGPRs up front (the compiler otherwise re-loads them from
@@ -1063,9 +1201,11 @@ struct Core {
     // the LDS reads of level L-1 are issued before level L is computed (software pipelining).
     const unsigned cross_levels = ln.pin(P.row_cross_levels);
     const unsigned ppull_levels = ln.pin(P.row_ppull_levels);
+    const unsigned pull_counts = ln.pin(P.row_pull_counts);
     const int floating = ln.pin(P.floating);
     V Ur[kRowLevels], Sr[kRowLevels], cr[kRowLevels], invd[kRowLevels], uu[kRowLevels];
     V accM[6], accp = zero, MA0[6], p0 = zero;
+    V dkeep[kRowLevels][3];  // anchored chains: d of the links that leave their chain at a level (pass 2 -> pass 3)
 #pragma unroll
     for (int j = 0; j < 6; ++j) accM[j] = zero, MA0[j] = zero;
     RowLevel cur, nxt;
@@ -1103,7 +1243,7 @@ struct Core {
             d = d + cur.S[j] * U[j];
           }
           const V u = cur.tau - red[6];
-          const V inv = vsel(has, vrcp(vsel(has, d, V(T(1)))), zero);
+          const V inv = vsel(has, vrcp_acc(vsel(has, d, V(T(1)))), zero);
           const V Ud = U_r * inv;
           V Ma[6], pa = pr + Ud * u;
 #pragma unroll
@@ -1115,13 +1255,36 @@ struct Core {
           // propagate: first children stay in their lanes, extra children are pulled by the
           // parent's lanes.  A fixed base receives nothing (rbda/aba.py:217-222).
           if (Lv >= 2 || floating) {
+            if (anch && ((cross_levels >> Lv) & 1u)) {
+              // re-refer the rows of the links that leave their chain here (d = 0 for first children)
+              const VI dbase = vsel(has, rt.rec[Lv], lane * 0) + RL_DP;
+              V d3[3];
+#pragma unroll
+              for (int k = 0; k < 3; ++k) d3[k] = vsel(has, ln.lds_read(dbase + k), zero), dkeep[Lv][k] = d3[k];
+              {  // row[3:6] -= row[0:3] x d
+                const V t0 = Ma[1] * d3[2] - Ma[2] * d3[1], t1 = Ma[2] * d3[0] - Ma[0] * d3[2], t2 = Ma[0] * d3[1] - Ma[1] * d3[0];
+                Ma[3] = Ma[3] - t0, Ma[4] = Ma[4] - t1, Ma[5] = Ma[5] - t2;
+              }
+              const V c1 = vsel(is_ang, pick3(d3, j1), zero);    //  d_{j+1}: multiplies LIN_{j+2}
+              const V c2 = vsel(is_ang, -pick3(d3, j2), zero);   // -d_{j+2}: multiplies LIN_{j+1}
+              V g1[7], g2[7];
+#pragma unroll
+              for (int j = 0; j < 6; ++j) g1[j] = ln.shfl(Ma[j], xsrc1), g2[j] = ln.shfl(Ma[j], xsrc2);
+              g1[6] = ln.shfl(pa, xsrc1), g2[6] = ln.shfl(pa, xsrc2);
+              ln.fence();
+#pragma unroll
+              for (int j = 0; j < 6; ++j) Ma[j] = Ma[j] + c1 * g2[j] + c2 * g1[j];
+              pa = pa + c1 * g2[6] + c2 * g1[6];
+            }
             const VM fc = ((rt.fcbits >> Lv) & 1) != 0;
 #pragma unroll
             for (int j = 0; j < 6; ++j) accM[j] = vsel(fc, Ma[j], zero);
             accp = vsel(fc, pa, zero);
             if ((cross_levels >> Lv) & 1u) {
+              const int npull = (int)((pull_counts >> (4 * Lv)) & 15u);  // wave-uniform
 #pragma unroll
               for (int k = 0; k < kRowExtra; ++k) {
+                if (k >= npull) break;
                 const VI src = rt.pull[Lv][k];
                 const VM ok = src >= 0;
                 V g[7];
@@ -1172,9 +1335,21 @@ struct Core {
         const VM has = rt.rec[Lv] >= 0;
         V apar = acar;
         if ((ppull_levels >> Lv) & 1u) {
+          const VM pulled = rt.ppull[Lv] >= 0;
           const V q = ln.shfl(acar, rt.ppull[Lv]);
-          ln.fence();
-          apar = vsel(rt.ppull[Lv] >= 0, q, acar);
+          if (anch) {
+            // the parent sits in another chain: its acceleration moves to this chain's anchor,
+            // a_lin += alpha x d, i.e. linear row k += alpha_{k+1} d_{k+2} - alpha_{k+2} d_{k+1}
+            const VI pslot = vsel(pulled, rt.ppull[Lv] - row, lane * 0);
+            const V al1 = ln.shfl(acar, pslot + 3 + j1), al2 = ln.shfl(acar, pslot + 3 + j2);
+            ln.fence();
+            const V* d3 = dkeep[Lv];  // cross levels and parent-pull levels are the same levels
+            const V sh = al1 * pick3(d3, j2) - al2 * pick3(d3, j1);
+            apar = vsel(pulled, q + vsel(is_lin, sh, zero), acar);
+          } else {
+            ln.fence();
+            apar = vsel(pulled, q, acar);
+          }
         }
         V ai = apar + cr[Lv];
         const V tot = ln.allreduce8(Ur[Lv] * ai);
@@ -1262,7 +1437,7 @@ struct Core {
   // the tangential deformation (rbda/collidable_points.py:9-65, rbda/contacts/common.py:25-63,
   // rbda/contacts/soft.py:195-388).
   JXS_HD void point_physics(const VM& valid, const V* Lp, const V* m, const V* Rb, const V* rb, const V* vbl,
-                            const V* vba, const V* pB, const V* doff, const V* vBc, const V* om, V* w6, V* md) const {
+                            const V* vba, const V* rab, const V* pB, const V* doff, const V* vBc, const V* om, V* w6, V* md) const {
     const V zero = V(T(0));
     V rc0[3], rc[3], pw[3], pd[3], t[3];
     mat3vec(Rb, Lp, rc0);
@@ -1347,11 +1522,13 @@ struct Core {
       const V md_sl = -(ft[k] + Kdp * mt[k]) * inv_Ddq;
       md[k] = vsel(no_contact, md_nc, vsel(sticking, md_st, md_sl));
     }
-    // wrench in C: [f; r_C x f]  (W_f = [f; p x f], soft.py:377-388, moved to the C origin)
+    // wrench [f; (r_C - rab) x f]  (W_f = [f; p x f], soft.py:377-388, moved to the reference point)
     w6[0] = vsel(valid, fn * nh[0] + ft[0], zero);
     w6[1] = vsel(valid, fn * nh[1] + ft[1], zero);
     w6[2] = vsel(valid, fn * nh[2] + ft[2], zero);
-    cross(rc, w6, w6 + 3);
+    // moment about the anchor of the parent link's chain (rab = 0: about the origin of C)
+    V lever[3] = {rc[0] - rab[0], rc[1] - rab[1], rc[2] - rab[2]};
+    cross(lever, w6, w6 + 3);
   }
 
   // One chunk of G collidable points.  Chunk 0 is carried in registers (state loaded up front, integrated
@@ -1360,14 +1537,14 @@ struct Core {
   // pointer phi that keeps the slot structs in scratch memory.
   template <bool kFirst>
   JXS_HD void contact_chunk(const VI& lane, PointSlot& ps, const V* R, const V* r, const V* vl, const V* va,
-                            const V* pB, const V* doff, const V* vBc, const V* om, V* fl, V* fa) const {
+                            const V* ra, const V* pB, const V* doff, const V* vBc, const V* om, V* fl, V* fa) const {
     const V zero = V(T(0));
     const VM valid = ps.body >= 0;
     V m[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) m[k] = vsel(valid, ps.m[k], zero);
     // kinematics of the parent link
-    V Rb[9], rb[3], vbl[3], vba[3];
+    V Rb[9], rb[3], vbl[3], vba[3], rab[3];
 #pragma unroll
     for (int e = 0; e < 9; ++e) Rb[e] = ln.shfl(R[e], ps.body);
 #pragma unroll
@@ -1375,10 +1552,11 @@ struct Core {
       rb[e] = ln.shfl(r[e], ps.body);
       vbl[e] = ln.shfl(vl[e], ps.body);
       vba[e] = ln.shfl(va[e], ps.body);
+      rab[e] = ln.shfl(ra[e], ps.body);
     }
     ln.fence();
     V w6[6], md[3];
-    point_physics(valid, ps.Lp, m, Rb, rb, vbl, vba, pB, doff, vBc, om, w6, md);
+    point_physics(valid, ps.Lp, m, Rb, rb, vbl, vba, rab, pB, doff, vBc, om, w6, md);
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       if (kFirst) ps.md[k] = md[k];
@@ -1388,13 +1566,13 @@ struct Core {
   }
 
   JXS_HD void contacts(const VI& lane, PointSlot& ps0, const V* R, const V* r, const V* vl, const V* va,
-                       const V* pB, const V* doff, const V* vBc, const V* om, V* fl, V* fa) const {
-    contact_chunk<true>(lane, ps0, R, r, vl, va, pB, doff, vBc, om, fl, fa);  // sets ps0.md
+                       const V* ra, const V* pB, const V* doff, const V* vBc, const V* om, V* fl, V* fa) const {
+    contact_chunk<true>(lane, ps0, R, r, vl, va, ra, pB, doff, vBc, om, fl, fa);  // sets ps0.md
     for (int ch = 1; ch < P.n_chunks; ++ch) {
       PointSlot ps;
       load_slot_tables(lane, ch, ps);
       load_slot_state(ps);
-      contact_chunk<false>(lane, ps, R, r, vl, va, pB, doff, vBc, om, fl, fa);
+      contact_chunk<false>(lane, ps, R, r, vl, va, ra, pB, doff, vBc, om, fl, fa);
     }
   }
 

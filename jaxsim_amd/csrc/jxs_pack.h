@@ -261,6 +261,14 @@ std::string pack_model(const jxs_model_desc& d, Packed<T>& out) {
     I(LI_LINK, lane) = i;
     I(LI_LEVEL, lane) = level[i];
     I(LI_SUBTREE, lane) = subtree[i];
+    {
+      int leaf = i;  // leaf of the first-child chain through link i
+      while (!children[leaf].empty()) leaf = children[leaf][0];
+      I(LI_ANCHOR, lane) = lane_of[leaf];
+      int pleaf = i == 0 ? 0 : d.parent[i];
+      while (!children[pleaf].empty()) pleaf = children[pleaf][0];
+      I(LI_PANCHOR, lane) = lane_of[pleaf];
+    }
     F(LF_MASS, lane) = (T)d.link_mass[i];
     for (int k = 0; k < 3; ++k) F(LF_COM + k, lane) = (T)d.link_com[3 * i + k];
     const double* Ii = d.link_inertia + 9 * i;
@@ -306,6 +314,8 @@ std::string pack_model(const jxs_model_desc& d, Packed<T>& out) {
     F(LF_DLIM, lane) = (T)d.position_limit_damper[i];
   }
   P.any_suc = any_suc;
+  // anchored ABA (jxs_core.h): on for the soft-contact / forward-dynamics kernels of every model with joints
+  P.anchored = (std::getenv("JXS_DISABLE_ANCHORS") == nullptr && nL > 1) ? 1 : 0;  // developer knob: A/B
 
   // point slots
   // at least one (empty) slot per lane: the kernels load the chunk-0 slot of every lane unconditionally
@@ -343,6 +353,7 @@ std::string pack_model(const jxs_model_desc& d, Packed<T>& out) {
   P.row_mode = 0;
   P.row_cross_levels = 0;
   P.row_ppull_levels = 0;
+  P.row_pull_counts = 0;
   out.rti.assign((size_t)kRtiStride * G, -1);
   {
     const int n_slots_row = G / 8;
@@ -394,6 +405,8 @@ std::string pack_model(const jxs_model_desc& d, Packed<T>& out) {
               while (children[pi][k + 1] != i) ++k;
               RI(RT_PULL + L * kRowExtra + k, 8 * slot[pi] + r) = lane;
               P.row_cross_levels |= 1u << L;
+              const unsigned cur = (P.row_pull_counts >> (4 * L)) & 15u;
+              if ((unsigned)(k + 1) > cur) P.row_pull_counts = (P.row_pull_counts & ~(15u << (4 * L))) | ((unsigned)(k + 1) << (4 * L));
             }
           }
         }

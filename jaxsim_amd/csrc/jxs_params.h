@@ -60,7 +60,10 @@ enum LaneI : int {
   LI_JROW = LI_LINK + 1,              // joint row (link index - 1), -1 for the base / padding lanes
   LI_SUBTREE = LI_JROW + 1,           // links in the subtree of this lane's link (itself included): in the
                                       // depth-first lane order the subtree of lane j is lanes [j, j + size)
-  LI_COUNT = LI_SUBTREE + 1
+  LI_ANCHOR = LI_SUBTREE + 1,         // lane of the LEAF of this link's first-child chain: the reference point of its
+                                      // articulated-body quantities (jxs_core.h, "Anchored ABA")
+  LI_PANCHOR = LI_ANCHOR + 1,         // LI_ANCHOR of the parent link (own anchor for the base / first children)
+  LI_COUNT = LI_PANCHOR + 1
 };
 constexpr int kLtiStride = (LI_COUNT + 3) / 4 * 4;
 
@@ -86,7 +89,7 @@ JXS_HD constexpr int chunk_bytes(int G) { return G * kPtStride * 4 + G * kPtStri
 // serial chain never leaves its lanes.
 constexpr int kRowLevels = 8;     // tree levels 0..7 (deeper trees use the link-per-lane sweeps)
 constexpr int kRowExtra = 3;      // extra (non-first) children per link handled by cross-slot pulls
-constexpr int kRowRec = 57;       // LDS words per link record (odd stride: conflict-free b32 access)
+constexpr int kRowRec = 61;       // LDS words per link record (odd stride: conflict-free b32 access)
 enum RowI : int {
   RT_REC = 0,                         // [kRowLevels] LDS word offset of the record of link(L, slot), -1 if none
   RT_FC = RT_REC + kRowLevels,        // bit L: link(L, slot) is the first child of link(L-1, slot)
@@ -95,11 +98,16 @@ enum RowI : int {
   RT_COUNT = RT_PPULL + kRowLevels
 };
 constexpr int kRtiStride = (RT_COUNT + 3) / 4 * 4;  // rti[lane * kRtiStride + field]
-// LDS record layout (words): 0..35 M (6x6), 36..41 S, 42..47 c, 48..53 pA, 54 tau
+// LDS record layout (words): 0..35 M (6x6), 36..41 S, 42..47 c, 48..53 pA, 54 tau, 55 sdd (result),
+// 56..58 anchor of this link's chain minus the anchor of its parent's chain (zero for first children)
 // exchange area after the G records: base rows 42 words, a0 6 words, sdd G words
-enum RowLds : int { RL_M = 0, RL_S = 36, RL_C = 42, RL_PA = 48, RL_TAU = 54, RL_SDD = 55 };
-JXS_HD constexpr int lds_kin_offset(int G) { return G * kRowRec + 48; }  // link kinematics for the contact phase: [G][18]
-JXS_HD constexpr int lds_words_per_env(int G) { return lds_kin_offset(G) + 18 * G; }  // records + base rows (42) + pad + kinematics
+enum RowLds : int { RL_M = 0, RL_S = 36, RL_C = 42, RL_PA = 48, RL_TAU = 54, RL_SDD = 55, RL_DP = 56 };
+// The link kinematics staged for the contact phase ([G][kKinRec] words) ALIAS the record area: the contact phase
+// has read them back before the ABA publishes its records (a single-wave workgroup executes its LDS
+// operations in program order).  20.6 KB -> 16 KB per humanoid wave: ten waves per CU instead of seven.
+constexpr int kKinRec = 21;  // R (9), r (3), v_lin (3), v_ang (3), anchor of the link's chain (3)
+JXS_HD constexpr int lds_kin_offset(int) { return 0; }
+JXS_HD constexpr int lds_words_per_env(int G) { return (G * kRowRec + 48 + 3) / 4 * 4; }  // records + base rows (42) + pad
 // rigid modes: Q and H packed lower triangles of order 3 n_cp + one exchange vector (jxs_rigid.inc)
 // RelaxedRigidContacts (rigid == 2) factorises in place of the Delassus matrix: one triangle
 JXS_HD constexpr int rigid_lds_words_per_env(int n_cp, int rigid = 1) {
@@ -139,6 +147,7 @@ struct KParams {
   int row_mode;                      // 1: ABA passes run row-distributed (tables in KArgs::rti)
   unsigned int row_cross_levels;     // bit L: some parent pulls an extra child of level L across slots
   unsigned int row_ppull_levels;     // bit L: some link of level L has its parent in another slot
+  unsigned int row_pull_counts;      // 4 bits per level L: max number of extra children (level L) any parent pulls
   JXS_HD int maxch(int L) const {
     // Constant indices and mask arithmetic only: a `L < 16 ? maxch_nib[0] : ...` chain is turned into a load
     // with a runtime index by the compiler, which puts this whole by-value struct into scratch memory and
@@ -180,6 +189,7 @@ struct KParams {
   T rr_tiny;                     // smallest positive normal number (guards pow of a non-positive base)
   int rr_refine;                 // refinement steps against the operator applied through the tree
   int rk4fast;                   // RungeKutta4Fast: contact forces and position derivatives of the initial state (api/integrators.py:170-276)
+  int anchored;                  // 1: the ABA of step / forward dynamics refers every first-child chain to its leaf link (fp32 conditioning)
 };
 
 // Device/host pointers handed to the core for one launch.

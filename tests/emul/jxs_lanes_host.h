@@ -63,6 +63,7 @@ struct Vec {
     for (int i = 0; i < G; ++i) r.v[i] = T(1) / a.v[i];
     return r;
   }
+  friend Vec vrcp_acc(const Vec& a) { return vrcp(a); }
   friend Vec vabs(const Vec& a) {
     Vec r;
     for (int i = 0; i < G; ++i) r.v[i] = std::fabs(a.v[i]);

@@ -15,16 +15,23 @@ from jaxsim_amd import state as st
 # (max |a - ref| / max(1, |ref|), element-wise, worst element of the whole batch).  The truth is
 # ALWAYS the fp64 oracle evaluated on the same (already rounded) inputs:
 #   fp64 kernels: 1e-10 (measured 1e-13);
-#   fp32 kernels: 3e-3 worst case for one step / one evaluation, with the distribution checked
-#   separately at full size (median < 5e-5, 99th percentile < 5e-4 of the per-environment error,
-#   test_full_size_step_*).  The test states use the reference's default K = 1e6 with random
-#   penetrations of centimetres, i.e. contact accelerations of 1e4..1e5 m/s^2: on 512 such
-#   humanoid states the reference formulation itself, run in fp32, is 1.3e-3 away from its fp64
-#   result in the worst environment (median 1e-7); the frame-C kernel 6e-4 in IEEE emulation
-#   (median 8e-6), up to 2e-3 on the GPU.  The reference calls its own 32-bit mode "still
-#   experimental" (src/jaxsim/__init__.py:37-41); fp64 kernels are provided for exactness.
+#   fp32 kernels, one step / one evaluation: 1e-3 WORST element of the worst environment, with the
+#   distribution checked at full size (test_full_size_step_*: median < 3e-6, 99th percentile < 3e-4 of the
+#   per-environment error).  Measured on MI355X with the anchored ABA (tools/fp32_error_gpu.py, 512 humanoid
+#   states with the reference's default K = 1e6 and centimetres of penetration, i.e. contact accelerations
+#   of 1e4..1e5 m/s^2): median 1.4e-6, p99 1.4e-4, worst 1.4e-4 .. 5.7e-4 depending on the seed; the
+#   reference formulation itself, run in fp32 (the oracle with float32 arrays), has median 2.8e-7, p99 7e-5,
+#   worst 6e-5 .. 7e-4 on the same states -- the worst case is the conditioning of the stiff-contact states,
+#   not of either formulation.  Round 1 (one reference point for the whole tree): median 2.1e-5, worst 1.2e-3,
+#   tolerance 3e-3.
+#   `chain9f` (a random 9-link floating chain with collidable points on light links): the reference
+#   formulation in fp32 is itself 3e-3 .. 7e-3 away from its fp64 result in the worst environment (median
+#   9e-6) -- a noise-limited model kept as a stress case: 2e-2.
+# The reference calls its own 32-bit mode "still experimental" (src/jaxsim/__init__.py:37-41); the fp64
+# kernels are exact to rounding.
 FP64_TOL = 1e-10
-FP32_TOL = 3e-3
+FP32_TOL = 1e-3
+FP32_TOL_BY_MODEL = {"chain9f": 2e-2}
 
 
 class ModelZoo:
@@ -116,8 +123,10 @@ def rel_err(a: np.ndarray, ref: np.ndarray) -> float:
     return float(np.max(np.abs(a - ref) / np.maximum(1.0, np.abs(ref)))) if a.size else 0.0
 
 
-def tol_of(dtype) -> float:
-    return FP64_TOL if np.dtype(dtype) == np.float64 else FP32_TOL
+def tol_of(dtype, name: str | None = None) -> float:
+    if np.dtype(dtype) == np.float64:
+        return FP64_TOL
+    return FP32_TOL_BY_MODEL.get(name, FP32_TOL)
 
 
 def random_inputs(model, N, seed, dtype):

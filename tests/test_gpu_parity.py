@@ -1,6 +1,6 @@
 """GPU parity tests (``-m gpu``): the gfx950 kernels, called through the C-ABI via the Python
 mirror of the reference API, against the oracle on the same seeded inputs.  Tolerances are
-stated in ``helpers.py`` (fp64 1e-10, fp32 3e-3 worst case, relative to the fp64 oracle)."""
+stated in ``helpers.py`` (fp64 1e-10, fp32 1e-3 worst case -- the rigid-contact models keep 3e-3 --, relative to the fp64 oracle)."""
 
 import dataclasses
 
@@ -48,7 +48,7 @@ def test_step_matches_oracle(models, name, dtype):
     ref = oracle.step(model, helpers.upcast(d), link_forces=f.astype(np.float64), joint_force_references=tau.astype(np.float64))
     out = js.model.step(model, to_gpu(model, d), link_forces=f, joint_force_references=tau)
     assert out.dtype == dtype
-    assert helpers.rel_err(out.state_block(), helpers.odata_to_block(model, ref)) < helpers.tol_of(dtype)
+    assert helpers.rel_err(out.state_block(), helpers.odata_to_block(model, ref)) < helpers.tol_of(dtype, name)
 
 
 @pytest.mark.parametrize("rep", [VelRepr.Inertial, VelRepr.Body, VelRepr.Mixed])
@@ -111,7 +111,7 @@ def test_forward_dynamics_matches_oracle(models, name, dtype, rep):
     tau, f = helpers.random_inputs(model, N, 7, dtype)
     vd, sdd = oracle.forward_dynamics_aba(model, helpers.upcast(d), joint_forces=tau.astype(np.float64), link_forces=f.astype(np.float64))
     gvd, gsdd = js.model.forward_dynamics_aba(model, to_gpu(model, d), joint_forces=tau, link_forces=f)
-    tol = helpers.tol_of(dtype)
+    tol = helpers.tol_of(dtype, name)
     assert helpers.rel_err(gsdd, sdd) < tol and helpers.rel_err(gvd, vd) < tol
 
 
@@ -131,7 +131,7 @@ def test_inverse_dynamics_matches_oracle(models, name, dtype, rep):
     ref = np.concatenate([fB if model.floating_base() else np.zeros_like(fB), tau], -1)
     got = np.concatenate([gfB if model.floating_base() else np.zeros_like(gfB), gtau], -1)
     scale = max(1.0, float(np.abs(ref).max()))
-    assert float(np.abs(got - ref).max()) / scale < helpers.tol_of(dtype)
+    assert float(np.abs(got - ref).max()) / scale < helpers.tol_of(dtype, name)
 
 
 def test_bias_and_gravity_forces(models):
@@ -149,8 +149,8 @@ def test_cached_kinematics_match_oracle(models, name, dtype):
     d = models.random_data(name, 10, seed=31, dtype=dtype)
     g = to_gpu(model, d)
     t = helpers.upcast(d).update_caches(model)
-    assert helpers.rel_err(g._link_transforms, t.link_transforms) < helpers.tol_of(dtype)
-    assert helpers.rel_err(g._link_velocities, t.link_velocities) < helpers.tol_of(dtype)
+    assert helpers.rel_err(g._link_transforms, t.link_transforms) < helpers.tol_of(dtype, name)
+    assert helpers.rel_err(g._link_velocities, t.link_velocities) < helpers.tol_of(dtype, name)
 
 
 def test_data_build_and_properties(models):
@@ -190,7 +190,7 @@ def test_full_size_round_trip_fd_id(models):
     scale = float(np.abs(tau).max())
     # ID(FD(tau)) = tau: worst environment within the stated fp32 tolerance, typical far below
     err = np.abs(tau_id - tau).max(axis=1) / scale
-    assert err.max() < 2 * helpers.FP32_TOL and np.median(err) < 1e-4
+    assert err.max() < 2 * helpers.FP32_TOL and np.median(err) < 1e-5
     assert float(np.abs(fB).max()) / max(scale, float(np.abs(f).max())) < 1e-2
 
 
@@ -214,7 +214,8 @@ def test_full_size_step_matches_oracle_and_keeps_unit_quaternion(models):
     truth = helpers.odata_to_block(model, ref)
     assert helpers.rel_err(out.state_block(), truth) < helpers.FP32_TOL
     per_env = (np.abs(out.state_block() - truth) / np.maximum(1.0, np.abs(truth))).max(axis=0)
-    assert np.median(per_env) < 5e-5 and np.percentile(per_env, 99) < 5e-4
+    # distribution with the anchored ABA (measured on MI355X: median 1.4e-6, p99 1.4e-4)
+    assert np.median(per_env) < 3e-6 and np.percentile(per_env, 99) < 3e-4
     # 50 more steps with the estimator's contact parameters (the reference's own recipe; with the
     # default K = 1e6 some of these random deep-penetration states diverge in the oracle as well)
     soft = helpers.with_params(model, contact_params=js.contact.estimate_good_contact_parameters(
@@ -267,10 +268,10 @@ def test_gpu_golden(models, name, dtype):
     model = models(name)
     data = js.data.JaxSimModelData.from_state_block(model, g["state"].astype(dtype), ja.VelRepr.Inertial)
     out = js.model.step(model, data, link_forces=g["link_forces"], joint_force_references=g["tau"])
-    assert helpers.rel_err(out.state_block(), g["step"]) < helpers.tol_of(dtype)
+    assert helpers.rel_err(out.state_block(), g["step"]) < helpers.tol_of(dtype, name)
     vd, sdd = js.model.forward_dynamics_aba(model, data, joint_forces=g["tau"], link_forces=g["link_forces"])
-    assert helpers.rel_err(np.concatenate([vd, sdd], -1), g["fd"]) < helpers.tol_of(dtype)
-    assert helpers.rel_err(data._link_transforms, g["link_transforms"]) < helpers.tol_of(dtype)
+    assert helpers.rel_err(np.concatenate([vd, sdd], -1), g["fd"]) < helpers.tol_of(dtype, name)
+    assert helpers.rel_err(data._link_transforms, g["link_transforms"]) < helpers.tol_of(dtype, name)
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
@@ -317,7 +318,7 @@ def test_rk4_step_matches_oracle_gpu(models, name, dtype):
     tau, f = helpers.random_inputs(model, N, 32, dtype)
     ref = oracle.step(model, helpers.upcast(d), link_forces=f.astype(np.float64), joint_force_references=tau.astype(np.float64))
     out = js.model.step(model, to_gpu(model, d), link_forces=f, joint_force_references=tau)
-    assert helpers.rel_err(out.state_block(), helpers.odata_to_block(model, ref)) < helpers.tol_of(dtype)
+    assert helpers.rel_err(out.state_block(), helpers.odata_to_block(model, ref)) < helpers.tol_of(dtype, name)
 
 
 @pytest.mark.parametrize("rep", [VelRepr.Inertial, VelRepr.Body, VelRepr.Mixed])
@@ -996,11 +997,11 @@ def test_actuation_limits_and_torque_speed_curve_gpu(models, name, dtype):
     tau = rng.uniform(-20, 20, size=(N, model.dofs())).astype(dtype)  # beyond torque_max: the clip is active
     ref = oracle.step(model, helpers.upcast(d), joint_force_references=tau.astype(np.float64))
     out = js.model.step(model, to_gpu(model, d), joint_force_references=tau)
-    assert helpers.rel_err(out.state_block(), helpers.odata_to_block(model, ref)) < helpers.tol_of(dtype)
+    assert helpers.rel_err(out.state_block(), helpers.odata_to_block(model, ref)) < helpers.tol_of(dtype, name)
     # the limit terms and the clip matter at this tolerance: without them the result is far away
     plain = helpers.with_params(models(name), actuation_params=ja.ActuationParams())
     off = oracle.step(plain, helpers.upcast(d), joint_force_references=tau.astype(np.float64))
-    assert helpers.rel_err(helpers.odata_to_block(model, off), helpers.odata_to_block(model, ref)) > 10 * helpers.tol_of(dtype) + 0.02
+    assert helpers.rel_err(helpers.odata_to_block(model, off), helpers.odata_to_block(model, ref)) > 10 * helpers.tol_of(dtype, name) + 0.02
 
 
 def test_actuation_known_answers_gpu(models):
@@ -1041,9 +1042,10 @@ def test_bench_model_step_matches_oracle_full_size_gpu():
     ref = oracle.step(model, helpers.block_to_odata(model, blk0.astype(np.float64)))
     refb = helpers.odata_to_block(model, ref)
     assert (np.abs(blk0[7 : 7 + model.dofs()]) > 1.0).sum() > 100
-    assert helpers.rel_err(out, refb) < helpers.FP32_TOL
+    # the benchmark's own model (estimated contact parameters): benign conditioning, tighter bounds
+    assert helpers.rel_err(out, refb) < 3e-4
     per_env = np.max(np.abs(out - refb) / np.maximum(1.0, np.abs(refb)), axis=0)
-    assert np.median(per_env) < 5e-5
+    assert np.median(per_env) < 1e-6
 
 
 # ---- RigidContacts: the device against the reference's UN-reduced QP statement ------------------------

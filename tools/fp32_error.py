@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """fp32 error budget of one step: per-environment error against the fp64 oracle of
-(a) the kernel core in IEEE emulation, (b) the same with the frame-C origin at the base position (round-1
-formulation, JXS_DISABLE_ANCHORS=1), (c) the reference formulation evaluated in fp32 (the oracle run with
-float32 arrays).  CPU only (test infrastructure: oracle + emulation).   python tools/fp32_error.py [N] [model]"""
+(a) the kernel core in IEEE emulation with the anchored ABA, (b) the same with one reference point for the
+whole tree (round-1 formulation, JXS_DISABLE_ANCHORS=1), both ABA layouts, (c) the reference formulation
+evaluated in fp32 (the oracle run with float32 arrays).  CPU only (test infrastructure: oracle + emulation).   python tools/fp32_error.py [N] [model]"""
 import os
 import sys
 
@@ -35,15 +35,20 @@ def report(tag, e):
     print(f"{tag:42s} median {np.median(e):.2e}  p90 {np.percentile(e, 90):.2e}  p99 {np.percentile(e, 99):.2e}  worst {e.max():.2e}")
 
 
-os.environ.pop("JXS_DISABLE_ANCHORS", None)
-report("kernel core, origin at the anchors", per_env(eb.run(model, eb.MODE_STEP, blk)))
-os.environ["JXS_DISABLE_ANCHORS"] = "1"
-report("kernel core, origin at the base (round 1)", per_env(eb.run(model, eb.MODE_STEP, blk)))
-os.environ.pop("JXS_DISABLE_ANCHORS", None)
+for rows in ("", "1"):
+    tag = "link-per-lane sweeps" if rows else "row-distributed passes"
+    if rows:
+        os.environ["JXS_DISABLE_ROW_MODE"] = "1"
+    os.environ.pop("JXS_DISABLE_ANCHORS", None)
+    report(f"kernel core, {tag}, anchored chains", per_env(eb.run(model, eb.MODE_STEP, blk)))
+    os.environ["JXS_DISABLE_ANCHORS"] = "1"
+    report(f"kernel core, {tag}, one origin (round 1)", per_env(eb.run(model, eb.MODE_STEP, blk)))
+    os.environ.pop("JXS_DISABLE_ANCHORS", None)
+    os.environ.pop("JXS_DISABLE_ROW_MODE", None)
 report("reference formulation in fp32 (oracle)", per_env(helpers.odata_to_block(model, oracle.step(model, d))))
 
 if os.environ.get("JXS_ERR_ROWS"):
-    for tag, env in (("anchors", None), ("base", "1")):
+    for tag, env in (("anchored", None), ("one origin", "1")):
         if env:
             os.environ["JXS_DISABLE_ANCHORS"] = env
         out = eb.run(model, eb.MODE_STEP, blk)
