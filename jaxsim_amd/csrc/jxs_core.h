@@ -1142,16 +1142,20 @@ struct Core {
     V Mrow[6], S[6], c[6], pr, S_r, c_r, tau;
   };
   JXS_HD void load_row_level(const VI& rec, const VI& row6, const VI& lane, RowLevel& o) const {
-    const VI base = vsel(rec >= 0, rec, lane * 0);
+    // no link in this slot at this level: the all-zero record; the two idle lanes of a slot read their
+    // row-specific values from it as well (the slot-uniform S, c, tau come from the link's record)
+    const VI zr = lane * 0 + lds_zero_rec(G);
+    const VI base = vsel(rec >= 0, rec, zr);
+    const VI brow = vsel((lane & 7) < 6, base, zr);
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
-      o.Mrow[j] = ln.lds_read(base + row6 * 6 + (RL_M + j));
+      o.Mrow[j] = ln.lds_read(brow + row6 * 6 + (RL_M + j));
       o.S[j] = ln.lds_read(base + (RL_S + j));
       o.c[j] = ln.lds_read(base + (RL_C + j));
     }
-    o.pr = ln.lds_read(base + row6 + RL_PA);
-    o.S_r = ln.lds_read(base + row6 + RL_S);
-    o.c_r = ln.lds_read(base + row6 + RL_C);
+    o.pr = ln.lds_read(brow + row6 + RL_PA);
+    o.S_r = ln.lds_read(brow + row6 + RL_S);
+    o.c_r = ln.lds_read(brow + row6 + RL_C);
     o.tau = ln.lds_read(base + RL_TAU);
   }
 
@@ -1172,6 +1176,8 @@ struct Core {
     }
     ln.lds_write(rec_me + RL_TAU, tau);
     ln.lds_write(rec_me + RL_SDD, zero);
+#pragma unroll
+    for (int k = 0; k < (kRowRec + G - 1) / G; ++k) ln.lds_write(lane + (lds_zero_rec(G) + k * G), zero, lane + k * G < kRowRec);
     if (anch) {
 #pragma unroll
       for (int k = 0; k < 3; ++k) ln.lds_write(rec_me + (RL_DP + k), dpl[k]);
@@ -1216,13 +1222,12 @@ struct Core {
       if (Lv >= 1) load_row_level(rt.rec[Lv - 1], row6, lane, nxt);  // prefetch the next level
       if (Lv <= max_depth && (Lv >= 1 || floating)) {
         const VM has = rt.rec[Lv] >= 0;
-        const VM live = has && rowok;
-        V MArow[6];
+        V MArow[6];  // (lanes without a link, and the idle lanes 6, 7 of a slot, read the all-zero record)
 #pragma unroll
-        for (int j = 0; j < 6; ++j) MArow[j] = vsel(live, cur.Mrow[j], zero) + accM[j];
-        const V pr = vsel(live, cur.pr, zero) + accp;
-        const V S_r = vsel(live, cur.S_r, zero);
-        const V c_r = vsel(live, cur.c_r, zero);
+        for (int j = 0; j < 6; ++j) MArow[j] = cur.Mrow[j] + accM[j];
+        const V pr = cur.pr + accp;
+        const V S_r = cur.S_r;
+        const V c_r = cur.c_r;
         if (Lv == 0) {
 #pragma unroll
           for (int j = 0; j < 6; ++j) MA0[j] = MArow[j];

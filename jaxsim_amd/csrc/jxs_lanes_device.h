@@ -198,9 +198,27 @@ struct DeviceLanes {
     x = x + dpp<0x141>(x);  // row_half_mirror
     return x;
   }
-  // seven independent 8-lane reductions advanced stage by stage: consecutive DPP instructions
-  // never read a register written by their predecessor (no s_nop between them)
-  __device__ __forceinline__ void allreduce8x7(V* x) const {
+  // seven independent 8-lane reductions advanced stage by stage: consecutive DPP instructions never read a
+  // register written by their predecessor.  fp32: v_add_f32_dpp written out (the compiler otherwise turns the
+  // first stage into v_mov_dpp + v_fmac, recomputing the product that feeds it: three instructions per value
+  // instead of two); the leading s_nop covers the VALU-write -> DPP-read hazard the assembler cannot see.
+  __device__ __forceinline__ void allreduce8x7(float* x) const {
+#define JXS_DPP7(CTRL)                                                                                       \
+  asm volatile("s_nop 1\n\t"                                                                                 \
+               "v_add_f32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                \
+               "v_add_f32_dpp %1, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                \
+               "v_add_f32_dpp %2, %2, %2 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                \
+               "v_add_f32_dpp %3, %3, %3 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                \
+               "v_add_f32_dpp %4, %4, %4 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                \
+               "v_add_f32_dpp %5, %5, %5 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                \
+               "v_add_f32_dpp %6, %6, %6 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1"                     \
+               : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]))
+    JXS_DPP7("quad_perm:[1,0,3,2]");
+    JXS_DPP7("quad_perm:[2,3,0,1]");
+    JXS_DPP7("row_half_mirror");
+#undef JXS_DPP7
+  }
+  __device__ __forceinline__ void allreduce8x7(double* x) const {
 #pragma unroll
     for (int k = 0; k < 7; ++k) x[k] = x[k] + dpp<0xB1>(x[k]);
     __builtin_amdgcn_sched_barrier(0);

@@ -107,7 +107,10 @@ enum RowLds : int { RL_M = 0, RL_S = 36, RL_C = 42, RL_PA = 48, RL_TAU = 54, RL_
 // operations in program order).  20.6 KB -> 16 KB per humanoid wave: ten waves per CU instead of seven.
 constexpr int kKinRec = 21;  // R (9), r (3), v_lin (3), v_ang (3), anchor of the link's chain (3)
 JXS_HD constexpr int lds_kin_offset(int) { return 0; }
-JXS_HD constexpr int lds_words_per_env(int G) { return (G * kRowRec + 48 + 3) / 4 * 4; }  // records + base rows (42) + pad
+// records + base rows (42 words) + pad (6) + one all-zero record: row lanes without a link at a level read
+// zeros from it instead of selecting them (nine v_cndmask per level saved)
+JXS_HD constexpr int lds_zero_rec(int G) { return G * kRowRec + 48; }
+JXS_HD constexpr int lds_words_per_env(int G) { return (lds_zero_rec(G) + kRowRec + 3) / 4 * 4; }
 // rigid modes: Q and H packed lower triangles of order 3 n_cp + one exchange vector (jxs_rigid.inc)
 // RelaxedRigidContacts (rigid == 2) factorises in place of the Delassus matrix: one triangle
 JXS_HD constexpr int rigid_lds_words_per_env(int n_cp, int rigid = 1) {
