@@ -282,36 +282,29 @@ def cpu_baseline(model, block, budget_s):
     }
 
 
-def timed_repetitions(run_steps, steps, reps, stream, barrier, lib):
-    """`reps` timed regions of EXACTLY `steps` launches each.  Every region is bracketed by a barrier
-    and a stream synchronisation on both sides; wall clock (perf_counter) and HIP events on the launch
-    stream are both taken.  The completion is waited for by polling (`jxs_stream_wait_spin`): a blocking
-    wait adds its wake-up latency, which is comparable to the whole region when `steps` is small."""
-    import ctypes as C  # noqa: F401
-
+def timed_repetitions(timed_region, run_steps, steps, reps, stream, barrier, lib):
+    """`reps` timed regions of EXACTLY `steps` launches each.  Every region is bracketed by a barrier and a
+    stream synchronisation on both sides and timed with the host wall clock; the synchronisation waits poll
+    (a blocking wait adds its wake-up latency, comparable to the whole region when `steps` is small), and
+    the bracket itself runs inside ONE C call (`jxs_step_repeat_timed`: sync, clock, launches, sync, clock) so
+    that no interpreter overhead sits inside the region.  Alternate repetitions take HIP events on the launch
+    stream instead (the two event records would otherwise sit inside the wall-clock region)."""
     from jaxsim_amd import _lib, runtime
 
     wall, evs = [], []
     for r in range(2 * reps):
-        # wall clock and HIP events are taken on alternate repetitions: the two event records would
-        # otherwise sit inside the wall-clock region (a few microseconds of host calls each)
-        with_events = r % 2 == 1
-        ev0, ev1 = (runtime.Event(), runtime.Event()) if with_events else (None, None)
         barrier()
-        _lib.check(lib.jxs_stream_wait_spin(stream.handle), "jxs_stream_wait_spin")
-        t0 = time.perf_counter()
-        if with_events:
-            ev0.record(stream)
-        run_steps(steps)
-        if with_events:
-            ev1.record(stream)
-        _lib.check(lib.jxs_stream_wait_spin(stream.handle), "jxs_stream_wait_spin")
-        t1 = time.perf_counter()
-        barrier()
-        if with_events:
-            evs.append(ev0.elapsed_ms(ev1) * 1e-3)
+        if r % 2 == 0:
+            wall.append(timed_region(steps))
         else:
-            wall.append(t1 - t0)
+            ev0, ev1 = runtime.Event(), runtime.Event()
+            _lib.check(lib.jxs_stream_wait_spin(stream.handle), "jxs_stream_wait_spin")
+            ev0.record(stream)
+            run_steps(steps)
+            ev1.record(stream)
+            _lib.check(lib.jxs_stream_wait_spin(stream.handle), "jxs_stream_wait_spin")
+            evs.append(ev0.elapsed_ms(ev1) * 1e-3)
+        barrier()
     return wall, evs
 
 
@@ -439,6 +432,11 @@ def main():
         if k > 0:
             _lib.check(lib.jxs_step_repeat(dm.handle, state_ptr, None, None, 2, n_local, k, stream.handle), "jxs_step_repeat")
 
+    def timed_region(k):
+        sec = C.c_double(0.0)
+        _lib.check(lib.jxs_step_repeat_timed(dm.handle, state_ptr, None, None, 2, n_local, k, stream.handle, C.byref(sec)), "jxs_step_repeat_timed")
+        return float(sec.value)
+
     def barrier():
         if comm is not None:
             comm.barrier()
@@ -452,7 +450,7 @@ def main():
     # Timed regions: EXACTLY --steps launches each, >= 5 repetitions, the MEDIAN region is reported (the
     # region of a short request, e.g. --steps 20 = 0.2 ms, is otherwise at the mercy of one host hiccup).
     reps = 5 if args.steps >= 500 else 9
-    wall, evs = timed_repetitions(run_steps, args.steps, reps, stream, barrier, lib)
+    wall, evs = timed_repetitions(timed_region, run_steps, args.steps, reps, stream, barrier, lib)
     if comm is not None:  # max over ranks, repetition by repetition
         wall = [float(comm.all_gather_scalars(w).max()) for w in wall]
     elapsed = float(np.median(wall))

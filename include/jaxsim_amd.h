@@ -160,6 +160,12 @@ int jxs_step(jxs_model* model, const void* state_in, void* state_out, const void
 int jxs_step_repeat(jxs_model* model, void* state, const void* tau, const void* link_forces,
                     int force_repr, int N, int n_launches, void* stream);
 
+/* jxs_step_repeat bracketed by stream synchronisations on both sides (polling waits) and a host wall clock,
+ * all inside one call: the timed region of a benchmark without the interpreter's call overhead inside it
+ * (bench.py times its regions of exactly --steps launches with this).  *seconds = wall time of the region. */
+int jxs_step_repeat_timed(jxs_model* model, void* state, const void* tau, const void* link_forces,
+                          int force_repr, int N, int n_launches, void* stream, double* seconds);
+
 /* `n_steps` consecutive steps with constant inputs in ONE launch sequence (what a
  * `jax.lax.fori_loop` over `step` does in the reference's notebooks); in place.           */
 int jxs_rollout(jxs_model* model, void* state, const void* tau, const void* link_forces,

@@ -215,6 +215,7 @@ def _declare(lib):
         "jxs_tile_to_env_major": [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp],
         "jxs_validate_state": [vp, vp, C.c_int, C.POINTER(C.c_int), vp],
         "jxs_step_repeat": [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp],
+        "jxs_step_repeat_timed": [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, C.POINTER(C.c_double)],
         "jxs_refresh_kinematics": [vp, vp, vp, vp, C.c_int, vp],
         "jxs_mass_matrix": [vp, vp, vp, C.c_int, vp],
         "jxs_solver_fault_counts": [vp, C.POINTER(C.c_int), C.c_int, vp],

@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <rccl/rccl.h>
 
 #include <cstdlib>
@@ -484,15 +485,6 @@ int jxs_step_repeat(jxs_model* model, void* state, const void* tau, const void* 
     // driver asking for 20 steps, replays a graph too instead of paying 20 plain launches
     static thread_local Slot slots[3];
     hipStream_t hs = static_cast<hipStream_t>(stream);
-    // A graph launch costs the host ~10 us before the device sees its first packet.  Two plain launches
-    // first give the (possibly idle) device ~18 us of work at once; the graphs are submitted behind them.
-    static const int kLead = std::getenv("JXS_STEP_LEAD_LAUNCHES") ? std::max(0, std::atoi(std::getenv("JXS_STEP_LEAD_LAUNCHES"))) : 2;
-    if (kLead > 0 && n_launches >= kLead + 2) {
-      const int rc = run_any(model, jxs::MODE_STEP, state, state, tau, link_forces, force_repr, nullptr, nullptr, nullptr,
-                             nullptr, N, kLead, stream, nullptr, /*fuse=*/false);
-      if (rc != JXS_OK) return rc;
-      n_launches -= kLead;
-    }
     for (int t = (kLong > kShort ? 0 : 1); t < 3; ++t) {
       const int block = t == 0 ? kLong : t == 1 ? kShort : n_launches;
       if (block < 2 || n_launches < block) continue;
@@ -524,6 +516,18 @@ int jxs_step_repeat(jxs_model* model, void* state, const void* tau, const void* 
   }
   return run_any(model, jxs::MODE_STEP, state, state, tau, link_forces, force_repr, nullptr, nullptr, nullptr, nullptr,
                  N, n_launches, stream, nullptr, /*fuse=*/false);
+}
+int jxs_step_repeat_timed(jxs_model* model, void* state, const void* tau, const void* link_forces, int force_repr, int N,
+                          int n_launches, void* stream, double* seconds) {
+  if (seconds == nullptr) return fail(JXS_EINVAL, "null seconds");
+  int rc = jxs_stream_wait_spin(stream);  // the region starts on an idle stream ...
+  if (rc != JXS_OK) return rc;
+  const auto t0 = std::chrono::steady_clock::now();
+  rc = jxs_step_repeat(model, state, tau, link_forces, force_repr, N, n_launches, stream);
+  if (rc != JXS_OK) return rc;
+  rc = jxs_stream_wait_spin(stream);      // ... and ends when the last launch has completed
+  *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  return rc;
 }
 int jxs_forward_dynamics_aba(jxs_model* model, const void* state, const void* joint_forces, const void* link_forces,
                              int force_repr, void* out_acc, int N, void* stream) {
