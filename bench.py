@@ -189,18 +189,16 @@ def other_contact_models(dtype, stream, steps=200, warmup=20):
         us = events(steps)
         us_step = us
         if with_tau:
-            # the step kernel inside the same controller loop (its run time depends on the contact state, so
-            # it is measured in place): one event pair around each step launch
-            pairs = []
-            for _ in range(50):
+            # the step kernel inside the same controller loop (its run time depends on the contact state, so a
+            # loop of step launches alone is a different workload): loop period minus the period of a loop of
+            # gravity-torque launches alone (a kernel whose run time does not depend on the state)
+            e0, e1 = runtime.Event(), runtime.Event()
+            e0.record(stream)
+            for _ in range(steps):
                 _lib.check(lib.jxs_gravity_torques(dm.handle, st, tp, n_envs, stream.handle), "jxs_gravity_torques")
-                e0, e1 = runtime.Event(), runtime.Event()
-                e0.record(stream)
-                _lib.check(lib.jxs_step(dm.handle, st, st, tp, None, 2, n_envs, stream.handle), "jxs_step")
-                e1.record(stream)
-                pairs.append((e0, e1))
+            e1.record(stream)
             stream.synchronize()
-            us_step = float(np.mean([a.elapsed_ms(b) for a, b in pairs])) * 1e3
+            us_step = us - e0.elapsed_ms(e1) / steps * 1e3
         finite = float(np.isfinite(data.state_block()).all(axis=0).mean())
         lay = dm.layout
         # read state + read tau + write state; the rigid contact models carry no
@@ -306,6 +304,51 @@ def timed_repetitions(timed_region, run_steps, steps, reps, stream, barrier, lib
             evs.append(ev0.elapsed_ms(ev1) * 1e-3)
         barrier()
     return wall, evs
+
+
+def other_configs(stream, steps=200):
+    """Secondary figures for BASELINE.json configs[0] and configs[1] (parity-test configurations, measured once
+    so that every config has a number): the 2-link pendulum at batch 1 in fp64 (a latency figure: one launch
+    per step, and the fused rollout) and the cartpole at batch 1024 in fp32."""
+    import ctypes as C
+
+    import jaxsim_amd as ja
+    import jaxsim_amd.api as js
+    from jaxsim_amd import _lib, robots, runtime
+
+    lib = _lib.load()
+    out = {}
+    for key, urdf, n_envs, dtype in (("config1_pendulum_batch1_fp64", robots.double_pendulum_urdf(), 1, np.float64),
+                                     ("config2_cartpole_batch1024_fp32", robots.cartpole_urdf(), 1024, np.float32)):  # fmt: skip
+        try:
+            model = ja.JaxSimModel.build_from_model_description(urdf)
+            data = js.data.random_model_data(model, batch_size=n_envs, seed=0, dtype=dtype)
+            dm = runtime.device_model(model, dtype)
+            sp = C.c_void_p(data._state.ptr)
+            run = lambda k: _lib.check(lib.jxs_step_repeat(dm.handle, sp, None, None, 2, n_envs, k, stream.handle), "jxs_step_repeat")  # noqa: E731
+            run(steps)
+            stream.synchronize()
+            e0, e1 = runtime.Event(), runtime.Event()
+            e0.record(stream)
+            run(steps)
+            e1.record(stream)
+            stream.synchronize()
+            us = e0.elapsed_ms(e1) / steps * 1e3
+            e2, e3 = runtime.Event(), runtime.Event()
+            e2.record(stream)
+            _lib.check(lib.jxs_rollout(dm.handle, sp, None, None, 2, n_envs, 1000, stream.handle), "jxs_rollout")
+            e3.record(stream)
+            stream.synchronize()
+            lay = dm.layout
+            alg = (2 * (13 + 2 * lay.n_joints + 3 * lay.n_points) + lay.n_joints) * np.dtype(dtype).itemsize
+            out[key] = {"envs": n_envs, "dtype": np.dtype(dtype).name, "us_per_step": us, "env_steps_per_s": n_envs / (us * 1e-6),
+                        "fused_rollout_us_per_step": e2.elapsed_ms(e3) / 1000 * 1e3, "algorithmic_bytes_per_env_step": alg,
+                        "hbm_frac": alg * n_envs / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                        "finite": bool(np.isfinite(data.state_block()).all())}  # fmt: skip
+        except Exception as e:
+            out[key] = {"error": repr(e)}
+    out["note"] = "secondary figures, not `value`: one launch per step through hipGraph replays; batch 1 is launch latency"
+    return out
 
 
 def secondary_dtype(model_name, n_local, dtype, stream, steps=200):
@@ -456,6 +499,20 @@ def main():
     elapsed = float(np.median(wall))
     kernel_ms = float(np.median(evs)) * 1e3 / args.steps  # HIP events on the launch stream
 
+    # secondary figure: the launch path at steady state (2000 launches, HIP events) when the timed regions are short
+    steady = None
+    if args.steps < 1000:
+        run_steps(2000)
+        stream.synchronize()
+        es0, es1 = runtime.Event(), runtime.Event()
+        es0.record(stream)
+        run_steps(2000)
+        es1.record(stream)
+        stream.synchronize()
+        us_ss = es0.elapsed_ms(es1) / 2000 * 1e3
+        steady = {"launches": 2000, "us_per_step": us_ss, "env_steps_per_s_rank0": n_local / (us_ss * 1e-6),
+                  "note": "same kernel and launch path (hipGraph replays of single-step launches), HIP events over 2000 launches; secondary figure"}
+
     # secondary figure: the same K steps as ONE fused jxs_rollout launch (state in registers
     # between steps; what jax.lax.fori_loop over step is to the reference).  Not the headline.
     k_roll = max(args.steps, 200)
@@ -540,6 +597,9 @@ def main():
                 "workload": f"{args.model} synthetic floating-base humanoid, soft contacts (K={model.contact_params.K:.4g}, D={model.contact_params.D:.4g}, mu=0.5), "
                 f"semi-implicit Euler dt=1e-3, nL={lay.n_links} n={n} n_cp={n_cp}, "
                 f"{n_local} envs per GPU x {world} GPU(s) = {n_total} envs, one step kernel launch per step (jxs_step_repeat: hipGraph replays of 250 / 50 / remainder launches, captured during warm-up)",
+                "note_on_value": "`value` is the wall clock of the median timed region of exactly --steps launches, launch and "
+                "synchronisation latency of the region included (~20 us per region: 10 % at --steps 20, 0.1 % at 2000); "
+                "`steady_state` is the same launch path measured over >= 2000 launches",
                 "envs_per_gpu": n_local,
                 "global_batch": n_total,
                 "lanes_per_env": int(lay.group),
@@ -570,6 +630,7 @@ def main():
             "allgather_ms": allgather_ms,
             "allgather_error": allgather_error,
             "comm": None if comm is None else {"kind": type(comm).__name__, "ranks": comm_ranks, "error": comm_error},
+            "steady_state": steady,
             "fused_rollout": {"us_per_step": rollout_ms_per_step * 1e3, "env_steps_per_s_rank0": n_local / (rollout_ms_per_step * 1e-3),
                               "note": "same steps as one jxs_rollout launch; secondary figure, not `value`"},
         }
@@ -581,6 +642,10 @@ def main():
             out["saturated"] = saturated
         if world == 1 and not args.no_other_contact_models:
             out["other_contact_models"] = other_contact_models(dtype, stream)
+            try:
+                out["other_configs"] = other_configs(stream)
+            except Exception as e:
+                out["other_configs"] = {"error": repr(e)}
             try:
                 other = np.dtype(np.float64 if dtype == np.float32 else np.float32)
                 out["other_precision"] = secondary_dtype(args.model, n_local, other, stream)
