@@ -59,6 +59,7 @@ struct Core {
     o[2] = R[6] * x[0] + R[7] * x[1] + R[8] * x[2];
   }
   static JXS_HD void mat3mul(const V* a, const V* b, V* o) {
+    if (L::mat3mul_packed(a, b, o)) return;  // device fp32: v_pk_fma_f32 (jxs_lanes_device.h)
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -1223,8 +1224,10 @@ struct Core {
       if (Lv <= max_depth && (Lv >= 1 || floating)) {
         const VM has = rt.rec[Lv] >= 0;
         V MArow[6];  // (lanes without a link, and the idle lanes 6, 7 of a slot, read the all-zero record)
+        if (!L::add6_packed(cur.Mrow, accM, MArow)) {
 #pragma unroll
-        for (int j = 0; j < 6; ++j) MArow[j] = cur.Mrow[j] + accM[j];
+          for (int j = 0; j < 6; ++j) MArow[j] = cur.Mrow[j] + accM[j];
+        }
         const V pr = cur.pr + accp;
         const V S_r = cur.S_r;
         const V c_r = cur.c_r;
@@ -1236,25 +1239,36 @@ struct Core {
           // U = MA S in every lane of the slot: column sums over the rows (MA symmetric); the six
           // reductions + the one of S^T pA advance stage by stage so that no DPP waits on its source
           V red[7];
+          if (!L::scale6_packed(MArow, S_r, red)) {
 #pragma unroll
-          for (int j = 0; j < 6; ++j) red[j] = MArow[j] * S_r;
+            for (int j = 0; j < 6; ++j) red[j] = MArow[j] * S_r;
+          }
           red[6] = S_r * pr;
           ln.allreduce8x7(red);
           const V* U = red;
-          V U_r = MArow[0] * cur.S[0], d = cur.S[0] * U[0];
+          V U_r, d;
+          if (!(L::dot6_packed(MArow, cur.S, &U_r) && L::dot6_packed(cur.S, U, &d))) {
+            U_r = MArow[0] * cur.S[0], d = cur.S[0] * U[0];
 #pragma unroll
-          for (int j = 1; j < 6; ++j) {
-            U_r = U_r + MArow[j] * cur.S[j];
-            d = d + cur.S[j] * U[j];
+            for (int j = 1; j < 6; ++j) {
+              U_r = U_r + MArow[j] * cur.S[j];
+              d = d + cur.S[j] * U[j];
+            }
           }
           const V u = cur.tau - red[6];
           const V inv = vsel(has, vrcp_acc(vsel(has, d, V(T(1)))), zero);
           const V Ud = U_r * inv;
           V Ma[6], pa = pr + Ud * u;
+          if (L::axpy6_packed(MArow, -Ud, U, Ma)) {
+            V t;
+            L::dot6_packed(Ma, cur.c, &t);
+            pa = pa + t;
+          } else {
 #pragma unroll
-          for (int j = 0; j < 6; ++j) {
-            Ma[j] = MArow[j] - Ud * U[j];
-            pa = pa + Ma[j] * cur.c[j];
+            for (int j = 0; j < 6; ++j) {
+              Ma[j] = MArow[j] - Ud * U[j];
+              pa = pa + Ma[j] * cur.c[j];
+            }
           }
           Ur[Lv] = U_r, Sr[Lv] = S_r, cr[Lv] = c_r, invd[Lv] = inv, uu[Lv] = u;
           // propagate: first children stay in their lanes, extra children are pulled by the
@@ -1306,6 +1320,7 @@ struct Core {
         }
       }
       cur = nxt;
+      ln.stamp(A, 24 + Lv);  // (profiling build: one stamp per tree level)
     }
 
     ln.stamp(A, 7);  // pass 2 (row-distributed)

@@ -76,6 +76,69 @@ struct DeviceLanes {
   using VM = bool;
   static constexpr int G = G_;
 
+  // Packed fp32 math (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two flops-pairs per issue slot).
+  // Measured on the step kernel:
+  // the 3x3 products alone 9.92 -> 9.84 us (round 2).  Each helper returns false where the packed form does
+  // not exist (fp64, host emulation) and the caller runs the scalar loop.
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  static __device__ __forceinline__ bool mat3mul_packed(const float* a, const float* b, float* o) {
+    const f2 b0 = {b[0], b[1]}, b1 = {b[3], b[4]}, b2 = {b[6], b[7]};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const f2 a0 = {a[3 * i], a[3 * i]}, a1 = {a[3 * i + 1], a[3 * i + 1]}, a2 = {a[3 * i + 2], a[3 * i + 2]};
+      const f2 r = __builtin_elementwise_fma(a2, b2, __builtin_elementwise_fma(a1, b1, a0 * b0));
+      o[3 * i] = r.x, o[3 * i + 1] = r.y;
+      o[3 * i + 2] = a[3 * i] * b[2] + a[3 * i + 1] * b[5] + a[3 * i + 2] * b[8];
+    }
+    return true;
+  }
+  // o[j] = a[j] + s * b[j], j < 6
+  static __device__ __forceinline__ bool axpy6_packed(const float* a, float s, const float* b, float* o) {
+    const f2 ss = {s, s};
+#pragma unroll
+    for (int j = 0; j < 6; j += 2) {
+      const f2 r = __builtin_elementwise_fma(ss, f2{b[j], b[j + 1]}, f2{a[j], a[j + 1]});
+      o[j] = r.x, o[j + 1] = r.y;
+    }
+    return true;
+  }
+  // o[j] = a[j] * s
+  static __device__ __forceinline__ bool scale6_packed(const float* a, float s, float* o) {
+    const f2 ss = {s, s};
+#pragma unroll
+    for (int j = 0; j < 6; j += 2) {
+      const f2 r = f2{a[j], a[j + 1]} * ss;
+      o[j] = r.x, o[j + 1] = r.y;
+    }
+    return true;
+  }
+  // o[j] = a[j] + b[j]
+  static __device__ __forceinline__ bool add6_packed(const float* a, const float* b, float* o) {
+#pragma unroll
+    for (int j = 0; j < 6; j += 2) {
+      const f2 r = f2{a[j], a[j + 1]} + f2{b[j], b[j + 1]};
+      o[j] = r.x, o[j + 1] = r.y;
+    }
+    return true;
+  }
+  // sum_j a[j] b[j]
+  static __device__ __forceinline__ bool dot6_packed(const float* a, const float* b, float* o) {
+    f2 r = f2{a[0], a[1]} * f2{b[0], b[1]};
+    r = __builtin_elementwise_fma(f2{a[2], a[3]}, f2{b[2], b[3]}, r);
+    r = __builtin_elementwise_fma(f2{a[4], a[5]}, f2{b[4], b[5]}, r);
+    *o = r.x + r.y;
+    return true;
+  }
+  template <typename... Args>
+  static __device__ __forceinline__ bool axpy6_packed(const double*, Args...) { return false; }
+  template <typename... Args>
+  static __device__ __forceinline__ bool scale6_packed(const double*, Args...) { return false; }
+  template <typename... Args>
+  static __device__ __forceinline__ bool add6_packed(const double*, Args...) { return false; }
+  template <typename... Args>
+  static __device__ __forceinline__ bool dot6_packed(const double*, Args...) { return false; }
+  static __device__ __forceinline__ bool mat3mul_packed(const double*, const double*, double*) { return false; }
+
   int lane_;    // lane within the group
   int base4_;   // (first wave lane of the group) * 4, for ds_bpermute byte addressing
   int env_;     // environment handled by this group
@@ -283,6 +346,47 @@ struct DeviceLanes {
     if (mask) lds_[addr] = v;
   }
   __device__ __forceinline__ V lds_read(int addr) const { return lds_[addr]; }
+  // N consecutive words with 128-bit LDS instructions; `addr` is a multiple of 16 bytes (4 floats / 2 doubles).
+  // One ds instruction costs a lone wave ~15 cycles whether it moves 4 or 16 bytes, a ds_bpermute ~19
+  // (tools/ubench/issue_rate.hip): exchanges of whole records go through these instead of one shuffle per word.
+  template <int N>
+  __device__ __forceinline__ void lds_writev(int addr, const T* v) const {
+    constexpr int W = 16 / (int)sizeof(T);
+    typedef T vec __attribute__((ext_vector_type(W)));
+    T* p = lds_ + addr;
+#pragma unroll
+    for (int i = 0; i + W <= N; i += W) {
+      vec x;
+#pragma unroll
+      for (int e = 0; e < W; ++e) x[e] = v[i + e];
+      *reinterpret_cast<vec*>(p + i) = x;
+    }
+    constexpr int done = N / W * W;
+    if constexpr (N - done >= 2) {
+      typedef T vec2 __attribute__((ext_vector_type(2)));
+      *reinterpret_cast<vec2*>(p + done) = vec2{v[done], v[done + 1]};
+    }
+    if constexpr ((N - done) % 2 == 1) p[N - 1] = v[N - 1];
+  }
+  template <int N>
+  __device__ __forceinline__ void lds_readv(int addr, T* v) const {
+    constexpr int W = 16 / (int)sizeof(T);
+    typedef T vec __attribute__((ext_vector_type(W)));
+    const T* p = lds_ + addr;
+#pragma unroll
+    for (int i = 0; i + W <= N; i += W) {
+      const vec x = *reinterpret_cast<const vec*>(p + i);
+#pragma unroll
+      for (int e = 0; e < W; ++e) v[i + e] = x[e];
+    }
+    constexpr int done = N / W * W;
+    if constexpr (N - done >= 2) {
+      typedef T vec2 __attribute__((ext_vector_type(2)));
+      const vec2 x = *reinterpret_cast<const vec2*>(p + done);
+      v[done] = x[0], v[done + 1] = x[1];
+    }
+    if constexpr ((N - done) % 2 == 1) v[N - 1] = p[N - 1];
+  }
   // Between LDS writes and reads of ANOTHER lane's data: the hardware keeps the DS queue of a wave in
   // order, but the compiler reasons per thread (it may forward a masked store to the following load, or
   // order the two sides of a lane-divergent branch either way) -- this fence pins program order.

@@ -105,6 +105,7 @@ enum RowLds : int { RL_M = 0, RL_S = 36, RL_C = 42, RL_PA = 48, RL_TAU = 54, RL_
 // The link kinematics staged for the contact phase ([G][kKinRec] words) ALIAS the record area: the contact phase
 // has read them back before the ABA publishes its records (a single-wave workgroup executes its LDS
 // operations in program order).  20.6 KB -> 16 KB per humanoid wave: ten waves per CU instead of seven.
+constexpr int kFkRec = 12;   // pointer-jumping exchange of the forward kinematics: R (9), r (3); [G + 1] records, aliased too
 constexpr int kKinRec = 21;  // R (9), r (3), v_lin (3), v_ang (3), anchor of the link's chain (3)
 JXS_HD constexpr int lds_kin_offset(int) { return 0; }
 // records + base rows (42 words) + pad (6) + one all-zero record: row lanes without a link at a level read

@@ -130,6 +130,16 @@ struct HostLanes {
   using VM = Vec<bool, G_>;
   static constexpr int G = G_;
 
+  static bool mat3mul_packed(const V*, const V*, V*) { return false; }
+  template <typename... Args>
+  static bool axpy6_packed(Args...) { return false; }
+  template <typename... Args>
+  static bool scale6_packed(Args...) { return false; }
+  template <typename... Args>
+  static bool add6_packed(Args...) { return false; }
+  template <typename... Args>
+  static bool dot6_packed(Args...) { return false; }
+
   int env_;
   int N_;
   mutable std::vector<T_> lds_;
@@ -223,6 +233,14 @@ struct HostLanes {
     V r;
     for (int i = 0; i < G; ++i) r.v[i] = lds_[addr.v[i]];
     return r;
+  }
+  template <int N>
+  void lds_writev(const VI& addr, const V* v) const {
+    for (int k = 0; k < N; ++k) lds_write(addr + k, v[k]);
+  }
+  template <int N>
+  void lds_readv(const VI& addr, V* v) const {
+    for (int k = 0; k < N; ++k) v[k] = lds_read(addr + k);
   }
   void fmac9_from_next(V* a, const V* x, const V& m) const {
     for (int k = 0; k < 9; ++k) a[k] = a[k] + m * from_next(x[k]);

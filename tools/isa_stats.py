@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Instruction statistics of the gfx950 kernels of one translation unit (developer aid).
     python tools/isa_stats.py float 0 [G]      -> compiles jxs_inst.hip for (dtype, mode) to assembly and counts"""
+import os
 import pathlib
 import re
 import subprocess
@@ -10,7 +11,7 @@ ROOT = pathlib.Path(__file__).resolve().parent.parent
 dtype, mode = sys.argv[1], sys.argv[2]
 only_g = sys.argv[3] if len(sys.argv) > 3 else None
 out = pathlib.Path(f"/tmp/inst_{dtype}_{mode}.s")
-subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-mllvm",
+subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", *os.environ.get("JXS_ISA_FLAGS", "-fno-slp-vectorize").split(), "-mllvm",
                 "-amdgpu-kernarg-preload-count=16", "-Wno-cuda-compat", "-Wno-pass-failed", f"-DJXS_INST_T={dtype}", f"-DJXS_INST_MODE={mode}",
                 "--cuda-device-only", "-S", "jxs_inst.hip", "-o", str(out)], cwd=ROOT / "jaxsim_amd" / "csrc", check=True,
                stderr=subprocess.DEVNULL)

@@ -38,5 +38,9 @@ print(f"  {'total':24s} {(out[:, 10] - out[:, 0]).mean():9.0f}")
 if out[:, 20].any():
     for i, n in ((20, "index tables arrived"), (21, "base state rows arrived"), (22, "point tables arrived"), (23, "joint state rows arrived")):
         print(f"  since wave start: {n:28s} {(out[:, i] - out[:, 0]).mean():9.0f}  (max {(out[:, i] - out[:, 0]).max()})")
+if out[:, 24].any():  # row-distributed pass 2: one stamp per tree level, deepest level first
+    lv = out[:, 31:23:-1]
+    dl = np.diff(np.concatenate([out[:, 6:7], lv], axis=1), axis=1)
+    print("  pass 2 per level (deepest first): " + " ".join(f"{x:.0f}" for x in dl.mean(axis=0)))
 span = out[:, 10].max() - out[:, 0].min()
 print(f"  first start -> last end: {span} ticks")

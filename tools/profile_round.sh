@@ -18,7 +18,13 @@ rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/c5" -- python "$R/
 rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/c5_relaxed" -- python "$R/tools/bench_c5.py" --contact relaxed --points 16 > "$OUT/c5_relaxed.log" 2>&1
 cd "$R"
 python bench.py > "$OUT/bench_N1.json" 2> "$OUT/bench_N1.err"
+python bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/bench_steps20.json" 2> "$OUT/bench_steps20.err"
 if [ -f jaxsim_amd/csrc/libjaxsim_amd_timing.so ]; then
   JAXSIM_AMD_LIB=$R/jaxsim_amd/csrc/libjaxsim_amd_timing.so python tools/phase_timing.py > "$OUT/phases.log" 2>&1
+  for a in "4 4096" "16 4096" "16 4096 relaxed standing" "32 1024 relaxed standing"; do
+    JAXSIM_AMD_LIB=$R/jaxsim_amd/csrc/libjaxsim_amd_timing.so python tools/phase_timing_rigid.py $a >> "$OUT/phases_contact_models.log" 2>&1
+  done
 fi
+python tools/fp32_error_gpu.py 512 > "$OUT/fp32_error_gpu.log" 2>&1
+python tools/experiments/env_per_lane.py > "$OUT/env_per_lane.log" 2>&1
 tail -c 600 "$OUT/bench_N1.json"

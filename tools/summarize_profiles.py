@@ -16,7 +16,7 @@ lines = [f"# rocprofv3 summary {tag} (source: {run})", ""]
 ks = glob.glob(str(run / "stats" / "*" / "*_kernel_stats.csv"))
 if ks:
     shutil.copy(ks[0], out / f"{tag}_kernel_stats.csv")
-    lines += ["## `rocprofv3 --kernel-trace --stats -- python bench.py --steps 500 --warmup 20 --no-cpu-baseline`", "",
+    lines += ["## `rocprofv3 --kernel-trace --stats -- python bench.py --steps 500 --warmup 20 --no-cpu-baseline --saturated-envs 0 --no-other-contact-models`", "",
               "| kernel | calls | total ns | avg ns | % |", "|---|---|---|---|---|"]
     for r in csv.DictReader(open(ks[0])):
         lines.append(f"| `{r['Name'][:90]}` | {r['Calls']} | {r['TotalDurationNs']} | {float(r['AverageNs']):.0f} | {float(r['Percentage']):.2f} |")
@@ -29,7 +29,7 @@ for d in sorted(run.glob("pmc_*")):
     agg = collections.defaultdict(list)
     waves = None
     for r in csv.DictReader(open(f[0])):
-        if "jxs_kernel<float, 32, 0>" in r["Kernel_Name"]:  # the step kernel only (not the fused rollout / kinematics)
+        if "jxs_kernel<float, 32, 0," in r["Kernel_Name"]:  # the step kernel only (not the fused rollout / kinematics)
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
             waves = int(r["Grid_Size"]) // 64
     for k, v in agg.items():
@@ -46,6 +46,12 @@ if summary:
         lines += [f"HBM-side traffic per launch: FETCH_SIZE {fetch / 1e6:.2f} MB raw (x2 gfx950 correction of "
                   f"MI355X_MICROARCH.md section HBM = {2 * fetch / 1e6:.2f} MB), WRITE_SIZE {write / 1e6:.2f} MB.", ""]
         summary["traffic_bytes_per_launch"] = 2 * fetch + write
+    # bench.py only quotes the traffic for the configuration and the kernel sources it was measured on
+    sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
+    import bench
+
+    summary["config"] = {"model": "icub23", "envs": 1024, "dtype": "float32"}
+    summary["kernel_source_sha"] = bench.kernel_source_sha()
     (out / f"{tag}_pmc.json").write_text(json.dumps(summary, indent=1))
 (out / f"{tag}_summary.md").write_text("\n".join(lines))
 print("\n".join(lines))
