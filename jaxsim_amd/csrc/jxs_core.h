@@ -1140,7 +1140,7 @@ struct Core {
   }
 
   struct RowLevel {
-    V Mrow[6], S[6], c[6], pr, S_r, c_r, tau;
+    V Mrow[6], S[6], c[6], pr, S_r, c_r, tau, dp[3];
   };
   JXS_HD void load_row_level(const VI& rec, const VI& row6, const VI& lane, RowLevel& o) const {
     // no link in this slot at this level: the all-zero record; the two idle lanes of a slot read their
@@ -1148,42 +1148,44 @@ struct Core {
     const VI zr = lane * 0 + lds_zero_rec(G);
     const VI base = vsel(rec >= 0, rec, zr);
     const VI brow = vsel((lane & 7) < 6, base, zr);
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      o.Mrow[j] = ln.lds_read(brow + row6 * 6 + (RL_M + j));
-      o.S[j] = ln.lds_read(base + (RL_S + j));
-      o.c[j] = ln.lds_read(base + (RL_C + j));
-    }
-    o.pr = ln.lds_read(brow + row6 + RL_PA);
-    o.S_r = ln.lds_read(brow + row6 + RL_S);
+    V rw[8], sc[12], td[4];
+    ln.template lds_readv<8>(brow + row6 * 8, rw);
+    ln.template lds_readv<12>(base + RL_S, sc);
+    ln.template lds_readv<4>(base + RL_TAU, td);
     o.c_r = ln.lds_read(brow + row6 + RL_C);
-    o.tau = ln.lds_read(base + RL_TAU);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) o.Mrow[j] = rw[j], o.S[j] = sc[j], o.c[j] = sc[6 + j];
+    o.pr = rw[RL_ROW_PA], o.S_r = rw[RL_ROW_S];
+    o.tau = td[0];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) o.dp[k] = td[1 + k];
   }
 
   JXS_HD void aba_rows(const VI& lane, const RowTabs& rt, const V* MA, const V* pA, const V* S6, const V* c6,
                        const V& tau, const bool anch, const V* dpl, V& sdd, V* a0) const {
     const V zero = V(T(0));
     const VI rec_me = lane * kRowRec;
-    // ---- link lanes publish their record -------------------------------------------------
+    // ---- link lanes publish their record (128-bit writes) ---------------------------------
 #pragma unroll
-    for (int i = 0; i < 6; ++i)
-#pragma unroll
-      for (int j = 0; j < 6; ++j) ln.lds_write(rec_me + (RL_M + 6 * i + j), MA[sidx(i, j)]);
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-      ln.lds_write(rec_me + (RL_S + k), S6[k]);
-      ln.lds_write(rec_me + (RL_C + k), c6[k]);
-      ln.lds_write(rec_me + (RL_PA + k), pA[k]);
+    for (int i = 0; i < 6; ++i) {
+      const V rw[8] = {MA[sidx(i, 0)], MA[sidx(i, 1)], MA[sidx(i, 2)], MA[sidx(i, 3)], MA[sidx(i, 4)], MA[sidx(i, 5)], pA[i], S6[i]};
+      ln.template lds_writev<8>(rec_me + (RL_ROW + 8 * i), rw);
     }
-    ln.lds_write(rec_me + RL_TAU, tau);
+    {
+      const V sc[12] = {S6[0], S6[1], S6[2], S6[3], S6[4], S6[5], c6[0], c6[1], c6[2], c6[3], c6[4], c6[5]};
+      ln.template lds_writev<12>(rec_me + RL_S, sc);
+      const V td[4] = {tau, anch ? dpl[0] : zero, anch ? dpl[1] : zero, anch ? dpl[2] : zero};
+      ln.template lds_writev<4>(rec_me + RL_TAU, td);
+    }
     ln.lds_write(rec_me + RL_SDD, zero);
+    {  // the all-zero record: kRowRec / 4 lanes write four words each
+      const V z4[4] = {zero, zero, zero, zero};
+      static_assert(kRowRec % 4 == 0, "record = whole 16-byte groups");
 #pragma unroll
-    for (int k = 0; k < (kRowRec + G - 1) / G; ++k) ln.lds_write(lane + (lds_zero_rec(G) + k * G), zero, lane + k * G < kRowRec);
-    if (anch) {
-#pragma unroll
-      for (int k = 0; k < 3; ++k) ln.lds_write(rec_me + (RL_DP + k), dpl[k]);
+      for (int k = 0; k < (kRowRec / 4 + G - 1) / G; ++k)
+        ln.template lds_writev_if<4>((lane + k * G) * 4 + lds_zero_rec(G), z4, lane + k * G < kRowRec / 4);
     }
-    const int XB = G * kRowRec;  // base rows: [XB + 7 r + j], j < 6 inertia row, j = 6 bias force
+    const int XB = G * kRowRec;  // base rows: [XB + 8 r + j], j < 6 inertia row, j = 6 bias force
 
     const VI row = lane & 7;
     const VM rowok = row < 6;
@@ -1276,10 +1278,9 @@ struct Core {
           if (Lv >= 2 || floating) {
             if (anch && ((cross_levels >> Lv) & 1u)) {
               // re-refer the rows of the links that leave their chain here (d = 0 for first children)
-              const VI dbase = vsel(has, rt.rec[Lv], lane * 0) + RL_DP;
-              V d3[3];
+              V d3[3];  // (arrived with tau; zero where the slot holds no link)
 #pragma unroll
-              for (int k = 0; k < 3; ++k) d3[k] = vsel(has, ln.lds_read(dbase + k), zero), dkeep[Lv][k] = d3[k];
+              for (int k = 0; k < 3; ++k) d3[k] = cur.dp[k], dkeep[Lv][k] = d3[k];
               {  // row[3:6] -= row[0:3] x d
                 const V t0 = Ma[1] * d3[2] - Ma[2] * d3[1], t1 = Ma[2] * d3[0] - Ma[0] * d3[2], t2 = Ma[0] * d3[1] - Ma[1] * d3[0];
                 Ma[3] = Ma[3] - t0, Ma[4] = Ma[4] - t1, Ma[5] = Ma[5] - t2;
@@ -1327,16 +1328,19 @@ struct Core {
     // ---- base acceleration (rbda/aba.py:240-243) --------------------------------------------
     if (floating) {
       // the six row lanes of slot 0 publish the base rows; every lane then solves the same 6x6
-#pragma unroll
-      for (int j = 0; j < 6; ++j) ln.lds_write(row6 * 7 + (XB + j), MA0[j], lane < 6);
-      ln.lds_write(row6 * 7 + (XB + 6), p0, lane < 6);
+      {
+        const V rw[8] = {MA0[0], MA0[1], MA0[2], MA0[3], MA0[4], MA0[5], p0, zero};
+        ln.template lds_writev_if<8>(row6 * 8 + XB, rw, lane < 6);
+      }
       V MAs[21], pAs[6];
       const VI z = lane * 0;
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
+        V rw[8];
+        ln.template lds_readv<8>(z + (XB + 8 * i), rw);
 #pragma unroll
-        for (int j = i; j < 6; ++j) MAs[sidx(i, j)] = ln.lds_read(z + (XB + 7 * i + j));
-        pAs[i] = ln.lds_read(z + (XB + 7 * i + 6));
+        for (int j = i; j < 6; ++j) MAs[sidx(i, j)] = rw[j];
+        pAs[i] = rw[6];
       }
       solve6(MAs, pAs, a0);
     } else {

@@ -369,6 +369,10 @@ struct DeviceLanes {
     if constexpr ((N - done) % 2 == 1) p[N - 1] = v[N - 1];
   }
   template <int N>
+  __device__ __forceinline__ void lds_writev_if(int addr, const T* v, bool mask) const {
+    if (mask) lds_writev<N>(addr, v);
+  }
+  template <int N>
   __device__ __forceinline__ void lds_readv(int addr, T* v) const {
     constexpr int W = 16 / (int)sizeof(T);
     typedef T vec __attribute__((ext_vector_type(W)));

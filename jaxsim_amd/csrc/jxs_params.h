@@ -89,7 +89,7 @@ JXS_HD constexpr int chunk_bytes(int G) { return G * kPtStride * 4 + G * kPtStri
 // serial chain never leaves its lanes.
 constexpr int kRowLevels = 8;     // tree levels 0..7 (deeper trees use the link-per-lane sweeps)
 constexpr int kRowExtra = 3;      // extra (non-first) children per link handled by cross-slot pulls
-constexpr int kRowRec = 61;       // LDS words per link record (odd stride: conflict-free b32 access)
+constexpr int kRowRec = 68;       // LDS words per link record (multiple of 16 bytes: 128-bit accesses)
 enum RowI : int {
   RT_REC = 0,                         // [kRowLevels] LDS word offset of the record of link(L, slot), -1 if none
   RT_FC = RT_REC + kRowLevels,        // bit L: link(L, slot) is the first child of link(L-1, slot)
@@ -98,17 +98,20 @@ enum RowI : int {
   RT_COUNT = RT_PPULL + kRowLevels
 };
 constexpr int kRtiStride = (RT_COUNT + 3) / 4 * 4;  // rti[lane * kRtiStride + field]
-// LDS record layout (words): 0..35 M (6x6), 36..41 S, 42..47 c, 48..53 pA, 54 tau, 55 sdd (result),
-// 56..58 anchor of this link's chain minus the anchor of its parent's chain (zero for first children)
-// exchange area after the G records: base rows 42 words, a0 6 words, sdd G words
-enum RowLds : int { RL_M = 0, RL_S = 36, RL_C = 42, RL_PA = 48, RL_TAU = 54, RL_SDD = 55, RL_DP = 56 };
+// LDS record layout (words).  Every group a lane reads together is 16-byte aligned and contiguous, because
+// one ds instruction costs a lone wave ~14 cycles whether it moves 4 or 16 bytes (tools/ubench/issue_rate.hip):
+//   8 r + 0..5  row r of M (6x6),  8 r + 6  pA[r],  8 r + 7  S[r]      (r < 6: what row lane r reads, two b128)
+//   48..53 S, 54..59 c                                                   (slot-uniform, three b128)
+//   60 tau, 61..63 anchor of this link's chain minus the anchor of its parent's chain (zero for first children)
+//   64 sdd (result)
+// after the G records: the base rows, 6 x 8 words {row of MA_0, pA_0[r], -}, then one all-zero record
+enum RowLds : int { RL_ROW = 0, RL_ROW_PA = 6, RL_ROW_S = 7, RL_S = 48, RL_C = 54, RL_TAU = 60, RL_DP = 61, RL_SDD = 64 };
 // The link kinematics staged for the contact phase ([G][kKinRec] words) ALIAS the record area: the contact phase
 // has read them back before the ABA publishes its records (a single-wave workgroup executes its LDS
 // operations in program order).  20.6 KB -> 16 KB per humanoid wave: ten waves per CU instead of seven.
-constexpr int kFkRec = 12;   // pointer-jumping exchange of the forward kinematics: R (9), r (3); [G + 1] records, aliased too
 constexpr int kKinRec = 21;  // R (9), r (3), v_lin (3), v_ang (3), anchor of the link's chain (3)
 JXS_HD constexpr int lds_kin_offset(int) { return 0; }
-// records + base rows (42 words) + pad (6) + one all-zero record: row lanes without a link at a level read
+// records + base rows (48 words) + one all-zero record: row lanes without a link at a level read
 // zeros from it instead of selecting them (nine v_cndmask per level saved)
 JXS_HD constexpr int lds_zero_rec(int G) { return G * kRowRec + 48; }
 JXS_HD constexpr int lds_words_per_env(int G) { return (lds_zero_rec(G) + kRowRec + 3) / 4 * 4; }

@@ -239,6 +239,10 @@ struct HostLanes {
     for (int k = 0; k < N; ++k) lds_write(addr + k, v[k]);
   }
   template <int N>
+  void lds_writev_if(const VI& addr, const V* v, const VM& mask) const {
+    for (int k = 0; k < N; ++k) lds_write(addr + k, v[k], mask);
+  }
+  template <int N>
   void lds_readv(const VI& addr, V* v) const {
     for (int k = 0; k < N; ++k) v[k] = lds_read(addr + k);
   }
