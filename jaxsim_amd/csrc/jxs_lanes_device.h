@@ -206,6 +206,11 @@ struct DeviceLanes {
   __device__ __forceinline__ int shfl(int x, int src) const { return __builtin_amdgcn_ds_bpermute(src4(src), x); }
   // true if the predicate holds in any lane of the wave (all environments of this tile)
   __device__ __forceinline__ bool any(bool m) const { return __builtin_amdgcn_ballot_w64(m) != 0ull; }
+  // bit l = the predicate of lane l of this environment, in every lane of the environment
+  __device__ __forceinline__ int env_bits(bool m) const {
+    const unsigned long long b = __builtin_amdgcn_ballot_w64(m) >> (base4_ >> 2);
+    return (int)((unsigned)b & (G >= 32 ? 0xffffffffu : ((1u << (G & 31)) - 1u)));
+  }
   __device__ __forceinline__ double shfl(double x, int src) const {
     const int a = src4(src);
     int lo = __double2loint(x), hi = __double2hiint(x);

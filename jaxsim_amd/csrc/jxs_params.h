@@ -118,7 +118,8 @@ JXS_HD constexpr int lds_words_per_env(int G) { return (lds_zero_rec(G) + kRowRe
 // rigid modes: Q and H packed lower triangles of order 3 n_cp + one exchange vector (jxs_rigid.inc)
 // RelaxedRigidContacts (rigid == 2) factorises in place of the Delassus matrix: one triangle
 JXS_HD constexpr int rigid_lds_words_per_env(int n_cp, int rigid = 1) {
-  return (rigid == 2 ? 1 : 2) * ((3 * n_cp * (3 * n_cp + 1)) / 2) + 3 * n_cp + 8;
+  // (+16: the gather buffer of the small-problem solver when the H triangle is shorter than it; whole 16-byte groups)
+  return ((rigid == 2 ? 1 : 2) * ((3 * n_cp * (3 * n_cp + 1)) / 2) + 3 * n_cp + 8 + 16 + 3) / 4 * 4;
 }
 constexpr int kQpMaxIter = 30;    // interior-point iterations (oracle/refrigid.py QP_MAX_ITER)
 constexpr int kRigidMaxPoints = 32;

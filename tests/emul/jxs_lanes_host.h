@@ -167,6 +167,11 @@ struct HostLanes {
   }
   V env_bcast16(const V& x, int src) const { return V(x.v[src]); }
   static unsigned uniform(unsigned x) { return x; }
+  VI env_bits(const VM& m) const {
+    int b = 0;
+    for (int i = 0; i < G && i < 32; ++i) b |= m.v[i] ? (1 << i) : 0;
+    return VI(b);
+  }
   bool any(const VM& m) const {
     for (int i = 0; i < G; ++i)
       if (m.v[i]) return true;
