@@ -1397,7 +1397,7 @@ struct Core {
   }
 
   struct PointSlot {
-    VI body, prow, tail, hd;
+    VI body, prow, tail, hd, l1;
     V Lp[3], m[3], md[3];  // md: deformation rate of the last evaluation (chunk 0)
   };
   JXS_HD void load_slot_tables(const VI& lane, int ch, PointSlot& ps) const {
@@ -1408,6 +1408,7 @@ struct Core {
     ps.body = ln.ploadi(pti, PI_BODY, lane);
     ps.prow = ln.ploadi(pti, PI_ROW, lane);
     ps.tail = ln.ploadi(pti, PI_TAIL, lane);
+    ps.l1 = ln.ploadi(pti, PI_L1, lane);
 #pragma unroll
     for (int k = 0; k < 3; ++k) ps.Lp[k] = ln.ploadf(ptf, PF_POS + k, lane);
     ps.hd = ln.hconsti(head, 0);

@@ -335,6 +335,30 @@ std::string pack_model(const jxs_model_desc& d, Packed<T>& out) {
     out.pti[(size_t)s * kPtStride + PI_ROW] = k;
     for (int c = 0; c < 3; ++c) out.ptf[(size_t)s * kPtStride + PF_POS + c] = (T)d.point_position[3 * k + c];
   }
+  // merged Delassus sweeps (jxs_rigid.inc): possible when every point has a subtree of the base to itself
+  P.rg_merge = 0;
+  for (int lane = 0; lane < G; ++lane) I(LI_RGPT, lane) = -1;
+  if (P.rigid && d.floating_base && n_en >= 1 && n_en <= 4 && n_chunks == 1 && std::getenv("JXS_DISABLE_RG_MERGE") == nullptr) {  // developer knob: A/B
+    std::vector<int> l1(n_en, -1);
+    bool ok = true;
+    for (int s = 0; s < n_en && ok; ++s) {
+      int a = d.point_body[en[s]];
+      if (level[a] < 1) ok = false;
+      while (ok && level[a] > 1) a = d.parent[a];
+      l1[s] = a;
+      for (int t = 0; t < s; ++t) ok = ok && l1[t] != a;
+    }
+    if (ok) {
+      P.rg_merge = 1;
+      for (int s = 0; s < n_en; ++s) {
+        out.pti[(size_t)s * kPtStride + PI_L1] = lane_of[l1[s]];
+        for (int a = d.point_body[en[s]];; a = d.parent[a]) {
+          I(LI_RGPT, lane_of[a]) = s;
+          if (level[a] == 1) break;
+        }
+      }
+    }
+  }
   for (int ch = 0; ch < n_chunks; ++ch) {
     int s = ch * G;
     const int end = std::min(n_en, (ch + 1) * G);

@@ -63,7 +63,9 @@ enum LaneI : int {
   LI_ANCHOR = LI_SUBTREE + 1,         // lane of the LEAF of this link's first-child chain: the reference point of its
                                       // articulated-body quantities (jxs_core.h, "Anchored ABA")
   LI_PANCHOR = LI_ANCHOR + 1,         // LI_ANCHOR of the parent link (own anchor for the base / first children)
-  LI_COUNT = LI_PANCHOR + 1
+  LI_RGPT = LI_PANCHOR + 1,           // rigid modes, merged Delassus sweeps (KParams::rg_merge): slot of the collidable
+                                      // point whose parent link lies in the subtree of this link, -1 if none
+  LI_COUNT = LI_RGPT + 1
 };
 constexpr int kLtiStride = (LI_COUNT + 3) / 4 * 4;
 
@@ -73,7 +75,8 @@ enum PointI : int {
   PI_BODY = 0,   // lane of the parent link, -1 for an empty slot
   PI_ROW = 1,    // original collidable-point index (row of the tangential deformation state)
   PI_TAIL = 2,   // number of slots after this one in the same (chunk, link) segment
-  PI_COUNT = 3
+  PI_L1 = 3,     // rigid modes (KParams::rg_merge): lane of the level-1 ancestor of the parent link
+  PI_COUNT = 4
 };
 constexpr int kPtStride = 4;
 // The point tables are stored per CHUNK of G slots, one fixed-size record per chunk (so that the address of
@@ -117,10 +120,13 @@ JXS_HD constexpr int lds_zero_rec(int G) { return G * kRowRec + 48; }
 JXS_HD constexpr int lds_words_per_env(int G) { return (lds_zero_rec(G) + kRowRec + 3) / 4 * 4; }
 // rigid modes: Q and H packed lower triangles of order 3 n_cp + one exchange vector (jxs_rigid.inc)
 // RelaxedRigidContacts (rigid == 2) factorises in place of the Delassus matrix: one triangle
-JXS_HD constexpr int rigid_lds_words_per_env(int n_cp, int rigid = 1) {
-  // (+16: the gather buffer of the small-problem solver when the H triangle is shorter than it; whole 16-byte groups)
+// (+16: the gather buffer of the small-problem solver when the H triangle is shorter than it; whole 16-byte
+// groups), then the exchange area of the merged Delassus sweeps: kRgMergeRec words per point, up to 4 points
+constexpr int kRgMergeRec = 40;  // [0, 18) wrench handed to the base per unit force, [20, 38) base acceleration
+JXS_HD constexpr int rigid_lds_merge_off(int n_cp, int rigid = 1) {
   return ((rigid == 2 ? 1 : 2) * ((3 * n_cp * (3 * n_cp + 1)) / 2) + 3 * n_cp + 8 + 16 + 3) / 4 * 4;
 }
+JXS_HD constexpr int rigid_lds_words_per_env(int n_cp, int rigid = 1) { return rigid_lds_merge_off(n_cp, rigid) + 4 * kRgMergeRec; }
 constexpr int kQpMaxIter = 30;    // interior-point iterations (oracle/refrigid.py QP_MAX_ITER)
 constexpr int kRigidMaxPoints = 32;
 constexpr int kDbgSlots = 32;      // developer profiling build: cycle stamps / counters per workgroup
@@ -186,6 +192,7 @@ struct KParams {
   // RigidContacts (rbda/contacts/rigid.py:95-174); K, D, mu above are then RigidContactsParams
   int rigid;                     // contact model: 0 SoftContacts, 1 RigidContacts, 2 RelaxedRigidContacts
   int n_cp;                      // enabled collidable points (= used slots of chunk 0 in the rigid modes)
+  int rg_merge;                  // every point sits alone in its own subtree of the base: merged Delassus sweeps (jxs_rigid.inc)
   T reg_delassus;                // regularization_delassus (1e-6)
   T qp_tol;                      // solver_options["solver_tol"] (1e-3)
   T impact_rel_tol;              // relative Tikhonov shift of the impact preconditioner

@@ -64,6 +64,11 @@ struct Vec {
     return r;
   }
   friend Vec vrcp_acc(const Vec& a) { return vrcp(a); }
+  friend Vec vrsqrt(const Vec& a) {
+    Vec r;
+    for (int i = 0; i < G; ++i) r.v[i] = T(1) / std::sqrt(a.v[i]);
+    return r;
+  }
   friend Vec vabs(const Vec& a) {
     Vec r;
     for (int i = 0; i < G; ++i) r.v[i] = std::fabs(a.v[i]);
