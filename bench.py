@@ -205,36 +205,66 @@ def other_contact_models(dtype, stream, steps=200, warmup=20):
         # tangential deformation (rbda/contacts/rigid.py:445-458), so the 3 n_cp term drops
         alg = (2 * (13 + 2 * lay.n_joints) + lay.n_joints) * np.dtype(dtype).itemsize
         gbs = alg * n_envs / (us_step * 1e-6) / 1e9
+        from jaxsim_amd import specialize
+
         return {"envs": n_envs, "steps": steps, "us_per_step": us, "env_steps_per_s": n_envs / (us * 1e-6), "finite_envs": finite,
+                "model_specialised_kernel": bool(specialize.modes(dm)),
                 "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                              "traffic": None, "algorithmic_bytes_per_env_step": alg, "kernel": kernel,
                              "kernel_avg_launch_us": us_step}}  # fmt: skip
 
-    def enable(model, idx):
-        kdp = model.kin_dyn_parameters
-        en = np.zeros(kdp.number_of_collidable_points(), dtype=bool)
-        en[list(idx)] = True
-        model.kin_dyn_parameters = dataclasses.replace(kdp, contact_enabled=en)
-
     try:
-        quad = ja.JaxSimModel.build_from_model_description(robots.anymal12_urdf())
-        enable(quad, [0, 8, 16, 24])  # one bottom corner of every foot box
-        quad.contact_model = ja.RigidContacts.build()
-        quad.contact_params = ja.RigidContactsParams(K=1e4, D=2e2)
+        quad = build_quadruped_rigid()
         out["config5_rigid_contacts"] = timed(quad, 4096, 100, True, f"jxs_kernel<{tname},16,MODE_STEP_RIGID>") | {
             "workload": "anymal12 synthetic, RigidContacts (4 points), tau = RNEA gravity term every step (jxs_gravity_torques + jxs_step)"}  # fmt: skip
     except Exception as e:
         out["config5_rigid_contacts"] = {"error": repr(e)}
     try:
-        hum = ja.JaxSimModel.build_from_model_description(robots.icub23_urdf(sole_boxes_per_foot=2))
-        hum.contact_model = ja.RelaxedRigidContacts.build()
-        hum.contact_params = js.contact.estimate_good_contact_parameters(hum)
+        hum = build_humanoid_relaxed()
         out["relaxed_rigid_contacts"] = timed(hum, 1024, 200, False, f"jxs_kernel<{tname},32,MODE_STEP_RIGID>") | {
             "workload": "icub23 synthetic, all 32 collidable points, RelaxedRigidContacts with estimate_good_contact_parameters (jxs_step)"}  # fmt: skip
     except Exception as e:
         out["relaxed_rigid_contacts"] = {"error": repr(e)}
     out["note"] = "secondary figures, not `value`; DESIGN.md sections 4d, 4e, 6"
     return out
+
+
+def build_quadruped_rigid():
+    """BASELINE.json configs[4]: quadruped with RigidContacts, one point per foot."""
+    import dataclasses
+
+    import jaxsim_amd as ja
+    from jaxsim_amd import robots
+
+    quad = ja.JaxSimModel.build_from_model_description(robots.anymal12_urdf())
+    kdp = quad.kin_dyn_parameters
+    en = np.zeros(kdp.number_of_collidable_points(), dtype=bool)
+    en[[0, 8, 16, 24]] = True  # one bottom corner of every foot box
+    quad.kin_dyn_parameters = dataclasses.replace(kdp, contact_enabled=en)
+    quad.contact_model = ja.RigidContacts.build()
+    quad.contact_params = ja.RigidContactsParams(K=1e4, D=2e2)
+    return quad
+
+
+def build_humanoid_relaxed():
+    import jaxsim_amd as ja
+    import jaxsim_amd.api as js
+    from jaxsim_amd import robots
+
+    hum = ja.JaxSimModel.build_from_model_description(robots.icub23_urdf(sole_boxes_per_foot=2))
+    hum.contact_model = ja.RelaxedRigidContacts.build()
+    hum.contact_params = js.contact.estimate_good_contact_parameters(hum)
+    return hum
+
+
+def secondary_models():
+    """(model, dtype) of the secondary figures: __graft_entry__.build() pre-builds their specialised kernels."""
+    import jaxsim_amd as ja
+    from jaxsim_amd import robots
+
+    return [(build_quadruped_rigid(), np.float32), (build_humanoid_relaxed(), np.float32),
+            (ja.JaxSimModel.build_from_model_description(robots.double_pendulum_urdf()), np.float64),
+            (ja.JaxSimModel.build_from_model_description(robots.cartpole_urdf()), np.float32)]  # fmt: skip
 
 
 def cpu_baseline(model, block, budget_s):
@@ -415,6 +445,10 @@ def main():
     if os.environ.get("JAXSIM_AMD_LIB"):
         # the developer knob of jaxsim_amd/_lib.py would let any library stand in for the product
         raise SystemExit("bench.py measures the in-tree library only: unset JAXSIM_AMD_LIB")
+    # Model-specialised step kernels (jaxsim_amd/specialize.py): what `jax.jit` is to the reference -- the same
+    # kernel source compiled with the model's integer flags as constants.  Built once per model (seconds, hipcc;
+    # __graft_entry__.build() pre-builds the configurations of this file), outside every timed region.
+    os.environ.setdefault("JAXSIM_AMD_SPECIALIZE", "1")
     # The contract is ONE JSON line on stdout.  Native libraries (RCCL prints "Librccl path : ..." through
     # C stdio, flushed at exit) share fd 1: keep a private handle for the result line and point fd 1 at
     # stderr for everything else.
@@ -513,6 +547,36 @@ def main():
         steady = {"launches": 2000, "us_per_step": us_ss, "env_steps_per_s_rank0": n_local / (us_ss * 1e-6),
                   "note": "same kernel and launch path (hipGraph replays of single-step launches), HIP events over 2000 launches; secondary figure"}
 
+    # secondary figure: the generic kernel of the library (model flags read at run time) on the same workload
+    generic = None
+    from jaxsim_amd import specialize
+
+    spec_modes = specialize.modes(dm)
+    if rank == 0 and spec_modes:
+        try:
+            saved = os.environ.get("JAXSIM_AMD_SPECIALIZE")
+            os.environ["JAXSIM_AMD_SPECIALIZE"] = "0"
+            try:
+                gmodel = build_model(args.model)
+                gdata = synthetic_state(gmodel, n_local, seed=rank, dtype=dtype)
+                gdm = runtime.device_model(gmodel, dtype)
+            finally:
+                os.environ["JAXSIM_AMD_SPECIALIZE"] = saved if saved is not None else "1"
+            gp = C.c_void_p(gdata._state.ptr)
+            _lib.check(lib.jxs_step_repeat(gdm.handle, gp, None, None, 2, n_local, 2000, stream.handle), "jxs_step_repeat")
+            stream.synchronize()
+            eg0, eg1 = runtime.Event(), runtime.Event()
+            eg0.record(stream)
+            _lib.check(lib.jxs_step_repeat(gdm.handle, gp, None, None, 2, n_local, 2000, stream.handle), "jxs_step_repeat")
+            eg1.record(stream)
+            stream.synchronize()
+            us_g = eg0.elapsed_ms(eg1) / 2000 * 1e3
+            generic = {"launches": 2000, "us_per_step": us_g, "env_steps_per_s_rank0": n_local / (us_g * 1e-6),
+                       "note": "libjaxsim_amd.so's generic kernel (JAXSIM_AMD_SPECIALIZE=0), same launch path, HIP events over 2000 launches; secondary figure"}
+            del gdata, gdm
+        except Exception as e:  # secondary: never lose the headline for it
+            generic = {"error": repr(e)}
+
     # secondary figure: the same K steps as ONE fused jxs_rollout launch (state in registers
     # between steps; what jax.lax.fori_loop over step is to the reference).  Not the headline.
     k_roll = max(args.steps, 200)
@@ -604,6 +668,9 @@ def main():
                 "global_batch": n_total,
                 "lanes_per_env": int(lay.group),
                 "aba_layout": "row-distributed (8 lanes per active link)" if lay.row_mode else "link per lane",
+                "kernel_variant": ("model-specialised: the step kernel compiled with this model's integer flags (tree shape, level masks, feature switches) as "
+                                   "constants, as jax.jit does for the reference; physical parameters are run-time data; `generic_kernel` is the library's run-time-flag kernel"
+                                   if spec_modes else "generic (model flags read at run time)"),
                 "parallelism": f"batch-sharded x{world}, no per-step communication",
             },
             "timing": {
@@ -621,7 +688,8 @@ def main():
                 "traffic": traffic,
                 "traffic_source": traffic_note,
                 "algorithmic_bytes_per_env_step": alg_bytes_per_env,
-                "kernel": f"jxs_kernel<{tname},{lay.group},MODE_STEP>",
+                "kernel": (f"jxs_launch_spec::jxs_kernel<{tname},{lay.group},MODE_STEP> (model-specialised build of the step kernel, jaxsim_amd/specialize.py)"
+                           if spec_modes else f"jxs_kernel<{tname},{lay.group},MODE_STEP>"),
                 "kernel_avg_launch_us": kernel_ms * 1e3,
                 "fp32_flop_model_per_env_step": FLOPS_PER_ENV_STEP,
                 "fp32_frac_of_vector_peak": FLOPS_PER_ENV_STEP * n_local / (kernel_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
@@ -631,6 +699,7 @@ def main():
             "allgather_error": allgather_error,
             "comm": None if comm is None else {"kind": type(comm).__name__, "ranks": comm_ranks, "error": comm_error},
             "steady_state": steady,
+            "generic_kernel": generic,
             "fused_rollout": {"us_per_step": rollout_ms_per_step * 1e3, "env_steps_per_s_rank0": n_local / (rollout_ms_per_step * 1e-3),
                               "note": "same steps as one jxs_rollout launch; secondary figure, not `value`"},
         }

@@ -144,6 +144,26 @@ int jxs_model_create(const jxs_model_desc* desc, jxs_model** out);
 int jxs_model_destroy(jxs_model* model);
 int jxs_model_layout(const jxs_model* model, jxs_layout* out);
 
+/* ---- model-specialised kernels ----------------------------------------------------------
+ * The reference compiles `step` per model: the kinematic tree (parent array, joint types, ...) is static
+ * under jax.jit (src/jaxsim/api/model.py:36-120, `static_field`s of KinDynParameters) and XLA folds it into
+ * the program.  The generic kernels of this library read the same facts as wave-uniform flags at run time
+ * and branch on them, which costs a lone wave ~20 % of the step.  A specialised
+ * kernel is the SAME hand-written kernel source compiled with those integer flags as constants
+ * (jaxsim_amd/csrc/jxs_spec.hip, built by jaxsim_amd/specialize.py with hipcc); physical parameters
+ * (masses, gains, time step, contact parameters) stay run-time data.
+ *
+ * jxs_kernel_spec: the canonical description of the flags a kernel of `mode` (JXS_MODE_* below) would be
+ *   specialised on, as text "T=float;G=32;MODE=0;P.n_chunks=1,P.seg_steps=4,...".  Host-only (no device
+ *   needed).  Returns the length written (excluding the terminator) or a negative error code.
+ * jxs_model_attach_specialized: loads a shared object built for exactly that description (checked) and
+ *   routes the launches of `mode` for this model through it.  Cached launch graphs are dropped.     */
+enum { JXS_MODE_STEP = 0, JXS_MODE_STEP_RIGID = 6 };
+int jxs_kernel_spec(const jxs_model_desc* desc, int mode, char* buf, int capacity);
+int jxs_model_attach_specialized(jxs_model* model, int mode, const char* shared_object_path);
+/* bit `mode` set: launches of that mode use a specialised kernel */
+int jxs_model_specialized_modes(const jxs_model* model, unsigned* mask);
+
 /* ---- hot path ------------------------------------------------------------------------- */
 
 /* js.model.step (src/jaxsim/api/model.py:2601-2681): actuation model -> soft contacts ->

@@ -204,6 +204,9 @@ def _declare(lib):
         "jxs_event_record": [vp, vp],
         "jxs_event_elapsed_ms": [vp, vp, C.POINTER(C.c_float)],
         "jxs_model_create": [C.POINTER(ModelDesc), C.POINTER(vp)],
+        "jxs_kernel_spec": [C.POINTER(ModelDesc), C.c_int, C.c_char_p, C.c_int],
+        "jxs_model_attach_specialized": [vp, C.c_int, C.c_char_p],
+        "jxs_model_specialized_modes": [vp, C.POINTER(C.c_uint)],
         "jxs_model_destroy": [vp],
         "jxs_model_layout": [vp, C.POINTER(Layout)],
         "jxs_step": [vp, vp, vp, vp, vp, C.c_int, C.c_int, vp],

@@ -116,6 +116,16 @@ def reduce(model: JaxSimModel, considered_joints, locked_joint_positions: dict |
     )
 
 
+def specialize(model: JaxSimModel, dtype=np.float32) -> bool:
+    """Build (hipcc, seconds) and attach the step kernel specialised on this model's kinematic tree -- the
+    counterpart of the reference compiling ``step`` per model under ``jax.jit`` (api/model.py:36-120 static
+    fields).  Physical parameters stay run-time data.  Returns False where no specialised build exists
+    (Runge-Kutta integrators); ``JAXSIM_AMD_SPECIALIZE=1`` does the same for every model on first use."""
+    from .. import specialize as _sp
+
+    return _sp.attach(runtime.device_model(model, np.dtype(dtype)), model, build=True)
+
+
 def step(
     model: JaxSimModel,
     data: JaxSimModelData,

@@ -69,9 +69,15 @@ template <typename T>
 struct ModelT {
   jxs::Packed<T> pk;
   unsigned char* mblk = nullptr;
+  // model-specialised kernels (jxs_model_attach_specialized): launch entry per mode, null = generic kernel
+  using SpecLaunch = int (*)(const void*, const unsigned char*, const void*, void*);
+  SpecLaunch spec_launch[16] = {};
+  void* spec_handle[16] = {};
   int* faults = nullptr;  // [2] discarded contact-force / impact solves since the last reset (rigid contact models)
 
   ~ModelT() {
+    for (void* h : spec_handle)
+      if (h != nullptr) dlclose(h);
     (void)hipFree(mblk);
     (void)hipFree(faults);
   }
@@ -161,7 +167,9 @@ int run_typed(jxs_model* model, int mode, const void* state_in, void* state_out,
     mode = jxs::MODE_ROLLOUT;
   }
   for (int it = 0; it < repeat; ++it) {
-    hipError_t e = launch_mode<T>(mode, mt->pk.G, mt->pk.P, mt->mblk, a, s);
+    hipError_t e = (mode >= 0 && mode < 16 && mt->spec_launch[mode] != nullptr)
+                       ? static_cast<hipError_t>(mt->spec_launch[mode](&mt->pk.P, mt->mblk, &a, s))
+                       : launch_mode<T>(mode, mt->pk.G, mt->pk.P, mt->mblk, a, s);
     if (e != hipSuccess) return hip_fail(e, "kernel launch");
     if (it == 0 && repeat > 1) a.state_in = a.state_out;  // unfused rollout continues from its own output
   }
@@ -253,6 +261,32 @@ __global__ void jxs_retile_kernel(const T* src, T* dst, int rows, int N, int til
   if (TO_TILED) dst[tiled] = src[i];
   else dst[i] = src[tiled];
 }
+
+namespace {
+template <typename T>
+int attach_typed(jxs_model* model, ModelT<T>* mt, int mode, const char* path) {
+  const std::string want = jxs::kernel_spec_string(mt->pk, mode);
+  void* h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+  if (h == nullptr) return fail(JXS_EINVAL, std::string("cannot load the specialised kernel: ") + dlerror());
+  auto text = reinterpret_cast<const char* (*)()>(dlsym(h, "jxs_spec_string"));
+  auto launch = reinterpret_cast<typename ModelT<T>::SpecLaunch>(dlsym(h, "jxs_spec_launch"));
+  if (text == nullptr || launch == nullptr) {
+    dlclose(h);
+    return fail(JXS_EINVAL, "not a specialised-kernel object (jxs_spec_string / jxs_spec_launch missing)");
+  }
+  if (want != text()) {
+    const std::string got = text();
+    dlclose(h);
+    return fail(JXS_EINVAL, "the specialised kernel was built for another model: " + got + " != " + want);
+  }
+  if (mt->spec_handle[mode] != nullptr) dlclose(mt->spec_handle[mode]);
+  mt->spec_handle[mode] = h;
+  mt->spec_launch[mode] = launch;
+  static std::atomic<unsigned long long> next_uid{1ull << 40};
+  model->uid = next_uid.fetch_add(1);  // launch graphs captured with the generic kernel are not found again
+  return JXS_OK;
+}
+}  // namespace
 
 extern "C" {
 
@@ -373,6 +407,42 @@ int jxs_model_create(const jxs_model_desc* desc, jxs_model** out) {
   *out = m.release();
   return JXS_OK;
 }
+int jxs_kernel_spec(const jxs_model_desc* desc, int mode, char* buf, int capacity) {
+  if (desc == nullptr || buf == nullptr || capacity <= 0) return fail(JXS_EINVAL, "null argument");
+  if (desc->dtype != JXS_F32 && desc->dtype != JXS_F64) return fail(JXS_EINVAL, "dtype must be JXS_F32 or JXS_F64");
+  std::string text, err;
+  if (desc->dtype == JXS_F64) {
+    jxs::Packed<double> pk;
+    err = jxs::pack_model<double>(*desc, pk);
+    if (err.empty()) text = jxs::kernel_spec_string(pk, mode);
+  } else {
+    jxs::Packed<float> pk;
+    err = jxs::pack_model<float>(*desc, pk);
+    if (err.empty()) text = jxs::kernel_spec_string(pk, mode);
+  }
+  if (!err.empty()) return fail(JXS_EINVAL, err);
+  if ((int)text.size() + 1 > capacity) return fail(JXS_EINVAL, "buffer too small for the kernel description");
+  std::memcpy(buf, text.c_str(), text.size() + 1);
+  return (int)text.size();
+}
+
+int jxs_model_attach_specialized(jxs_model* model, int mode, const char* path) {
+  if (model == nullptr || path == nullptr) return fail(JXS_EINVAL, "null argument");
+  if (mode < 0 || mode >= 16) return fail(JXS_EINVAL, "invalid mode");
+  return model->dtype == JXS_F64 ? attach_typed<double>(model, model->f64.get(), mode, path)
+                                 : attach_typed<float>(model, model->f32.get(), mode, path);
+}
+int jxs_model_specialized_modes(const jxs_model* model, unsigned* mask) {
+  if (model == nullptr || mask == nullptr) return fail(JXS_EINVAL, "null argument");
+  unsigned m = 0;
+  for (int k = 0; k < 16; ++k) {
+    const bool on = model->dtype == JXS_F64 ? model->f64->spec_launch[k] != nullptr : model->f32->spec_launch[k] != nullptr;
+    if (on) m |= 1u << k;
+  }
+  *mask = m;
+  return JXS_OK;
+}
+
 int jxs_model_destroy(jxs_model* model) {
   delete model;
   return JXS_OK;

@@ -56,6 +56,10 @@ __global__ __launch_bounds__(64, OCC2 ? 2 : 1) void jxs_kernel(const T* pre_stat
   P.n_rows = pre_n_rows, P.n = pre_n;
   P.row_pos = 0, P.row_quat = 3, P.row_s = 7, P.row_vlin = 7 + pre_n, P.row_vang = 10 + pre_n, P.row_sd = 13 + pre_n;
   P.row_m = 13 + 2 * pre_n;
+#ifdef JXS_SPEC_ASSIGN
+  // model-specialised build (jxs_spec.hip): the integer model flags are compile-time constants from here on
+  JXS_SPEC_ASSIGN;
+#endif
   extern __shared__ __align__(16) unsigned char jxs_smem[];
   const jxs::DeviceLanes<T, G> ln(A.N, reinterpret_cast<T*>(jxs_smem),
                                   (MODE == jxs::MODE_STEP_RIGID || MODE == jxs::MODE_STEP_RK4_RIGID) ? jxs::rigid_lds_words_per_env(P.n_cp, P.rigid)

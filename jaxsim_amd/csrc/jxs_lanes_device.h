@@ -340,6 +340,10 @@ struct DeviceLanes {
     return __hiloint2double(hi, lo);
   }
   // keep a wave-uniform kernel-argument value in an SGPR from here on
+#ifdef JXS_SPEC_ASSIGN  // (constants must stay visible to the optimiser)
+  static __device__ __forceinline__ unsigned pin(unsigned x) { return x; }
+  static __device__ __forceinline__ int pin(int x) { return x; }
+#else
   static __device__ __forceinline__ unsigned pin(unsigned x) {
     asm volatile("" : "+s"(x));
     return x;
@@ -348,6 +352,7 @@ struct DeviceLanes {
     asm volatile("" : "+s"(x));
     return x;
   }
+#endif
   // a value that is the same in every lane by construction, handed to the compiler as a scalar (loops
   // over it become SALU loops instead of exec-masked ones)
   static __device__ __forceinline__ unsigned uniform(unsigned x) { return (unsigned)__builtin_amdgcn_readfirstlane((int)x); }

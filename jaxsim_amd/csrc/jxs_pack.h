@@ -4,6 +4,7 @@
 #pragma once
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
@@ -39,6 +40,34 @@ struct Packed {
   int n_disabled = 0;
   int integrator = 0;  // JXS_INTEGRATOR_*
 };
+
+// Canonical text of the wave-uniform integer flags the kernels of `mode` branch on (include/jaxsim_amd.h,
+// "model-specialised kernels"): "T=..;G=..;MODE=..;" followed by a comma-separated list of assignments
+// that jxs_kernels.h applies to its copy of KParams when it is compiled with -DJXS_SPEC_ASSIGN=<list>.
+template <typename T>
+std::string kernel_spec_string(const Packed<T>& pk, int mode) {
+  const KParams<T>& P = pk.P;
+  std::string s = std::string("T=") + (sizeof(T) == 8 ? "double" : "float") + ";G=" + std::to_string(pk.G) + ";MODE=" + std::to_string(mode) + ";";
+  auto add = [&](const char* name, unsigned long long v, bool hex = false) {
+    char b[96];
+    std::snprintf(b, sizeof b, hex ? "P.%s=0x%llxull," : "P.%s=%llu,", name, v);
+    s += b;
+  };
+  add("nL", P.nL), add("n", P.n), add("n_points", P.n_points), add("n_slots", P.n_slots), add("n_chunks", P.n_chunks);
+  add("seg_steps", P.seg_steps), add("n_rounds", P.n_rounds), add("max_depth", P.max_depth), add("floating", P.floating);
+  add("any_suc", P.any_suc), add("seg_dpp_ok", P.seg_dpp_ok), add("row_mode", P.row_mode);
+  add("row_cross_levels", P.row_cross_levels, true), add("row_ppull_levels", P.row_ppull_levels, true);
+  add("row_pull_counts", P.row_pull_counts, true), add("nonadj_levels", P.nonadj_levels, true);
+  for (int k = 0; k < (int)(sizeof(P.maxch_nib) / sizeof(P.maxch_nib[0])); ++k) {
+    char nm[32];
+    std::snprintf(nm, sizeof nm, "maxch_nib[%d]", k);
+    add(nm, P.maxch_nib[k], true);
+  }
+  add("flat", P.flat), add("enable_friction", P.enable_friction), add("pq_half", P.pq_half), add("anchored", P.anchored);
+  add("rigid", P.rigid), add("n_cp", P.n_cp), add("rg_merge", P.rg_merge), add("rr_refine", P.rr_refine), add("rk4fast", P.rk4fast);
+  s.pop_back();
+  return s;
+}
 
 inline int pow2ceil(int x) {
   int p = 1;
@@ -454,6 +483,11 @@ std::string pack_model(const jxs_model_desc& d, Packed<T>& out) {
   while ((1 << seg_steps) < max_seg) ++seg_steps;
   P.seg_steps = seg_steps;
   P.seg_dpp_ok = seg_dpp;
+  if (std::getenv("JXS_PRINT_PARAMS") != nullptr)  // developer aid: the wave-uniform flags the kernels branch on
+    std::fprintf(stderr, "jxs params: G=%d nL=%d n=%d n_chunks=%d seg_steps=%d n_rounds=%d max_depth=%d floating=%d any_suc=%d row_mode=%d "
+                 "cross=0x%x ppull=0x%x pulls=0x%x seg_dpp_ok=%d flat=%d friction=%d anchored=%d nonadj=0x%llx pq_half=%d\n",
+                 G, P.nL, P.n, P.n_chunks, P.seg_steps, P.n_rounds, P.max_depth, P.floating, P.any_suc, P.row_mode, P.row_cross_levels,
+                 P.row_ppull_levels, P.row_pull_counts, P.seg_dpp_ok, P.flat, P.enable_friction, P.anchored, P.nonadj_levels, P.pq_half);
   return std::string();
 }
 

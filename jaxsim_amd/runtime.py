@@ -275,5 +275,15 @@ def device_model(model, dtype) -> DeviceModel:
     if hit is not None and hit[0] == sig:
         return hit[1]
     dm = DeviceModel(model, dtype)
+    from . import specialize  # model-specialised step kernel: a cached object, or built now if asked for
+
+    how = specialize.policy()
+    if how != "off":
+        try:
+            specialize.attach(dm, model, build=(how == "build"))
+        except (RuntimeError, OSError) as exc:  # no hipcc / failed build: the generic kernel of the library runs
+            import warnings
+
+            warnings.warn(f"jaxsim_amd: no model-specialised kernel ({exc}); using the generic one", RuntimeWarning, stacklevel=2)
     cache[np.dtype(dtype).str] = (sig, dm)
     return dm

@@ -1,0 +1,123 @@
+"""Model-specialised kernels (include/jaxsim_amd.h, section "model-specialised kernels").
+
+The reference compiles ``js.model.step`` per model: the kinematic tree is static under ``jax.jit``
+(src/jaxsim/api/model.py:36-120) and XLA folds it into the program.  The generic kernels of
+``libjaxsim_amd.so`` read the same facts as wave-uniform flags at run time; here the SAME hand-written kernel
+source (jaxsim_amd/csrc/jxs_spec.hip -> jxs_kernels.h -> jxs_core.h) is compiled once per
+(dtype, lanes per environment, mode, integer model flags) with those flags as constants.  Physical parameters
+stay run-time data: changing masses, gains, the time step or the contact parameters never needs a rebuild.
+
+* ``spec(model, dtype, mode)``      canonical description (text) of what a kernel would be specialised on;
+* ``cached(...)`` / ``compile(...)``  the shared object in ``jaxsim_amd/csrc/spec_cache`` (file name = hash of
+  the description, the kernel sources and the compiler flags), built with hipcc (gfx950; ~20 s);
+* ``attach(device_model, model)``   route the launches of the mode through it (checked by the library).
+
+``runtime.device_model`` attaches a cached object when there is one; it compiles one only when asked to:
+``JAXSIM_AMD_SPECIALIZE=1`` in the environment or ``js.model.specialize(model)``.  ``JAXSIM_AMD_SPECIALIZE=0``
+disables the lookup.  ``__graft_entry__.build()`` pre-builds the objects of the benchmark configurations.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import hashlib
+import os
+import pathlib
+import subprocess
+
+import numpy as np
+
+from . import _lib
+
+MODE_STEP = 0
+MODE_STEP_RIGID = 6
+_CSRC = pathlib.Path(__file__).resolve().parent / "csrc"
+CACHE = _CSRC / "spec_cache"
+_HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-fno-slp-vectorize",
+          "-mllvm", "-amdgpu-kernarg-preload-count=16", "-Wno-cuda-compat", "-Wno-pass-failed", "-Djxs_launch=jxs_launch_spec"]  # fmt: skip
+
+
+def source_sha() -> str:
+    """Hash of the kernel sources a specialised object is compiled from."""
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(_CSRC)):
+        if name.endswith((".h", ".inc")) or name == "jxs_spec.hip":
+            h.update(name.encode() + b"\0" + (_CSRC / name).read_bytes())
+    h.update((pathlib.Path(__file__).resolve().parent.parent / "include" / "jaxsim_amd.h").read_bytes())
+    return h.hexdigest()[:16]
+
+
+def mode_of(model) -> int | None:
+    """The kernel mode ``js.model.step`` launches for this model, None where no specialised build exists
+    (Runge-Kutta integrators)."""
+    desc, _keep = _lib.make_desc(model, np.float32)
+    if desc.integrator != 0:
+        return None
+    enabled = desc.n_points > 0 and any(desc.point_enabled[k] for k in range(desc.n_points))
+    return MODE_STEP_RIGID if desc.contact_model != 0 and enabled else MODE_STEP
+
+
+def spec(model, dtype, mode: int = MODE_STEP) -> str:
+    lib = _lib.load()
+    desc, _keep = _lib.make_desc(model, dtype)
+    buf = C.create_string_buffer(4096)
+    n = lib.jxs_kernel_spec(C.byref(desc), mode, buf, len(buf))
+    if n < 0:
+        _lib.check(n, "jxs_kernel_spec")
+    return buf.value.decode()
+
+
+def path_of(text: str) -> pathlib.Path:
+    key = hashlib.sha256((text + "|" + source_sha() + "|" + " ".join(_FLAGS)).encode()).hexdigest()[:20]
+    return CACHE / f"libjxs_spec_{key}.so"
+
+
+def cached(model, dtype, mode: int = MODE_STEP) -> pathlib.Path | None:
+    p = path_of(spec(model, dtype, mode))
+    return p if p.exists() else None
+
+
+def compile(model, dtype, mode: int = MODE_STEP, *, force: bool = False) -> pathlib.Path:  # noqa: A001
+    """Build (or find) the specialised kernel object; needs hipcc, not a GPU."""
+    text = spec(model, dtype, mode)
+    out = path_of(text)
+    if out.exists() and not force:
+        return out
+    head, assign = text.rsplit(";", 1)
+    fields = dict(kv.split("=") for kv in head.split(";"))
+    CACHE.mkdir(exist_ok=True)
+    tmp = out.with_suffix(f".tmp{os.getpid()}.so")
+    cmd = [_HIPCC, *_FLAGS, f"-DJXS_SPEC_T={fields['T']}", f"-DJXS_SPEC_G={fields['G']}", f"-DJXS_SPEC_MODE={fields['MODE']}",
+           f"-DJXS_SPEC_ASSIGN={assign}", f'-DJXS_SPEC_STRING="{text}"', "jxs_spec.hip", "-o", str(tmp)]  # fmt: skip
+    r = subprocess.run(cmd, cwd=_CSRC, capture_output=True, text=True)
+    if r.returncode != 0:
+        tmp.unlink(missing_ok=True)
+        raise RuntimeError(f"hipcc failed for the specialised kernel ({text}):\n{r.stderr[-4000:]}")
+    os.replace(tmp, out)  # atomic: concurrent ranks may build the same object
+    return out
+
+
+def attach(dm, model, mode: int | None = None, *, build: bool = False) -> bool:
+    """Attach the specialised kernel of ``mode`` to the device model ``dm``; False if there is none."""
+    mode = mode_of(model) if mode is None else mode
+    if mode is None:
+        return False
+    p = compile(model, dm.dtype, mode) if build else cached(model, dm.dtype, mode)
+    if p is None:
+        return False
+    lib = _lib.load()
+    _lib.check(lib.jxs_model_attach_specialized(dm.handle, mode, str(p).encode()), "jxs_model_attach_specialized")
+    return True
+
+
+def modes(dm) -> list[int]:
+    """Modes of the device model that run a specialised kernel."""
+    mask = C.c_uint()
+    _lib.check(_lib.load().jxs_model_specialized_modes(dm.handle, C.byref(mask)), "jxs_model_specialized_modes")
+    return [k for k in range(16) if mask.value >> k & 1]
+
+
+def policy() -> str:
+    """'off' (never), 'cached' (default: use an object that exists), 'build' (compile on first use)."""
+    v = os.environ.get("JAXSIM_AMD_SPECIALIZE", "")
+    return "off" if v == "0" else "build" if v == "1" else "cached"

@@ -1,0 +1,113 @@
+"""Model-specialised kernels (jaxsim_amd/specialize.py): description, cache, build, and on the GPU the
+specialised kernel against the generic one of the same library."""
+import ctypes as C
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+import helpers
+import jaxsim_amd.api as js
+from jaxsim_amd import _lib, runtime, specialize
+
+HIPCC = shutil.which("hipcc") or ("/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else None)
+
+
+@pytest.fixture(scope="module")
+def models():
+    return helpers.ModelZoo()
+
+
+def test_description_names_topology_not_physics(models):
+    m = models("icub")
+    a = specialize.spec(m, np.float32)
+    assert a.startswith("T=float;G=32;MODE=0;") and "P.floating=1" in a and "P.row_mode=1" in a
+    # physical parameters are run-time data: another time step / contact stiffness / mass is the same kernel
+    b = specialize.spec(helpers.with_params(m, K=2.0 * float(m.contact_params.K)), np.float32)
+    assert a == b
+    assert specialize.spec(m, np.float64).startswith("T=double;")
+    # another tree is another kernel
+    assert specialize.spec(models("anymal"), np.float32) != a
+    assert specialize.path_of(a) != specialize.path_of(specialize.spec(m, np.float64))
+
+
+def test_mode_follows_the_contact_model_and_integrator(models):
+    assert specialize.mode_of(models("icub")) == specialize.MODE_STEP
+    rigid = helpers.rigid_model(models("anymal"), helpers.ANYMAL_FEET_4)
+    assert specialize.mode_of(rigid) == specialize.MODE_STEP_RIGID
+    assert specialize.spec(rigid, np.float32, specialize.MODE_STEP_RIGID).count("P.rg_merge=1") == 1
+
+
+@pytest.mark.skipif(HIPCC is None, reason="hipcc not installed")
+def test_build_produces_the_two_entry_points(models, tmp_path, monkeypatch):
+    monkeypatch.setattr(specialize, "CACHE", tmp_path)
+    m = models("cartpole")
+    assert specialize.cached(m, np.float32) is None
+    so = specialize.compile(m, np.float32)
+    assert so.parent == tmp_path and specialize.cached(m, np.float32) == so
+    lib = C.CDLL(str(so))
+    lib.jxs_spec_string.restype = C.c_char_p
+    assert lib.jxs_spec_string().decode() == specialize.spec(m, np.float32)
+    assert hasattr(lib, "jxs_spec_launch")
+    # the kernel lives in its own namespace: the generic instantiation of libjaxsim_amd.so (same template
+    # arguments) is another symbol and cannot be bound across the two objects
+    import subprocess
+
+    syms = subprocess.run(["nm", "-D", "--defined-only", str(so)], capture_output=True, text=True).stdout
+    assert "jxs_launch_spec" in syms and "_ZN10jxs_launch10jxs_kernel" not in syms
+
+
+def _step_n(model, data, n):
+    for _ in range(n):
+        data = js.model.step(model, data)
+    return data.state_block()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,dtype", [("icub", np.float32), ("icub", np.float64), ("anymal", np.float32), ("cartpole", np.float32),
+                                        ("double_pendulum", np.float64)])  # fmt: skip
+def test_specialised_step_equals_the_generic_kernel(models, name, dtype, monkeypatch):
+    model = models(name)
+    d = models.random_data(name, 37, seed=3, dtype=dtype)
+    block = helpers.odata_to_block(model, d)
+    monkeypatch.setenv("JAXSIM_AMD_SPECIALIZE", "0")
+    model.__dict__.pop("_device", None)
+    ref = _step_n(model, js.data.JaxSimModelData.from_state_block(model, block, 2), 3)
+    assert specialize.modes(runtime.device_model(model, dtype)) == []
+    monkeypatch.setenv("JAXSIM_AMD_SPECIALIZE", "1")
+    model.__dict__.pop("_device", None)
+    out = _step_n(model, js.data.JaxSimModelData.from_state_block(model, block, 2), 3)
+    assert specialize.modes(runtime.device_model(model, dtype)) == [specialize.MODE_STEP]
+    model.__dict__.pop("_device", None)
+    # the same arithmetic with the branches folded: identical up to the contraction choices of the compiler
+    tol = 1e-12 if dtype == np.float64 else 2e-5
+    assert helpers.rel_err(out, ref) < tol
+
+
+@pytest.mark.gpu
+def test_specialised_rigid_step_equals_the_generic_kernel(models, monkeypatch):
+    model = helpers.rigid_model(models("anymal"), helpers.ANYMAL_FEET_4)
+    d = helpers.standing_data(model, 24, seed=1, dtype=np.float64)
+    block = helpers.odata_to_block(model, d)
+    monkeypatch.setenv("JAXSIM_AMD_SPECIALIZE", "0")
+    model.__dict__.pop("_device", None)
+    ref = _step_n(model, js.data.JaxSimModelData.from_state_block(model, block, 2), 2)
+    monkeypatch.setenv("JAXSIM_AMD_SPECIALIZE", "1")
+    model.__dict__.pop("_device", None)
+    out = _step_n(model, js.data.JaxSimModelData.from_state_block(model, block, 2), 2)
+    assert specialize.modes(runtime.device_model(model, np.float64)) == [specialize.MODE_STEP_RIGID]
+    model.__dict__.pop("_device", None)
+    assert helpers.rel_err(out, ref) < 1e-9
+
+
+@pytest.mark.gpu
+def test_attach_refuses_a_kernel_built_for_another_model(models, monkeypatch):
+    monkeypatch.setenv("JAXSIM_AMD_SPECIALIZE", "0")
+    icub, anymal = models("icub"), models("anymal")
+    so = specialize.compile(anymal, np.float32)
+    icub.__dict__.pop("_device", None)
+    dm = runtime.device_model(icub, np.float32)
+    rc = _lib.load().jxs_model_attach_specialized(dm.handle, specialize.MODE_STEP, str(so).encode())
+    assert rc != 0 and specialize.modes(dm) == []
+    icub.__dict__.pop("_device", None)
