@@ -47,14 +47,22 @@ def source_sha() -> str:
     return h.hexdigest()[:16]
 
 
-def mode_of(model) -> int | None:
-    """The kernel mode ``js.model.step`` launches for this model, None where no specialised build exists
-    (Runge-Kutta integrators)."""
+MODE_ROLLOUT, MODE_STEP_RK4, MODE_STEP_RK4_RIGID = 4, 5, 7
+
+
+def modes_of(model) -> list[int]:
+    """The kernel modes ``js.model.step`` / ``js.model.rollout`` launch for this model (csrc/jxs_params.h Mode)."""
     desc, _keep = _lib.make_desc(model, np.float32)
-    if desc.integrator != 0:
-        return None
     enabled = desc.n_points > 0 and any(desc.point_enabled[k] for k in range(desc.n_points))
-    return MODE_STEP_RIGID if desc.contact_model != 0 and enabled else MODE_STEP
+    rigid = desc.contact_model != 0 and enabled
+    if desc.integrator != 0:  # Runge-Kutta: one launch per step, four dynamics evaluations inside
+        return [MODE_STEP_RK4_RIGID if rigid else MODE_STEP_RK4]
+    return [MODE_STEP_RIGID] if rigid else [MODE_STEP, MODE_ROLLOUT]
+
+
+def mode_of(model) -> int:
+    """The mode of a single ``js.model.step``."""
+    return modes_of(model)[0]
 
 
 def spec(model, dtype, mode: int = MODE_STEP) -> str:
@@ -67,8 +75,12 @@ def spec(model, dtype, mode: int = MODE_STEP) -> str:
     return buf.value.decode()
 
 
+def _flags() -> list[str]:
+    return _FLAGS + os.environ.get("JAXSIM_AMD_SPEC_EXTRA_FLAGS", "").split()  # developer aid, e.g. -DJXS_PHASE_TIMING
+
+
 def path_of(text: str) -> pathlib.Path:
-    key = hashlib.sha256((text + "|" + source_sha() + "|" + " ".join(_FLAGS)).encode()).hexdigest()[:20]
+    key = hashlib.sha256((text + "|" + source_sha() + "|" + " ".join(_flags())).encode()).hexdigest()[:20]
     return CACHE / f"libjxs_spec_{key}.so"
 
 
@@ -87,7 +99,7 @@ def compile(model, dtype, mode: int = MODE_STEP, *, force: bool = False) -> path
     fields = dict(kv.split("=") for kv in head.split(";"))
     CACHE.mkdir(exist_ok=True)
     tmp = out.with_suffix(f".tmp{os.getpid()}.so")
-    cmd = [_HIPCC, *_FLAGS, f"-DJXS_SPEC_T={fields['T']}", f"-DJXS_SPEC_G={fields['G']}", f"-DJXS_SPEC_MODE={fields['MODE']}",
+    cmd = [_HIPCC, *_flags(), f"-DJXS_SPEC_T={fields['T']}", f"-DJXS_SPEC_G={fields['G']}", f"-DJXS_SPEC_MODE={fields['MODE']}",
            f"-DJXS_SPEC_ASSIGN={assign}", f'-DJXS_SPEC_STRING="{text}"', "jxs_spec.hip", "-o", str(tmp)]  # fmt: skip
     r = subprocess.run(cmd, cwd=_CSRC, capture_output=True, text=True)
     if r.returncode != 0:
@@ -98,16 +110,16 @@ def compile(model, dtype, mode: int = MODE_STEP, *, force: bool = False) -> path
 
 
 def attach(dm, model, mode: int | None = None, *, build: bool = False) -> bool:
-    """Attach the specialised kernel of ``mode`` to the device model ``dm``; False if there is none."""
-    mode = mode_of(model) if mode is None else mode
-    if mode is None:
-        return False
-    p = compile(model, dm.dtype, mode) if build else cached(model, dm.dtype, mode)
-    if p is None:
-        return False
+    """Attach the specialised kernels of the model (all modes of ``modes_of``, or one ``mode``) to the device
+    model ``dm``.  Without ``build`` only objects found in the cache are used.  True if any was attached."""
     lib = _lib.load()
-    _lib.check(lib.jxs_model_attach_specialized(dm.handle, mode, str(p).encode()), "jxs_model_attach_specialized")
-    return True
+    done = False
+    for m in modes_of(model) if mode is None else [mode]:
+        p = compile(model, dm.dtype, m) if build else cached(model, dm.dtype, m)
+        if p is not None:
+            _lib.check(lib.jxs_model_attach_specialized(dm.handle, m, str(p).encode()), "jxs_model_attach_specialized")
+            done = True
+    return done
 
 
 def modes(dm) -> list[int]:

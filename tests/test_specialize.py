@@ -34,8 +34,13 @@ def test_description_names_topology_not_physics(models):
 
 def test_mode_follows_the_contact_model_and_integrator(models):
     assert specialize.mode_of(models("icub")) == specialize.MODE_STEP
+    assert specialize.modes_of(models("icub")) == [specialize.MODE_STEP, specialize.MODE_ROLLOUT]
     rigid = helpers.rigid_model(models("anymal"), helpers.ANYMAL_FEET_4)
     assert specialize.mode_of(rigid) == specialize.MODE_STEP_RIGID
+    import jaxsim_amd as ja
+
+    rk4 = helpers.with_params(models("icub"), integrator=ja.IntegratorType.RungeKutta4)
+    assert specialize.modes_of(rk4) == [specialize.MODE_STEP_RK4]
     assert specialize.spec(rigid, np.float32, specialize.MODE_STEP_RIGID).count("P.rg_merge=1") == 1
 
 
@@ -78,7 +83,7 @@ def test_specialised_step_equals_the_generic_kernel(models, name, dtype, monkeyp
     monkeypatch.setenv("JAXSIM_AMD_SPECIALIZE", "1")
     model.__dict__.pop("_device", None)
     out = _step_n(model, js.data.JaxSimModelData.from_state_block(model, block, 2), 3)
-    assert specialize.modes(runtime.device_model(model, dtype)) == [specialize.MODE_STEP]
+    assert specialize.modes(runtime.device_model(model, dtype)) == [specialize.MODE_STEP, specialize.MODE_ROLLOUT]
     model.__dict__.pop("_device", None)
     # the same arithmetic with the branches folded: identical up to the contraction choices of the compiler
     tol = 1e-12 if dtype == np.float64 else 2e-5

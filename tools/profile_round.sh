@@ -19,12 +19,19 @@ rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/c5_relaxed" -- pyt
 cd "$R"
 python bench.py > "$OUT/bench_N1.json" 2> "$OUT/bench_N1.err"
 python bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/bench_steps20.json" 2> "$OUT/bench_steps20.err"
+# cycle stamps: the model-specialised kernels with -DJXS_PHASE_TIMING (built on first use, seconds), then the generic
+# kernels of a timing build of the library (cd jaxsim_amd/csrc && JXS_EXTRA_FLAGS=-DJXS_PHASE_TIMING JXS_OUT=libjaxsim_amd_timing.so bash build.sh)
+export JAXSIM_AMD_SPEC_EXTRA_FLAGS=-DJXS_PHASE_TIMING
+JAXSIM_AMD_SPECIALIZE=1 python tools/phase_timing.py > "$OUT/phases.log" 2>&1
+for a in "4 4096" "4 4096 rigid standing" "16 4096" "16 4096 relaxed standing" "32 1024 relaxed standing"; do
+  JAXSIM_AMD_SPECIALIZE=1 python tools/phase_timing_rigid.py $a >> "$OUT/phases_contact_models.log" 2>&1
+done
+unset JAXSIM_AMD_SPEC_EXTRA_FLAGS
 if [ -f jaxsim_amd/csrc/libjaxsim_amd_timing.so ]; then
-  JAXSIM_AMD_LIB=$R/jaxsim_amd/csrc/libjaxsim_amd_timing.so python tools/phase_timing.py > "$OUT/phases.log" 2>&1
-  for a in "4 4096" "16 4096" "16 4096 relaxed standing" "32 1024 relaxed standing"; do
-    JAXSIM_AMD_LIB=$R/jaxsim_amd/csrc/libjaxsim_amd_timing.so python tools/phase_timing_rigid.py $a >> "$OUT/phases_contact_models.log" 2>&1
-  done
+  JAXSIM_AMD_SPECIALIZE=0 JAXSIM_AMD_LIB=$R/jaxsim_amd/csrc/libjaxsim_amd_timing.so python tools/phase_timing.py > "$OUT/phases_generic.log" 2>&1
+  JAXSIM_AMD_SPECIALIZE=0 JAXSIM_AMD_LIB=$R/jaxsim_amd/csrc/libjaxsim_amd_timing.so python tools/phase_timing_rigid.py 4 4096 > "$OUT/phases_contact_models_generic.log" 2>&1
 fi
 python tools/fp32_error_gpu.py 512 > "$OUT/fp32_error_gpu.log" 2>&1
 python tools/experiments/env_per_lane.py > "$OUT/env_per_lane.log" 2>&1
+timeout 60 tools/ubench/issue_rate > "$OUT/issue_rate.log" 2>&1
 tail -c 600 "$OUT/bench_N1.json"
