@@ -21,25 +21,35 @@ if ks:
     for r in csv.DictReader(open(ks[0])):
         lines.append(f"| `{r['Name'][:90]}` | {r['Calls']} | {r['TotalDurationNs']} | {float(r['AverageNs']):.0f} | {float(r['Percentage']):.2f} |")
     lines.append("")
-summary = {}
+summary, generic, headline_kernel = {}, {}, "jxs_kernel<float,32,MODE_STEP>"
 for d in sorted(run.glob("pmc_*")):
     f = glob.glob(str(d / "*" / "*counter_collection.csv"))
     if not f:
         continue
-    agg = collections.defaultdict(list)
-    waves = None
-    for r in csv.DictReader(open(f[0])):
-        if "jxs_kernel<float, 32, 0," in r["Kernel_Name"]:  # the step kernel only (not the fused rollout / kinematics)
-            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
-            waves = int(r["Grid_Size"]) // 64
-    for k, v in agg.items():
-        summary[k] = {"mean_per_launch": sum(v) / len(v), "launches": len(v), "waves_per_launch": waves}
+    rows = list(csv.DictReader(open(f[0])))
+    # the step kernel only (not the fused rollout / kinematics): the model-specialised build that the headline runs
+    # (namespace jxs_launch_spec) when there is one, else the generic kernel of the library; the generic one separately
+    spec = any("jxs_launch_spec::jxs_kernel<float, 32, 0," in r["Kernel_Name"] for r in rows)
+    for name, dst in (("jxs_launch_spec::jxs_kernel<float, 32, 0," if spec else "jxs_launch::jxs_kernel<float, 32, 0,", summary),
+                      ("jxs_launch::jxs_kernel<float, 32, 0,", generic)):
+        agg = collections.defaultdict(list)
+        waves = None
+        for r in rows:
+            if name in r["Kernel_Name"]:
+                agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+                waves = int(r["Grid_Size"]) // 64
+        for k, v in agg.items():
+            dst[k] = {"mean_per_launch": sum(v) / len(v), "launches": len(v), "waves_per_launch": waves}
+    headline_kernel = "jxs_launch_spec::jxs_kernel<float,32,MODE_STEP> (model-specialised)" if spec else "jxs_launch::jxs_kernel<float,32,MODE_STEP>"
 if summary:
-    lines += ["## PMC counters of `jxs_kernel<float,32,MODE_STEP>` (separate `--pmc` passes, mean per launch)", "",
-              "| counter | mean per launch | per wave | launches |", "|---|---|---|---|"]
-    for k, v in summary.items():
-        lines.append(f"| {k} | {v['mean_per_launch']:.1f} | {v['mean_per_launch'] / v['waves_per_launch']:.1f} | {v['launches']} |")
-    lines.append("")
+    for title, tab in ((headline_kernel, summary), ("jxs_launch::jxs_kernel<float,32,MODE_STEP> (generic kernel, bench.py's `generic_kernel` secondary)", generic)):
+        if not tab or (tab is generic and "spec" not in headline_kernel):
+            continue
+        lines += [f"## PMC counters of `{title}` (separate `--pmc` passes, mean per launch)", "",
+                  "| counter | mean per launch | per wave | launches |", "|---|---|---|---|"]
+        for k, v in tab.items():
+            lines.append(f"| {k} | {v['mean_per_launch']:.1f} | {v['mean_per_launch'] / v['waves_per_launch']:.1f} | {v['launches']} |")
+        lines.append("")
     if "FETCH_SIZE" in summary and "WRITE_SIZE" in summary:
         fetch = summary["FETCH_SIZE"]["mean_per_launch"] * 1024
         write = summary["WRITE_SIZE"]["mean_per_launch"] * 1024
@@ -52,6 +62,20 @@ if summary:
 
     summary["config"] = {"model": "icub23", "envs": 1024, "dtype": "float32"}
     summary["kernel_source_sha"] = bench.kernel_source_sha()
+    summary["kernel"] = headline_kernel
     (out / f"{tag}_pmc.json").write_text(json.dumps(summary, indent=1))
 (out / f"{tag}_summary.md").write_text("\n".join(lines))
 print("\n".join(lines))
+
+# the other artefacts of tools/profile_round.sh, copied under the round's tag
+for src, dst in (("c5", "c5_kernel_stats.csv"), ("c5_relaxed", "c5_relaxed_kernel_stats.csv")):
+    ks = glob.glob(str(run / src / "*" / "*_kernel_stats.csv"))
+    if ks:
+        shutil.copy(ks[0], out / f"{tag}_{dst}")
+for src, dst in (("phases.log", "phase_cycles.txt"), ("phases_generic.log", "phase_cycles_generic_kernel.txt"),
+                 ("phases_contact_models.log", "phase_cycles_contact_models.txt"),
+                 ("phases_contact_models_generic.log", "phase_cycles_contact_models_generic_kernel.txt"),
+                 ("bench_N1.json", "bench_N1.json"), ("bench_steps20.json", "bench_steps20.json"),
+                 ("fp32_error_gpu.log", "fp32_error_gpu.txt"), ("issue_rate.log", "issue_rate_ubench.txt"), ("c5.log", "c5_bench.txt")):  # fmt: skip
+    if (run / src).exists():
+        shutil.copy(run / src, out / f"{tag}_{dst}")
