@@ -1143,11 +1143,10 @@ struct Core {
     V Mrow[6], S[6], c[6], pr, S_r, c_r, tau, dp[3];
   };
   JXS_HD void load_row_level(const VI& rec, const VI& row6, const VI& lane, RowLevel& o) const {
-    // no link in this slot at this level: the all-zero record; the two idle lanes of a slot read their
-    // row-specific values from it as well (the slot-uniform S, c, tau come from the link's record)
-    const VI zr = lane * 0 + lds_zero_rec(G);
-    const VI base = vsel(rec >= 0, rec, zr);
-    const VI brow = vsel((lane & 7) < 6, base, zr);
+    // `rec`: the link's record for its six row lanes; the all-zero record for lanes without a link at this
+    // level (empty slot, idle lanes 6 and 7 of a slot) -- resolved by the packer, no address selects here
+    (void)lane;
+    const VI base = rec, brow = rec;
     V rw[8], sc[12], td[4];
     ln.template lds_readv<8>(brow + row6 * 8, rw);
     ln.template lds_readv<12>(base + RL_S, sc);
@@ -1224,7 +1223,7 @@ struct Core {
       Ur[Lv] = zero, Sr[Lv] = zero, cr[Lv] = zero, invd[Lv] = zero, uu[Lv] = zero;
       if (Lv >= 1) load_row_level(rt.rec[Lv - 1], row6, lane, nxt);  // prefetch the next level
       if (Lv <= max_depth && (Lv >= 1 || floating)) {
-        const VM has = rt.rec[Lv] >= 0;
+        const VM has = rt.rec[Lv] != lds_zero_rec(G);
         V MArow[6];  // (lanes without a link, and the idle lanes 6, 7 of a slot, read the all-zero record)
         if (!L::add6_packed(cur.Mrow, accM, MArow)) {
 #pragma unroll
@@ -1356,7 +1355,7 @@ struct Core {
 #pragma unroll
     for (int Lv = 1; Lv < kRowLevels; ++Lv) {
       if (Lv <= max_depth) {
-        const VM has = rt.rec[Lv] >= 0;
+        const VM has = rt.rec[Lv] != lds_zero_rec(G);
         V apar = acar;
         if ((ppull_levels >> Lv) & 1u) {
           const VM pulled = rt.ppull[Lv] >= 0;
@@ -1380,7 +1379,7 @@ struct Core {
         const V sd = (uu[Lv] - tot) * invd[Lv];
         ai = ai + Sr[Lv] * sd;
         acar = vsel(has, ai, acar);
-        ln.lds_write(vsel(has, rt.rec[Lv], lane * 0) + RL_SDD, sd, has && (row == 0));
+        ln.lds_write(rt.rec[Lv] + RL_SDD, sd, has && (row == 0));
       }
     }
     sdd = ln.lds_read(rec_me + RL_SDD);

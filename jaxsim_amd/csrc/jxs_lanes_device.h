@@ -279,18 +279,17 @@ struct DeviceLanes {
   // instead of two); the leading s_nop covers the VALU-write -> DPP-read hazard the assembler cannot see.
   __device__ __forceinline__ void allreduce8x7(float* x) const {
 #define JXS_DPP7(CTRL)                                                                                       \
-  asm volatile("s_nop 1\n\t"                                                                                 \
-               "v_add_f32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                \
-               "v_add_f32_dpp %1, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                \
-               "v_add_f32_dpp %2, %2, %2 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                \
-               "v_add_f32_dpp %3, %3, %3 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                \
-               "v_add_f32_dpp %4, %4, %4 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                \
-               "v_add_f32_dpp %5, %5, %5 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                \
-               "v_add_f32_dpp %6, %6, %6 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1"                     \
-               : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]))
-    JXS_DPP7("quad_perm:[1,0,3,2]");
-    JXS_DPP7("quad_perm:[2,3,0,1]");
-    JXS_DPP7("row_half_mirror");
+  "v_add_f32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                           \
+  "v_add_f32_dpp %1, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                           \
+  "v_add_f32_dpp %2, %2, %2 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                           \
+  "v_add_f32_dpp %3, %3, %3 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                           \
+  "v_add_f32_dpp %4, %4, %4 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                           \
+  "v_add_f32_dpp %5, %5, %5 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                           \
+  "v_add_f32_dpp %6, %6, %6 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+    // one block: the stages follow each other without further wait states (a value is read six instructions
+    // after it was written); only the first DPP needs the s_nop behind the VALU that produced its source
+    asm volatile("s_nop 1\n\t" JXS_DPP7("quad_perm:[1,0,3,2]") JXS_DPP7("quad_perm:[2,3,0,1]") JXS_DPP7("row_half_mirror")
+                 : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]));
 #undef JXS_DPP7
   }
   __device__ __forceinline__ void allreduce8x7(double* x) const {

@@ -445,7 +445,7 @@ std::string pack_model(const jxs_model_desc& d, Packed<T>& out) {
         const int L = level[i], s2 = slot[i];
         for (int r = 0; r < 8; ++r) {
           const int lane = 8 * s2 + r;
-          RI(RT_REC + L, lane) = lane_of[i] * kRowRec;
+          if (r < 6) RI(RT_REC + L, lane) = lane_of[i] * kRowRec;  // (the two idle lanes of a slot: the zero record, below)
           if (i != 0) {
             const int pi = d.parent[i];
             if (children[pi][0] == i) {
@@ -464,6 +464,11 @@ std::string pack_model(const jxs_model_desc& d, Packed<T>& out) {
           }
         }
       }
+      // a row lane without a link at a level -- empty slot, or one of the two idle lanes of a slot -- reads the
+      // all-zero record: the table holds its offset, the kernel never selects an address
+      for (int lane = 0; lane < G; ++lane)
+        for (int L = 0; L < kRowLevels; ++L)
+          if (RI(RT_REC + L, lane) < 0) RI(RT_REC + L, lane) = lds_zero_rec(G);
       P.row_mode = 1;
     }
   }

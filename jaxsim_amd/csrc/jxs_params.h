@@ -94,7 +94,8 @@ constexpr int kRowLevels = 8;     // tree levels 0..7 (deeper trees use the link
 constexpr int kRowExtra = 3;      // extra (non-first) children per link handled by cross-slot pulls
 constexpr int kRowRec = 68;       // LDS words per link record (multiple of 16 bytes: 128-bit accesses)
 enum RowI : int {
-  RT_REC = 0,                         // [kRowLevels] LDS word offset of the record of link(L, slot), -1 if none
+  RT_REC = 0,                         // [kRowLevels] LDS word offset of the record this row lane reads at level L:
+                                      // link(L, slot)'s for its six row lanes, the all-zero record (lds_zero_rec) otherwise
   RT_FC = RT_REC + kRowLevels,        // bit L: link(L, slot) is the first child of link(L-1, slot)
   RT_PULL = RT_FC + 1,                // [kRowLevels][kRowExtra] lane to pull an extra child (level L) from, -1
   RT_PPULL = RT_PULL + kRowLevels * kRowExtra,  // [kRowLevels] lane holding the parent's row, -1 = same lane
