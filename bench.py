@@ -660,9 +660,9 @@ def main():
             "config": {
                 "workload": f"{args.model} synthetic floating-base humanoid, soft contacts (K={model.contact_params.K:.4g}, D={model.contact_params.D:.4g}, mu=0.5), "
                 f"semi-implicit Euler dt=1e-3, nL={lay.n_links} n={n} n_cp={n_cp}, "
-                f"{n_local} envs per GPU x {world} GPU(s) = {n_total} envs, one step kernel launch per step (jxs_step_repeat: hipGraph replays of 250 / 50 / remainder launches, captured during warm-up)",
+                f"{n_local} envs per GPU x {world} GPU(s) = {n_total} envs, one step kernel launch per step (jxs_step_repeat: hipGraph replays of blocks of 250 / 50 launches captured during warm-up, fewer than 50 launched plainly)",
                 "note_on_value": "`value` is the wall clock of the median timed region of exactly --steps launches, launch and "
-                "synchronisation latency of the region included (~20 us per region: 10 % at --steps 20, 0.1 % at 2000); "
+                "synchronisation latency of the region included (~11 us per region: 7 % at --steps 20, 0.1 % at 2000); "
                 "`steady_state` is the same launch path measured over >= 2000 launches",
                 "envs_per_gpu": n_local,
                 "global_batch": n_total,

@@ -175,8 +175,9 @@ int jxs_step(jxs_model* model, const void* state_in, void* state_out, const void
 
 /* `n_launches` back-to-back in-place jxs_step launches enqueued from one call (no fusion: one kernel
  * launch per step, exactly what a host loop over jxs_step enqueues, without the per-call cost of the
- * host language).  On a created stream blocks of 250 and of 50 launches, and the remainder (>= 2 launches),
- * are captured once into hipGraphs and replayed while the arguments stay the same.             */
+ * host language).  On a created stream blocks of 250 and of 50 launches are captured once into hipGraphs
+ * and replayed while the arguments stay the same; a remainder below 50 is launched plainly (faster to get
+ * going than a graph of that size: tools/region_overhead.py).                                   */
 int jxs_step_repeat(jxs_model* model, void* state, const void* tau, const void* link_forces,
                     int force_repr, int N, int n_launches, void* stream);
 

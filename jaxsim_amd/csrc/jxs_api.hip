@@ -550,12 +550,15 @@ int jxs_step_repeat(jxs_model* model, void* state, const void* tau, const void* 
       Key key{};
       hipGraphExec_t exec = nullptr;
     };
-    // slot 0: blocks of kLong launches, slot 1: blocks of kShort, slot 2: one graph of exactly the remainder
-    // (2 ... kShort-1 launches; re-captured when the remainder changes) -- a short request, e.g. a benchmark
-    // driver asking for 20 steps, replays a graph too instead of paying 20 plain launches
+    // slot 0: blocks of kLong launches, slot 1: blocks of kShort; the remainder (< kShort) is launched plainly.
+    // Measured with the 7.7 us kernel (tools/region_overhead.py, wall time of a region of n launches):
+    // graph of exactly n launches 17.1 us + 7.77 n, plain launches 11.0 us + 7.72 n -- a graph launch costs 6 us
+    // more to get going than the first of n plain launches, and the host loop in C keeps ahead of the device.
+    // (JXS_STEP_GRAPH_REMAINDER=1 brings the graph of exactly the remainder back: slot 2.)
+    static const bool graph_remainder = std::getenv("JXS_STEP_GRAPH_REMAINDER") != nullptr;  // developer knob: A/B
     static thread_local Slot slots[3];
     hipStream_t hs = static_cast<hipStream_t>(stream);
-    for (int t = (kLong > kShort ? 0 : 1); t < 3; ++t) {
+    for (int t = (kLong > kShort ? 0 : 1); t < (graph_remainder ? 3 : 2); ++t) {
       const int block = t == 0 ? kLong : t == 1 ? kShort : n_launches;
       if (block < 2 || n_launches < block) continue;
       const Key k{model->uid, state, tau, link_forces, force_repr, N, stream, block};
