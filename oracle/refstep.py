@@ -826,7 +826,17 @@ def rk4fast_integration(model, data: OracleData, link_forces, joint_torques) -> 
       state itself is returned as its derivative (``:214``): the deformation after the step is
       meaningless.  Without collidable points ``W_f_L_terrain`` is undefined (``:175-187``, NameError).
       Both cases are refused here; the function is restated for the contact models without contact
-      state (RigidContacts, RelaxedRigidContacts), where it is well defined."""
+      state (RigidContacts, RelaxedRigidContacts), where it is well defined.
+
+    One **deliberate deviation**: the reference calls ``link_contact_forces`` with the data in its own
+    representation (``:175-187``, outside the Inertial switch) and hands it the *already inertial* external
+    wrenches; its rigid / relaxed models rebuild their references with
+    ``velocity_representation=data.velocity_representation``, so with Mixed or Body data and non-zero
+    ``link_forces`` the inertial wrenches are re-read in that representation (converted twice).  Here the
+    contact solve sees the external wrenches as what they are -- inertial -- whatever the representation of
+    the data: the physics of the step does not depend on the representation the caller happens to use
+    (``tests/test_oracle_rigid.py::test_rk4fast_link_forces_do_not_depend_on_the_data_representation``
+    pins this; with Inertial data or without link forces the two readings coincide)."""
     kdp = model.kin_dyn_parameters
     if not (is_rigid_contact_model(model) or is_relaxed_rigid_contact_model(model)):
         raise NotImplementedError("rk4fast_integration corrupts the tangential deformation of SoftContacts in the reference")

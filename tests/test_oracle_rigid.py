@@ -122,3 +122,32 @@ def test_box_settles_on_rigid_ground(models):
     np.testing.assert_allclose(d.base_position[0, :2], 0.0, atol=1e-9)
     assert d.base_position[0, 2] == pytest.approx(0.05, abs=1e-4)
     assert np.abs(d.base_linear_velocity).max() < 1e-3
+
+
+def test_rk4fast_link_forces_do_not_depend_on_the_data_representation():
+    """RungeKutta4Fast with a contact model without contact state and non-zero external link forces: the
+    step of Mixed data with the forces given in Mixed equals the step of the same state held as Inertial data
+    with the same wrenches converted to Inertial.  The reference hands the already inertial wrenches to a
+    contact solve that re-reads them in the data's representation (api/integrators.py:175-187); the
+    restatement -- and the kernel checked against it -- deliberately does not (oracle/refstep.py docstring)."""
+    import jaxsim_amd as ja
+
+    zoo = helpers.ModelZoo()
+    rr.REDUCED_QP = True
+    try:
+        model = helpers.with_params(helpers.rigid_model(zoo("anymal"), helpers.ANYMAL_FEET_4), integrator=ja.IntegratorType.RungeKutta4Fast)
+        N = 6
+        d_mixed = zoo.random_data("anymal", N, seed=5)
+        assert d_mixed.velocity_representation == VelRepr.Mixed
+        tau, f_mixed = helpers.random_inputs(model, N, 7, np.float64)
+        f_inertial = rs.other_representation_to_inertial(f_mixed, VelRepr.Mixed, d_mixed.link_transforms, is_force=True)
+        assert np.abs(f_inertial - f_mixed).max() > 1e-3  # the two readings of the numbers differ
+        d_inertial = dataclasses.replace(d_mixed, velocity_representation=VelRepr.Inertial).update_caches(model)
+        a = oracle.step(model, d_mixed, link_forces=f_mixed, joint_force_references=tau)
+        b = oracle.step(model, d_inertial, link_forces=f_inertial, joint_force_references=tau)
+        assert helpers.rel_err(helpers.odata_to_block(model, a), helpers.odata_to_block(model, b)) < 1e-12
+        # and the forces matter in this sample
+        c = oracle.step(model, d_mixed, joint_force_references=tau)
+        assert helpers.rel_err(helpers.odata_to_block(model, a), helpers.odata_to_block(model, c)) > 1e-6
+    finally:
+        rr.REDUCED_QP = False
