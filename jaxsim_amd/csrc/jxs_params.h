@@ -121,13 +121,18 @@ JXS_HD constexpr int lds_zero_rec(int G) { return G * kRowRec + 48; }
 JXS_HD constexpr int lds_words_per_env(int G) { return (lds_zero_rec(G) + kRowRec + 3) / 4 * 4; }
 // rigid modes: Q and H packed lower triangles of order 3 n_cp + one exchange vector (jxs_rigid.inc)
 // RelaxedRigidContacts (rigid == 2) factorises in place of the Delassus matrix: one triangle
-// (+16: the gather buffer of the small-problem solver when the H triangle is shorter than it; whole 16-byte
-// groups), then the exchange area of the merged Delassus sweeps: kRgMergeRec words per point, up to 4 points
+// Problems of <= 4 points (the row-distributed register solver and the merged Delassus sweeps, jxs_rigid.inc) get
+// 16 words for the solver's gather buffer (the H triangle may be shorter than it) and kRgMergeRec words per point
+// for the exchange of the merged sweeps.  Larger problems get nothing extra: at 16 points four environments of a
+// wave use 38.5 KB and four waves share a CU -- 176 more words per environment made it three (measured: the
+// standing 16-point quadruped 0.83 -> 1.43 ms).
 constexpr int kRgMergeRec = 40;  // [0, 18) wrench handed to the base per unit force, [20, 38) base acceleration
 JXS_HD constexpr int rigid_lds_merge_off(int n_cp, int rigid = 1) {
-  return ((rigid == 2 ? 1 : 2) * ((3 * n_cp * (3 * n_cp + 1)) / 2) + 3 * n_cp + 8 + 16 + 3) / 4 * 4;
+  return ((rigid == 2 ? 1 : 2) * ((3 * n_cp * (3 * n_cp + 1)) / 2) + 3 * n_cp + 8 + (n_cp <= 4 ? 16 : 0) + 3) / 4 * 4;
 }
-JXS_HD constexpr int rigid_lds_words_per_env(int n_cp, int rigid = 1) { return rigid_lds_merge_off(n_cp, rigid) + 4 * kRgMergeRec; }
+JXS_HD constexpr int rigid_lds_words_per_env(int n_cp, int rigid = 1) {
+  return rigid_lds_merge_off(n_cp, rigid) + (n_cp <= 4 ? 4 * kRgMergeRec : 0);
+}
 constexpr int kQpMaxIter = 30;    // interior-point iterations (oracle/refrigid.py QP_MAX_ITER)
 constexpr int kRigidMaxPoints = 32;
 constexpr int kDbgSlots = 32;      // developer profiling build: cycle stamps / counters per workgroup
