@@ -363,8 +363,9 @@ struct DeviceLanes {
   }
   __device__ __forceinline__ V lds_read(int addr) const { return lds_[addr]; }
   // N consecutive words with 128-bit LDS instructions; `addr` is a multiple of 16 bytes (4 floats / 2 doubles).
-  // One ds instruction costs a lone wave ~15 cycles whether it moves 4 or 16 bytes, a ds_bpermute ~19
-  // (tools/ubench/issue_rate.hip): exchanges of whole records go through these instead of one shuffle per word.
+  // A ds instruction costs a lone wave the same issue slot whether it moves 4 or 16 bytes (tools/ubench/
+  // issue_rate.hip); what it does NOT buy is latency: a write -> read -> wait round trip is ~90 cycles exposed,
+  // where a batch of ds_bpermute pipelines (the forward-kinematics rounds through LDS were slower).
   template <int N>
   __device__ __forceinline__ void lds_writev(int addr, const T* v) const {
     constexpr int W = 16 / (int)sizeof(T);

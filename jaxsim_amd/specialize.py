@@ -109,12 +109,16 @@ def compile(model, dtype, mode: int = MODE_STEP, *, force: bool = False) -> path
     return out
 
 
+# forward dynamics, inverse dynamics, cached kinematics, mass matrix, Jacobians, mass-matrix inverse: on request
+QUERY_MODES = (1, 2, 3, 8, 9, 10)
+
+
 def attach(dm, model, mode: int | None = None, *, build: bool = False) -> bool:
     """Attach the specialised kernels of the model (all modes of ``modes_of``, or one ``mode``) to the device
     model ``dm``.  Without ``build`` only objects found in the cache are used.  True if any was attached."""
     lib = _lib.load()
     done = False
-    for m in modes_of(model) if mode is None else [mode]:
+    for m in modes_of(model) if mode is None else ([mode] if isinstance(mode, int) else list(mode)):
         p = compile(model, dm.dtype, m) if build else cached(model, dm.dtype, m)
         if p is not None:
             _lib.check(lib.jxs_model_attach_specialized(dm.handle, m, str(p).encode()), "jxs_model_attach_specialized")

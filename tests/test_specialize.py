@@ -116,3 +116,28 @@ def test_attach_refuses_a_kernel_built_for_another_model(models, monkeypatch):
     rc = _lib.load().jxs_model_attach_specialized(dm.handle, specialize.MODE_STEP, str(so).encode())
     assert rc != 0 and specialize.modes(dm) == []
     icub.__dict__.pop("_device", None)
+
+
+@pytest.mark.gpu
+def test_specialised_query_kernels_equal_the_generic_ones(models, monkeypatch):
+    """forward / inverse dynamics, mass matrix and its inverse through kernels specialised on the model."""
+    model = models("anymal")
+    d = models.random_data("anymal", 19, seed=2, dtype=np.float64)
+    block = helpers.odata_to_block(model, d)
+
+    def queries():
+        data = js.data.JaxSimModelData.from_state_block(model, block, 2)
+        a, sdd = js.model.forward_dynamics_aba(model, data)
+        tau = js.model.inverse_dynamics(model, data, joint_accelerations=np.asarray(sdd), base_acceleration=np.asarray(a))
+        return [np.asarray(x) for x in (a, sdd, tau[0], tau[1], js.model.free_floating_mass_matrix(model, data),
+                                        js.model.free_floating_mass_matrix_inverse(model, data))]  # fmt: skip
+
+    monkeypatch.setenv("JAXSIM_AMD_SPECIALIZE", "0")
+    model.__dict__.pop("_device", None)
+    ref = queries()
+    assert js.model.specialize(model, np.float64, queries=True)
+    assert set(specialize.QUERY_MODES) <= set(specialize.modes(runtime.device_model(model, np.float64)))
+    out = queries()
+    model.__dict__.pop("_device", None)
+    for x, y in zip(out, ref):
+        assert helpers.rel_err(x, y) < 1e-12
