@@ -141,3 +141,39 @@ def test_specialised_query_kernels_equal_the_generic_ones(models, monkeypatch):
     model.__dict__.pop("_device", None)
     for x, y in zip(out, ref):
         assert helpers.rel_err(x, y) < 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_links,fixed,max_back,seed", [(3, True, 1, 11), (7, False, 1, 12), (12, False, 3, 13), (20, True, 2, 14),
+                                                         (33, False, 4, 15), (9, False, 8, 16)])  # fmt: skip
+def test_specialised_random_trees_equal_the_generic_kernel(n_links, fixed, max_back, seed, monkeypatch):
+    """Random trees (serial chains, bushy trees, fixed and floating bases, with and without contact points, both
+    ABA layouts): the constant folding of a specialised build must not change what the kernel computes."""
+    import jaxsim_amd as ja
+    from jaxsim_amd import robots
+
+    model = ja.JaxSimModel.build_from_model_description(robots.chain_urdf(n_links, fixed_base=fixed, seed=seed, max_back=max_back))
+    data0 = js.data.random_model_data(model, batch_size=13, seed=seed, dtype=np.float32)
+    block = data0.state_block()
+    rng = np.random.default_rng(seed)
+    tau = rng.uniform(-1, 1, (13, model.dofs())).astype(np.float32)
+
+    def run():
+        # one step: these random trees in random states are violent (a state of 1e7 after three steps of the
+        # 33-link tree), further steps only measure how chaos amplifies the last bit
+        data = js.data.JaxSimModelData.from_state_block(model, block, 2)
+        a, sdd = js.model.forward_dynamics_aba(model, data, joint_forces=tau)
+        data = js.model.step(model, data, joint_force_references=tau)
+        return [data.state_block(), np.asarray(a), np.asarray(sdd)]
+
+    monkeypatch.setenv("JAXSIM_AMD_SPECIALIZE", "0")
+    model.__dict__.pop("_device", None)
+    ref = run()
+    assert js.model.specialize(model, np.float32, queries=True)
+    out = run()
+    model.__dict__.pop("_device", None)
+    for x, y in zip(out, ref):
+        assert np.isfinite(y).all()
+        # fp32 rounding with other contraction choices; deep random chains amplify it (they are 2e-2 from the fp64
+        # oracle, tests/helpers.py) -- a folded branch gone wrong would be O(1)
+        assert helpers.rel_err(x, y) < 5e-4
