@@ -388,6 +388,9 @@ RIGID_CASES = {
     "anymal4": ("anymal", helpers.ANYMAL_FEET_4, dict()),
     "chain9f6": ("chain9f", [0, 1, 2, 3, 8, 9], dict(K=1e3, mu=0.8)),
     "icub8": ("icub16", [0, 1, 2, 3, 8, 9, 10, 11], dict(K=1e4)),
+    # <= 4 points in a 32-lane group: the row-distributed register solver with the general Delassus sweeps
+    # (two points per foot: no merged sweep)
+    "icub4": ("icub16", [2, 9, 10, 11], dict(K=1e4)),
 }
 
 
