@@ -391,6 +391,7 @@ RIGID_CASES = {
     # <= 4 points in a 32-lane group: the row-distributed register solver with the general Delassus sweeps
     # (two points per foot: no merged sweep)
     "icub4": ("icub16", [2, 9, 10, 11], dict(K=1e4)),
+    "anymal2": ("anymal", [0, 16], dict()),  # merged sweeps and the 12-row solver with identity padding
 }
 
 
