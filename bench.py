@@ -572,7 +572,8 @@ def main():
             stream.synchronize()
             us_g = eg0.elapsed_ms(eg1) / 2000 * 1e3
             generic = {"launches": 2000, "us_per_step": us_g, "env_steps_per_s_rank0": n_local / (us_g * 1e-6),
-                       "note": "libjaxsim_amd.so's generic kernel (JAXSIM_AMD_SPECIALIZE=0), same launch path, HIP events over 2000 launches; secondary figure"}
+                       "note": "libjaxsim_amd.so's own kernel without a model-specialised build (JAXSIM_AMD_SPECIALIZE=0: the ahead-of-time variant with the common "
+                               "feature switches as constants, 9.7 us with all flags read at run time), same launch path, HIP events over 2000 launches; secondary figure"}
             del gdata, gdm
         except Exception as e:  # secondary: never lose the headline for it
             generic = {"error": repr(e)}

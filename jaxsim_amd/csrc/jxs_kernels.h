@@ -33,8 +33,15 @@ struct KTail {
 // to scratch).  Measured on the quadruped with one point per foot: -2 % at 4096 environments (one wave per
 // SIMD either way), +26 % at 16384, +58 % at 65536 -- the launcher picks it when the grid has more waves than
 // the chip has SIMDs and the LDS footprint of the contact problem lets a second wave in.
-template <typename T, int G, int MODE, bool OCC2 = false>
-__global__ __launch_bounds__(64, OCC2 ? 2 : 1) void jxs_kernel(const T* pre_state_in, T* pre_state_out, const unsigned char* __restrict__ pre_mblk,
+//
+// COMMON (soft-contact step / rollout only): the feature switches of the most common kind of model -- floating
+// base, no joint-successor transforms, row-distributed ABA, flat terrain, p = q = 1/2, anchored chains, one
+// contact chunk -- as constants; the launcher picks it when the model's flags say exactly that.  It is the
+// part of a model-specialised build (jxs_spec.hip) that needs no knowledge of the tree: 9.74 -> 8.55 us per
+// step for the 23-DoF humanoid where the full specialisation reaches 7.68 (tools/spec_split_experiment.py).
+enum KernelVariant : int { KV_GENERIC = 0, KV_OCC2 = 1, KV_COMMON = 2 };
+template <typename T, int G, int MODE, int VARIANT = KV_GENERIC>
+__global__ __launch_bounds__(64, VARIANT == KV_OCC2 ? 2 : 1) void jxs_kernel(const T* pre_state_in, T* pre_state_out, const unsigned char* __restrict__ pre_mblk,
                                                  const T* pre_tau, const T* pre_link_f, int pre_N, int pre_n_rows,
                                                  int pre_n, int pre_force_repr, int pre_n_steps,
                                                  const KTail<T> tail) {
@@ -56,6 +63,10 @@ __global__ __launch_bounds__(64, OCC2 ? 2 : 1) void jxs_kernel(const T* pre_stat
   P.n_rows = pre_n_rows, P.n = pre_n;
   P.row_pos = 0, P.row_quat = 3, P.row_s = 7, P.row_vlin = 7 + pre_n, P.row_vang = 10 + pre_n, P.row_sd = 13 + pre_n;
   P.row_m = 13 + 2 * pre_n;
+  if constexpr (VARIANT == KV_COMMON) {
+    P.floating = 1, P.any_suc = 0, P.seg_dpp_ok = 1, P.row_mode = 1, P.flat = 1, P.pq_half = 1, P.anchored = 1, P.rigid = 0;
+    P.rk4fast = 0, P.n_chunks = 1;
+  }
 #ifdef JXS_SPEC_ASSIGN
   // model-specialised build (jxs_spec.hip): the integer model flags are compile-time constants from here on
   JXS_SPEC_ASSIGN;
@@ -88,11 +99,20 @@ hipError_t launch_one(const jxs::KParams<T>& P, const unsigned char* mblk, const
     // the LDS of a CU (160 KiB)
     constexpr bool kHasOcc2 = (MODE == jxs::MODE_STEP_RIGID || MODE == jxs::MODE_STEP_RK4_RIGID) && sizeof(T) == 4;
     if (kHasOcc2 && blocks > 1024 && lds_bytes * 8 <= 160 * 1024 && P.n_cp <= 8) {
-      hipLaunchKernelGGL((jxs_kernel<T, G, MODE, kHasOcc2>), dim3(blocks), dim3(64), lds_bytes, s, A.state_in, A.state_out, mblk,
+      hipLaunchKernelGGL((jxs_kernel<T, G, MODE, kHasOcc2 ? KV_OCC2 : KV_GENERIC>), dim3(blocks), dim3(64), lds_bytes, s, A.state_in, A.state_out, mblk,
                          A.tau, A.link_f, A.N, P.n_rows, P.n, A.force_repr, A.n_steps, tail);
       return hipGetLastError();
     }
   }
+#ifndef JXS_SPEC_ASSIGN  // (a model-specialised build has these constants anyway)
+  constexpr bool kHasCommon = (MODE == jxs::MODE_STEP || MODE == jxs::MODE_ROLLOUT) && G >= 8;
+  if (kHasCommon && P.floating == 1 && P.any_suc == 0 && P.seg_dpp_ok == 1 && P.row_mode == 1 && P.flat == 1 && P.pq_half == 1 &&
+      P.anchored == 1 && P.rigid == 0 && P.rk4fast == 0 && P.n_chunks == 1) {
+    hipLaunchKernelGGL((jxs_kernel<T, G, MODE, kHasCommon ? KV_COMMON : KV_GENERIC>), dim3(blocks), dim3(64), lds_bytes, s, A.state_in,
+                       A.state_out, mblk, A.tau, A.link_f, A.N, P.n_rows, P.n, A.force_repr, A.n_steps, tail);
+    return hipGetLastError();
+  }
+#endif
   hipLaunchKernelGGL((jxs_kernel<T, G, MODE>), dim3(blocks), dim3(64), lds_bytes, s, A.state_in, A.state_out, mblk, A.tau,
                      A.link_f, A.N, P.n_rows, P.n, A.force_repr, A.n_steps, tail);
   return hipGetLastError();
