@@ -42,7 +42,7 @@ for d in sorted(run.glob("pmc_*")):
             dst[k] = {"mean_per_launch": sum(v) / len(v), "launches": len(v), "waves_per_launch": waves}
     headline_kernel = "jxs_launch_spec::jxs_kernel<float,32,MODE_STEP> (model-specialised)" if spec else "jxs_launch::jxs_kernel<float,32,MODE_STEP>"
 if summary:
-    for title, tab in ((headline_kernel, summary), ("jxs_launch::jxs_kernel<float,32,MODE_STEP> (generic kernel, bench.py's `generic_kernel` secondary)", generic)):
+    for title, tab in ((headline_kernel, summary), ("jxs_launch::jxs_kernel<float,32,MODE_STEP> (the library's kernel without a per-model build -- variant 2 = KV_COMMON; bench.py's `generic_kernel` secondary)", generic)):
         if not tab or (tab is generic and "spec" not in headline_kernel):
             continue
         lines += [f"## PMC counters of `{title}` (separate `--pmc` passes, mean per launch)", "",
