@@ -55,7 +55,7 @@ def timed(tag, sub):
     print(f"{tag:34s} {min(best):6.2f} us per step", flush=True)
 
 
-timed("generic (nothing constant)", None)
+timed("library kernel (KV_COMMON where it applies; JXS_DISABLE_COMMON_VARIANT=1: nothing constant)", None)
 timed("feature switches only", pick(FEATURES))
 timed("tree-shape constants only", pick(SHAPE))
 timed("everything (the product's build)", assign)
