@@ -35,7 +35,7 @@ def timed(tag, sub):
     model.__dict__.pop("_device", None)
     dm = runtime.device_model(model, np.float32)
     if sub is not None:
-        out = f"/tmp/spec_{tag}.so"
+        out = "/tmp/spec_" + "".join(ch if ch.isalnum() else "_" for ch in tag) + ".so"
         cmd = [sp._HIPCC, *sp._FLAGS, "-DJXS_SPEC_T=float", "-DJXS_SPEC_G=32", "-DJXS_SPEC_MODE=0", f"-DJXS_SPEC_ASSIGN={sub}",
                f'-DJXS_SPEC_STRING="{text}"', "jxs_spec.hip", "-o", out]
         subprocess.run(cmd, cwd=sp._CSRC, check=True, capture_output=True)
@@ -58,4 +58,6 @@ def timed(tag, sub):
 timed("library kernel (KV_COMMON where it applies; JXS_DISABLE_COMMON_VARIANT=1: nothing constant)", None)
 timed("feature switches only", pick(FEATURES))
 timed("tree-shape constants only", pick(SHAPE))
+timed("features + rounds / depth / seg steps", pick(FEATURES + ("n_rounds", "max_depth", "seg_steps")))
+timed("features + row-layout level masks", pick(FEATURES + ("row_cross_levels", "row_ppull_levels", "row_pull_counts")))
 timed("everything (the product's build)", assign)
