@@ -20,19 +20,30 @@ if [ -z "$UNITS" ]; then
   UNITS="$UNITS api"
 fi
 compile() {
-  local u=$1
+  local u=$1 o
   if [ "$u" = api ]; then
-    "$HIPCC" $FLAGS -c jxs_api.hip -o "$OBJ/api.o"
+    o="$OBJ/api.o"; rm -f "$o"
+    "$HIPCC" $FLAGS -c jxs_api.hip -o "$o" || { echo "$u" >> "$OBJ/failed"; return 1; }
   else
     local t=${u%%:*} m=${u##*:}
-    "$HIPCC" $FLAGS -DJXS_INST_T=$t -DJXS_INST_MODE=$m -c jxs_inst.hip -o "$OBJ/inst_${t}_${m}.o"
+    o="$OBJ/inst_${t}_${m}.o"; rm -f "$o"     # a stale object must never be linked after a failed compile
+    "$HIPCC" $FLAGS -DJXS_INST_T=$t -DJXS_INST_MODE=$m -c jxs_inst.hip -o "$o" || { echo "$u" >> "$OBJ/failed"; return 1; }
   fi
 }
 export -f compile
 export HIPCC FLAGS OBJ
 # the slowest units first (rigid contact modes 6, 7; Runge-Kutta 5)
 ORDERED=$(for u in $UNITS; do case $u in *:7) echo "0 $u";; *:6) echo "1 $u";; *:5) echo "2 $u";; *) echo "3 $u";; esac; done | sort -s -k1,1 | cut -d' ' -f2)
-printf '%s\n' $ORDERED | xargs -P "$JOBS" -I{} bash -c 'compile {}' 2>&1 | grep -v "warning: loop not unrolled\|^ *[0-9]* *|\|\^\|warning generated\|warnings generated" || true
+rm -f "$OBJ/failed" "$OBJ/compile.log"
+set +e
+printf '%s\n' $ORDERED | xargs -P "$JOBS" -I{} bash -c 'compile {}' > "$OBJ/compile.log" 2>&1
+RC=$?
+set -e
+grep -v "warning: loop not unrolled\|^ *[0-9]* *|\|\^\|warning generated\|warnings generated" "$OBJ/compile.log" || true
+if [ $RC -ne 0 ] || [ -s "$OBJ/failed" ]; then
+  echo "build.sh: compilation failed (xargs rc $RC) for units: $(tr '\n' ' ' < "$OBJ/failed" 2>/dev/null)" >&2
+  exit 1
+fi
 for t in float double; do for m in 0 1 2 3 4 5 6 7 8 9 10; do [ -f "$OBJ/inst_${t}_${m}.o" ] || { echo "missing object inst_${t}_${m}.o" >&2; exit 1; }; done; done
 [ -f "$OBJ/api.o" ] || { echo "missing object api.o" >&2; exit 1; }
 "$HIPCC" --offload-arch=gfx950 -shared -fPIC "$OBJ"/api.o "$OBJ"/inst_*.o -o "$OUT" -ldl
