@@ -76,8 +76,10 @@ struct ModelT {
   int* faults = nullptr;  // [2] discarded contact-force / impact solves since the last reset (rigid contact models)
 
   ~ModelT() {
-    for (void* h : spec_handle)
-      if (h != nullptr) dlclose(h);
+    // The specialised-kernel objects are NOT unloaded (attach_typed): launches of this model may still be in
+    // flight on some stream, and unloading a code object under a running kernel is undefined; hipFree
+    // synchronises the device.  The objects stay mapped for the life of the process (a few hundred KB each),
+    // which also keeps them visible in /proc/self/maps to whoever audits which native code ran.
     (void)hipFree(mblk);
     (void)hipFree(faults);
   }
@@ -279,8 +281,7 @@ int attach_typed(jxs_model* model, ModelT<T>* mt, int mode, const char* path) {
     dlclose(h);
     return fail(JXS_EINVAL, "the specialised kernel was built for another model: " + got + " != " + want);
   }
-  if (mt->spec_handle[mode] != nullptr) dlclose(mt->spec_handle[mode]);
-  mt->spec_handle[mode] = h;
+  mt->spec_handle[mode] = h;  // (a replaced object stays loaded, see ~ModelT; dlopen of the same path returns the same handle)
   mt->spec_launch[mode] = launch;
   static std::atomic<unsigned long long> next_uid{1ull << 40};
   model->uid = next_uid.fetch_add(1);  // launch graphs captured with the generic kernel are not found again

@@ -44,6 +44,7 @@ struct Core {
   mutable unsigned rg_amask_ = 0xffffffffu;
   mutable VM rg_mine_;  // this lane's own point has its bit set
   mutable int rg_hoff_ = 0;  // LDS word offset of the working matrix H: behind Q, or Q itself (relaxed model)
+  mutable int duo_seen_ = 0;  // two-wave workgroups, main wave: last value read from the inertia wave's progress word
 
   JXS_HD Core(const KParams<T>& p, const KArgs<T>& a, const L& l) : P(p), A(a), ln(l) {}
 
@@ -108,13 +109,19 @@ struct Core {
   }
 
   // ==========================================================================================
-  template <int MODE>
+  // ROLE_SOLO: the whole step in one wave.  ROLE_MAIN: the main wave of a two-wave workgroup -- everything but the
+  // articulated-inertia recursion of ABA pass 2, which the inertia wave (run_inertia) runs concurrently from the
+  // same joint positions and hands over level by level (aba_rows_main).
+  template <int MODE, int ROLE = ROLE_SOLO>
   JXS_HD void run() {
+    static_assert(ROLE == ROLE_SOLO || (ROLE == ROLE_MAIN && MODE == MODE_STEP), "two-wave workgroups: single step only");
+    constexpr int kArea = (ROLE == ROLE_MAIN) ? duo_main_off(G) : 0;  // LDS area of this wave (words)
     constexpr bool kRK4 = (MODE == MODE_STEP_RK4 || MODE == MODE_STEP_RK4_RIGID);
     constexpr bool kRigid = (MODE == MODE_STEP_RIGID || MODE == MODE_STEP_RK4_RIGID);
     constexpr bool kStep = (MODE == MODE_STEP || MODE == MODE_ROLLOUT || kRK4 || kRigid);
     const VI lane = ln.lane();
     ln.stamp(A, 0);
+    ln.stamp_hwid(A, 11);
 
     // ======================================================================================
     // Batch 1 of global loads: every address below is known at launch, so all of them are in
@@ -138,6 +145,16 @@ struct Core {
     for (int k = 0; k < kMaxChildren; ++k) child[k] = ln.lconsti(A.lti, LI_CHILD + k);
     // state (row D): the joint rows need the lane's joint index, one dependent round trip behind the tables
     V pB[3], q[4], vW[3], om[3];
+    // The 13 environment-uniform rows (base position, quaternion, base velocity): one load instruction per row
+    // costs the CU's vector-memory pipeline 32 ticks each (tools/ubench/cu_share.hip; the prologue is bound by
+    // that pipeline, which the waves of a CU share).  With an LDS area at hand lane k < 13 loads row k -- ONE
+    // instruction -- and the values reach every lane through one LDS write and four broadcast reads.
+    const bool stage_base = G >= 16 && A.has_lds != 0;
+    V base_stage = V(T(0));
+    if (stage_base) {
+      const VI brow = vsel(lane < 7, lane, vsel(lane < 13, lane + P.n, lane * 0));  // rows 0..6 and 7+n..12+n
+      base_stage = ln.gload(A.state_in, brow, P.n_rows);
+    } else {
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       pB[k] = ln.gload_u(A.state_in, P.row_pos + k, P.n_rows);
@@ -146,6 +163,7 @@ struct Core {
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) q[k] = ln.gload_u(A.state_in, P.row_quat + k, P.n_rows);
+    }
     V ax[3], Rpre[9], ppre[3], cL[3], IL[6];
 #pragma unroll
     for (int k = 0; k < 3; ++k) ax[k] = ln.lconstf(A.ltf, LF_AXIS + k);
@@ -181,6 +199,17 @@ struct Core {
     V s = ln.gload(A.state_in, jrow_c + P.row_s, P.n_rows);
     V sd = ln.gload(A.state_in, jrow_c + P.row_sd, P.n_rows);
     ln.fence();
+    if (stage_base) {
+      ln.lds_write(lane + kArea, base_stage, lane < 16);
+      ln.lds_sync();
+      V b16[16];
+      ln.template lds_readv<16>(lane * 0 + kArea, b16);
+      ln.lds_sync();
+#pragma unroll
+      for (int k = 0; k < 3; ++k) pB[k] = b16[k], vW[k] = b16[7 + k], om[k] = b16[10 + k];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) q[k] = b16[3 + k];
+    }
     ln.stamp_after(A, 20, jrow);   // profiling build: index tables arrived
     ln.stamp_after(A, 21, q[3]);   // base rows of the state arrived
     ln.stamp_after(A, 22, ps0.hd); // point-slot tables arrived
@@ -267,97 +296,29 @@ struct Core {
     if (kRigid && stage == kImpactStage && P.rigid == 2) break;  // RelaxedRigidContacts: no velocity reset (relaxed_rigid.py:265-281)
     // ---- base rotation: DCM of q/|q| (data.base_orientation, api/data.py:267-286) --------
     V R[9], r[3];
-    {
-      const V nsq = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
-      const V nrm = vsqrt(nsq);
-      const V inv = vrcp(nrm + vsel(nrm == V(T(0)), V(P.eps), V(T(0))));
-#pragma unroll
-      for (int k = 0; k < 4; ++k) q[k] = q[k] * inv;
-    }
     V R0[9];
-    {
-      const V w = q[0], x = q[1], y = q[2], z = q[3];
-      const V two = V(T(2));
-      R0[0] = V(T(1)) - two * (y * y + z * z);
-      R0[1] = two * (x * y - w * z);
-      R0[2] = two * (x * z + w * y);
-      R0[3] = two * (x * y + w * z);
-      R0[4] = V(T(1)) - two * (x * x + z * z);
-      R0[5] = two * (y * z - w * x);
-      R0[6] = two * (x * z - w * y);
-      R0[7] = two * (y * z + w * x);
-      R0[8] = V(T(1)) - two * (x * x + y * y);
-    }
-
+    base_dcm(q, R0);
+    V fkrec[kDuoFkRec];  // two-wave workgroups: link pose and anchors as published by the inertia wave
+    if constexpr (ROLE == ROLE_MAIN) {
+      ln.stamp(A, 2);
+      ln.flag_wait(kDuoFlagFk, duo_seen_);
+      ln.template lds_readv<kDuoFkRec>(lane * kDuoFkRec + duo_fk_off(G), fkrec);
+#pragma unroll
+      for (int e = 0; e < 9; ++e) R[e] = fkrec[e];
+#pragma unroll
+      for (int e = 0; e < 3; ++e) r[e] = fkrec[9 + e];
+      ln.stamp_after(A, 3, r[2]);
+    } else {
     // ---- H: local parent->child transform lambda_H_pre * pre_H_suc(s) * suc_H_i ----------
     //      (api/kin_dyn_parameters.py:396-451, math/joint_model.py:146-200, math/rotation.py:58-84)
-    {
-      // Rodrigues from the half angle: sin s = 2 sh ch, 1 - cos s = 2 sh^2 (the reference also
-      // forms 1 - cos as 2 sin^2(theta/2)), cos s = 1 - 2 sh^2.
-      V sh, chh;
-      vsincos(vsel(is_rev, s, V(T(0))) * T(0.5), sh, chh);
-      const V sn = T(2) * sh * chh;
-      const V c1 = T(2) * sh * sh;
-      const V cs = V(T(1)) - c1;
-      V Rj[9];
-      Rj[0] = cs + c1 * ax[0] * ax[0];
-      Rj[1] = -sn * ax[2] + c1 * ax[0] * ax[1];
-      Rj[2] = sn * ax[1] + c1 * ax[0] * ax[2];
-      Rj[3] = sn * ax[2] + c1 * ax[1] * ax[0];
-      Rj[4] = cs + c1 * ax[1] * ax[1];
-      Rj[5] = -sn * ax[0] + c1 * ax[1] * ax[2];
-      Rj[6] = -sn * ax[1] + c1 * ax[2] * ax[0];
-      Rj[7] = sn * ax[0] + c1 * ax[2] * ax[1];
-      Rj[8] = cs + c1 * ax[2] * ax[2];
-      V pj[3];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) pj[k] = vsel(is_pri, s * ax[k], V(T(0)));
-      V Rl[9], pl[3];
-      if (P.any_suc) {
-        V tmp[9], t3[3];
-        mat3mul(Rj, Rsuc, tmp);
-        mat3mul(Rpre, tmp, Rl);
-        mat3vec(Rj, psuc, t3);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) t3[k] = t3[k] + pj[k];
-        mat3vec(Rpre, t3, pl);
-      } else {
-        mat3mul(Rpre, Rj, Rl);
-        mat3vec(Rpre, pj, pl);
-      }
-#pragma unroll
-      for (int k = 0; k < 3; ++k) pl[k] = pl[k] + ppre[k];
-      // The base lane starts from (R0, 0): frame C has its origin at the base position.
-#pragma unroll
-      for (int k = 0; k < 9; ++k) R[k] = vsel(is_root, R0[k], Rl[k]);
-#pragma unroll
-      for (int k = 0; k < 3; ++k) r[k] = vsel(is_root, V(T(0)), pl[k]);
-    }
+    local_transform(is_rev, is_pri, is_root, s, ax, Rpre, ppre, Rsuc, psuc, R0, R, r);
     ln.stamp(A, 2);  // actuation + local transforms
 
     // ---- M: forward kinematics as a tree prefix product (pointer jumping) ----------------
     //      equals the scan of rbda/forward_kinematics.py:80-103 in exact arithmetic
-#pragma unroll
-    for (int k = 0; k < kMaxRounds; ++k) {
-      if (k < P.n_rounds) {
-        const VI src = jump[k];
-        const VM ok = src >= 0;
-        V Ra[9], ra[3];
-#pragma unroll
-        for (int e = 0; e < 9; ++e) Ra[e] = ln.shfl(R[e], src);
-#pragma unroll
-        for (int e = 0; e < 3; ++e) ra[e] = ln.shfl(r[e], src);
-        ln.fence();
-        V Rn[9], rn[3];
-        mat3mul(Ra, R, Rn);
-        mat3vec(Ra, r, rn);
-#pragma unroll
-        for (int e = 0; e < 9; ++e) R[e] = vsel(ok, Rn[e], R[e]);
-#pragma unroll
-        for (int e = 0; e < 3; ++e) r[e] = vsel(ok, rn[e] + ra[e], r[e]);
-      }
-    }
+    fk_prefix(jump, R, r);
     ln.stamp(A, 3);  // forward kinematics
+    }
 
     // Anchored ABA (see "G: articulated-body algorithm" below): origin of the leaf link of this lane's
     // first-child chain, and of the parent's chain -- fetched here so that the shuffles complete behind the
@@ -365,7 +326,10 @@ struct Core {
     constexpr bool kAnchMode = (kStep && !kRigid) || MODE == MODE_FD;
     const bool anch = kAnchMode && P.anchored != 0;
     V ra[3] = {V(T(0)), V(T(0)), V(T(0))}, dpl[3] = {V(T(0)), V(T(0)), V(T(0))};
-    if (anch) {
+    if constexpr (ROLE == ROLE_MAIN) {
+#pragma unroll
+      for (int e = 0; e < 3; ++e) ra[e] = fkrec[12 + e], dpl[e] = fkrec[15 + e];  // (zeros without anchors)
+    } else if (anch) {
       const VI anchor = ln.lconsti(A.lti, LI_ANCHOR), panchor = ln.lconsti(A.lti, LI_PANCHOR);
       V rq[3];
 #pragma unroll
@@ -504,31 +468,42 @@ struct Core {
       // The kinematics of the parent links reach the point lanes through the LDS scratch of the
       // row-distributed layout (18 writes + 18 reads, one round trip) instead of 18 ds_bpermute:
       // measured 9.70 -> 9.56 us per step (ds_bpermute issues every ~22 cycles for a lone wave).
-      const int KIN = lds_kin_offset(G);
-      const VI kb = lane * kKinRec + KIN;
-#pragma unroll
-      for (int e = 0; e < 9; ++e) ln.lds_write(kb + e, R[e]);
-#pragma unroll
-      for (int e = 0; e < 3; ++e) {
-        ln.lds_write(kb + (9 + e), r[e]);
-        ln.lds_write(kb + (12 + e), vl[e]);
-        ln.lds_write(kb + (15 + e), va[e]);
-        ln.lds_write(kb + (18 + e), ra[e]);
-      }
-      ln.lds_sync();
+      const int KIN = lds_kin_offset(G) + kArea;
       const VM valid = ps0.body >= 0;
       V m[3], Rb[9], rb[3], vbl[3], vba[3], rab[3];
 #pragma unroll
       for (int k = 0; k < 3; ++k) m[k] = vsel(valid, ps0.m[k], V(T(0)));
-      const VI kr = vsel(valid, ps0.body, lane * 0) * kKinRec + KIN;
+      const VI body_c = vsel(valid, ps0.body, lane * 0);
+      if constexpr (ROLE == ROLE_MAIN) {
+        // pose and anchor of the parent link: straight from the record the inertia wave published (wide reads);
+        // only the link velocities are staged here (8 words per link)
+        const V v8[8] = {vl[0], vl[1], vl[2], va[0], va[1], va[2], V(T(0)), V(T(0))};
+        ln.template lds_writev<8>(lane * 8 + KIN, v8);
+        ln.lds_sync();
+        V pr16[16], pv8[8];
+        ln.template lds_readv<16>(body_c * kDuoFkRec + duo_fk_off(G), pr16);
+        ln.template lds_readv<8>(body_c * 8 + KIN, pv8);
 #pragma unroll
-      for (int e = 0; e < 9; ++e) Rb[e] = ln.lds_read(kr + e);
+        for (int e = 0; e < 9; ++e) Rb[e] = pr16[e];
 #pragma unroll
-      for (int e = 0; e < 3; ++e) {
-        rb[e] = ln.lds_read(kr + (9 + e)), vbl[e] = ln.lds_read(kr + (12 + e)), vba[e] = ln.lds_read(kr + (15 + e));
-        rab[e] = ln.lds_read(kr + (18 + e));
-      }
+        for (int e = 0; e < 3; ++e) rb[e] = pr16[9 + e], rab[e] = pr16[12 + e], vbl[e] = pv8[e], vba[e] = pv8[3 + e];
+        ln.lds_sync();
+      } else {
+      // one record of kKinRec = 24 words per link, written and read with 128-bit LDS instructions (an LDS
+      // instruction costs a wave 11..15 ticks of issue whatever its width, tools/ubench/cu_share.hip: six writes
+      // and six reads instead of twenty-one of each)
+      const V k24[kKinRec] = {R[0], R[1], R[2], R[3], R[4], R[5], R[6], R[7], R[8], r[0], r[1], r[2], vl[0], vl[1], vl[2],
+                              va[0], va[1], va[2], ra[0], ra[1], ra[2], V(T(0)), V(T(0)), V(T(0))};
+      ln.template lds_writev<kKinRec>(lane * kKinRec + KIN, k24);
       ln.lds_sync();
+      V p24[kKinRec];
+      ln.template lds_readv<kKinRec>(body_c * kKinRec + KIN, p24);
+#pragma unroll
+      for (int e = 0; e < 9; ++e) Rb[e] = p24[e];
+#pragma unroll
+      for (int e = 0; e < 3; ++e) rb[e] = p24[9 + e], vbl[e] = p24[12 + e], vba[e] = p24[15 + e], rab[e] = p24[18 + e];
+      ln.lds_sync();
+      }
       V w6[6], mdl[3];
       point_physics(valid, ps0.Lp, m, Rb, rb, vbl, vba, rab, pB, doff, vBc, om, w6, mdl);
 #pragma unroll
@@ -542,21 +517,7 @@ struct Core {
     // M = [[m I, m S(c)^T],[m S(c), I_c + m S(c) S(c)^T]]  (math/inertia.py:14-41) with the CoM
     // c = r + R c_L and I_c = R I_L R^T expressed in C.
     V cw[3], Ic[6];
-    {
-      mat3vec(R, cL, cw);
-#pragma unroll
-      for (int k = 0; k < 3; ++k) cw[k] = cw[k] + r[k];
-      // T = R * I_L (3x3), then Ic = T * R^T (symmetric)
-      const V I9[9] = {IL[0], IL[1], IL[2], IL[1], IL[3], IL[4], IL[2], IL[4], IL[5]};
-      V Tm[9];
-      mat3mul(R, I9, Tm);
-      Ic[0] = Tm[0] * R[0] + Tm[1] * R[1] + Tm[2] * R[2];
-      Ic[1] = Tm[0] * R[3] + Tm[1] * R[4] + Tm[2] * R[5];
-      Ic[2] = Tm[0] * R[6] + Tm[1] * R[7] + Tm[2] * R[8];
-      Ic[3] = Tm[3] * R[3] + Tm[4] * R[4] + Tm[5] * R[5];
-      Ic[4] = Tm[3] * R[6] + Tm[4] * R[7] + Tm[5] * R[8];
-      Ic[5] = Tm[6] * R[6] + Tm[7] * R[7] + Tm[8] * R[8];
-    }
+    link_inertia_C(R, r, cL, IL, cw, Ic);
     // h = M v:  h_lin = m (v + w x c),  h_ang = I_c w + c x h_lin
     V hl[3], ha[3];
     {
@@ -622,26 +583,7 @@ struct Core {
     }
     // MA_i = M_i (upper triangle of the symmetric 6x6)
     V MA[21];
-    {
-      const V zero = V(T(0));
-      const V mcx = mass * cw[0], mcy = mass * cw[1], mcz = mass * cw[2];
-      // top-left: m I
-      MA[sidx(0, 0)] = mass; MA[sidx(0, 1)] = zero; MA[sidx(0, 2)] = zero;
-      MA[sidx(1, 1)] = mass; MA[sidx(1, 2)] = zero;
-      MA[sidx(2, 2)] = mass;
-      // top-right: m S(c)^T = -m S(c) = [[0, mcz, -mcy],[-mcz, 0, mcx],[mcy, -mcx, 0]]
-      MA[sidx(0, 3)] = zero; MA[sidx(0, 4)] = mcz; MA[sidx(0, 5)] = -mcy;
-      MA[sidx(1, 3)] = -mcz; MA[sidx(1, 4)] = zero; MA[sidx(1, 5)] = mcx;
-      MA[sidx(2, 3)] = mcy; MA[sidx(2, 4)] = -mcx; MA[sidx(2, 5)] = zero;
-      // bottom-right: I_c + m (|c|^2 I - c c^T)
-      const V cc = cw[0] * cw[0] + cw[1] * cw[1] + cw[2] * cw[2];
-      MA[sidx(3, 3)] = Ic[0] + mass * (cc - cw[0] * cw[0]);
-      MA[sidx(3, 4)] = Ic[1] - mcx * cw[1];
-      MA[sidx(3, 5)] = Ic[2] - mcx * cw[2];
-      MA[sidx(4, 4)] = Ic[3] + mass * (cc - cw[1] * cw[1]);
-      MA[sidx(4, 5)] = Ic[4] - mcy * cw[2];
-      MA[sidx(5, 5)] = Ic[5] + mass * (cc - cw[2] * cw[2]);
-    }
+    assemble_MA(mass, cw, Ic, MA);
     const V S6[6] = {Sl[0], Sl[1], Sl[2], Sa[0], Sa[1], Sa[2]};
     const V c6[6] = {cl[0], cl[1], cl[2], ca[0], ca[1], ca[2]};
     ln.stamp(A, 6);  // inertia + bias
@@ -655,7 +597,10 @@ struct Core {
     V acl[3], aca[3];  // base spatial acceleration in C incl. gravity (valid in every lane)
     if (P.row_mode && (kStep || MODE == MODE_FD) && !kRigid) {
       V a0[6];
-      aba_rows(lane, rt, MA, pA, S6, c6, tau, anch, dpl, sdd, a0);
+      if constexpr (ROLE == ROLE_MAIN)
+        aba_rows_main(lane, rt, pA, S6, c6, tau, anch, dpl, sdd, a0);
+      else
+        aba_rows(lane, rt, MA, pA, S6, c6, tau, anch, dpl, sdd, a0);
       if (anch && P.floating) {  // from the base chain's anchor back to the origin of C: a_lin - alpha x ra_0
         V ra0[3], t[3];
         const VI zero_lane = lane * 0;
@@ -678,7 +623,9 @@ struct Core {
       V U[6], inv_d = V(T(0)), u = V(T(0));
   #pragma unroll
       for (int k = 0; k < 6; ++k) U[k] = V(T(0));
-      const int first_level = P.floating ? 1 : 2;  // fixed base: nothing propagates into link 0
+      // fixed base: nothing propagates into link 0 -- except for the mass-matrix inverse, where the reference treats
+      // the base of every model as a free body (rbda/mass_inverse.py:118-178)
+      const int first_level = (P.floating || MODE == MODE_MINV) ? 1 : 2;
       const int max_depth = P.max_depth;
       const unsigned long long mc0 = P.maxch_nib[0], mc1 = P.maxch_nib[1], mc2 = P.maxch_nib[2], mc3 = P.maxch_nib[3];
       const unsigned long long nonadj = P.nonadj_levels;
@@ -1040,6 +987,133 @@ struct Core {
     ln.stamp(A, 10);  // integrate + stores issued
   }
 
+  // ---- pieces of run() shared with the inertia wave of a two-wave workgroup (run_inertia) --------------
+  // base rotation: q <- q / |q| and its DCM (data.base_orientation, api/data.py:267-286)
+  JXS_HD void base_dcm(V* q, V* R0) const {
+    {
+      const V nsq = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+      const V nrm = vsqrt(nsq);
+      const V inv = vrcp(nrm + vsel(nrm == V(T(0)), V(P.eps), V(T(0))));
+#pragma unroll
+      for (int k = 0; k < 4; ++k) q[k] = q[k] * inv;
+    }
+    const V w = q[0], x = q[1], y = q[2], z = q[3];
+    const V two = V(T(2));
+    R0[0] = V(T(1)) - two * (y * y + z * z);
+    R0[1] = two * (x * y - w * z);
+    R0[2] = two * (x * z + w * y);
+    R0[3] = two * (x * y + w * z);
+    R0[4] = V(T(1)) - two * (x * x + z * z);
+    R0[5] = two * (y * z - w * x);
+    R0[6] = two * (x * z - w * y);
+    R0[7] = two * (y * z + w * x);
+    R0[8] = V(T(1)) - two * (x * x + y * y);
+  }
+  // local parent->child transform lambda_H_pre * pre_H_suc(s) * suc_H_i; the base lane starts from (R0, 0)
+  JXS_HD void local_transform(const VM& is_rev, const VM& is_pri, const VM& is_root, const V& s, const V* ax, const V* Rpre,
+                              const V* ppre, const V* Rsuc, const V* psuc, const V* R0, V* R, V* r) const {
+    // Rodrigues from the half angle: sin s = 2 sh ch, 1 - cos s = 2 sh^2 (the reference also
+    // forms 1 - cos as 2 sin^2(theta/2)), cos s = 1 - 2 sh^2.
+    V sh, chh;
+    vsincos(vsel(is_rev, s, V(T(0))) * T(0.5), sh, chh);
+    const V sn = T(2) * sh * chh;
+    const V c1 = T(2) * sh * sh;
+    const V cs = V(T(1)) - c1;
+    V Rj[9];
+    Rj[0] = cs + c1 * ax[0] * ax[0];
+    Rj[1] = -sn * ax[2] + c1 * ax[0] * ax[1];
+    Rj[2] = sn * ax[1] + c1 * ax[0] * ax[2];
+    Rj[3] = sn * ax[2] + c1 * ax[1] * ax[0];
+    Rj[4] = cs + c1 * ax[1] * ax[1];
+    Rj[5] = -sn * ax[0] + c1 * ax[1] * ax[2];
+    Rj[6] = -sn * ax[1] + c1 * ax[2] * ax[0];
+    Rj[7] = sn * ax[0] + c1 * ax[2] * ax[1];
+    Rj[8] = cs + c1 * ax[2] * ax[2];
+    V pj[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) pj[k] = vsel(is_pri, s * ax[k], V(T(0)));
+    V Rl[9], pl[3];
+    if (P.any_suc) {
+      V tmp[9], t3[3];
+      mat3mul(Rj, Rsuc, tmp);
+      mat3mul(Rpre, tmp, Rl);
+      mat3vec(Rj, psuc, t3);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) t3[k] = t3[k] + pj[k];
+      mat3vec(Rpre, t3, pl);
+    } else {
+      mat3mul(Rpre, Rj, Rl);
+      mat3vec(Rpre, pj, pl);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) pl[k] = pl[k] + ppre[k];
+    // The base lane starts from (R0, 0): frame C has its origin at the base position.
+#pragma unroll
+    for (int k = 0; k < 9; ++k) R[k] = vsel(is_root, R0[k], Rl[k]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) r[k] = vsel(is_root, V(T(0)), pl[k]);
+  }
+  // forward kinematics as a tree prefix product (pointer jumping)
+  JXS_HD void fk_prefix(const VI* jump, V* R, V* r) const {
+#pragma unroll
+    for (int k = 0; k < kMaxRounds; ++k) {
+      if (k < P.n_rounds) {
+        const VI src = jump[k];
+        const VM ok = src >= 0;
+        V Ra[9], ra[3];
+#pragma unroll
+        for (int e = 0; e < 9; ++e) Ra[e] = ln.shfl(R[e], src);
+#pragma unroll
+        for (int e = 0; e < 3; ++e) ra[e] = ln.shfl(r[e], src);
+        ln.fence();
+        V Rn[9], rn[3];
+        mat3mul(Ra, R, Rn);
+        mat3vec(Ra, r, rn);
+#pragma unroll
+        for (int e = 0; e < 9; ++e) R[e] = vsel(ok, Rn[e], R[e]);
+#pragma unroll
+        for (int e = 0; e < 3; ++e) r[e] = vsel(ok, rn[e] + ra[e], r[e]);
+      }
+    }
+  }
+  // CoM c = r + R c_L and rotational inertia I_c = R I_L R^T of the link in C
+  JXS_HD void link_inertia_C(const V* R, const V* r, const V* cL, const V* IL, V* cw, V* Ic) const {
+    mat3vec(R, cL, cw);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) cw[k] = cw[k] + r[k];
+    // T = R * I_L (3x3), then Ic = T * R^T (symmetric)
+    const V I9[9] = {IL[0], IL[1], IL[2], IL[1], IL[3], IL[4], IL[2], IL[4], IL[5]};
+    V Tm[9];
+    mat3mul(R, I9, Tm);
+    Ic[0] = Tm[0] * R[0] + Tm[1] * R[1] + Tm[2] * R[2];
+    Ic[1] = Tm[0] * R[3] + Tm[1] * R[4] + Tm[2] * R[5];
+    Ic[2] = Tm[0] * R[6] + Tm[1] * R[7] + Tm[2] * R[8];
+    Ic[3] = Tm[3] * R[3] + Tm[4] * R[4] + Tm[5] * R[5];
+    Ic[4] = Tm[3] * R[6] + Tm[4] * R[7] + Tm[5] * R[8];
+    Ic[5] = Tm[6] * R[6] + Tm[7] * R[7] + Tm[8] * R[8];
+  }
+  // M = [[m I, m S(c)^T],[m S(c), I_c + m S(c) S(c)^T]]  (math/inertia.py:14-41), upper triangle
+  static JXS_HD void assemble_MA(const V& mass, const V* cw, const V* Ic, V* MA) {
+    const V zero = V(T(0));
+    const V mcx = mass * cw[0], mcy = mass * cw[1], mcz = mass * cw[2];
+    // top-left: m I
+    MA[sidx(0, 0)] = mass; MA[sidx(0, 1)] = zero; MA[sidx(0, 2)] = zero;
+    MA[sidx(1, 1)] = mass; MA[sidx(1, 2)] = zero;
+    MA[sidx(2, 2)] = mass;
+    // top-right: m S(c)^T = -m S(c) = [[0, mcz, -mcy],[-mcz, 0, mcx],[mcy, -mcx, 0]]
+    MA[sidx(0, 3)] = zero; MA[sidx(0, 4)] = mcz; MA[sidx(0, 5)] = -mcy;
+    MA[sidx(1, 3)] = -mcz; MA[sidx(1, 4)] = zero; MA[sidx(1, 5)] = mcx;
+    MA[sidx(2, 3)] = mcy; MA[sidx(2, 4)] = -mcx; MA[sidx(2, 5)] = zero;
+    // bottom-right: I_c + m (|c|^2 I - c c^T)
+    const V cc = cw[0] * cw[0] + cw[1] * cw[1] + cw[2] * cw[2];
+    MA[sidx(3, 3)] = Ic[0] + mass * (cc - cw[0] * cw[0]);
+    MA[sidx(3, 4)] = Ic[1] - mcx * cw[1];
+    MA[sidx(3, 5)] = Ic[2] - mcx * cw[2];
+    MA[sidx(4, 4)] = Ic[3] + mass * (cc - cw[1] * cw[1]);
+    MA[sidx(4, 5)] = Ic[4] - mcy * cw[2];
+    MA[sidx(5, 5)] = Ic[5] + mass * (cc - cw[2] * cw[2]);
+  }
+
   // Qdot = 1/2 Q_inertial(q) [K |w| (1 - |q|); w]   (math/quaternion.py:68-132), q normalised
   static JXS_HD void quat_derivative(const V* q, const V* w, const T K, V* qd) {
     const V nw = vsqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
@@ -1380,6 +1454,476 @@ struct Core {
         ai = ai + Sr[Lv] * sd;
         acar = vsel(has, ai, acar);
         ln.lds_write(rt.rec[Lv] + RL_SDD, sd, has && (row == 0));
+      }
+    }
+    sdd = ln.lds_read(rec_me + RL_SDD);
+  }
+
+  // ==========================================================================================
+  // Two-wave workgroups.  At the benchmark size half of the chip's SIMDs hold no wave and
+  // the step time is the length of ONE wave's instruction stream.  The articulated-INERTIA recursion of ABA pass 2
+  // (MA -> U = MA S -> d = S.U -> Ma = MA - U U^T / d, rbda/aba.py:184-224) depends on the joint positions only;
+  // the BIAS recursion (pA -> u = tau - S.pA -> pa = pA + Ma c + U u / d) on velocities and contact forces.  So a
+  // second wave on another SIMD of the CU -- the inertia wave -- runs forward kinematics and the inertia recursion
+  // while the main wave runs velocities, contacts and bias forces; per level it hands over row r of Ma, U_r and
+  // 1 / d through the LDS (XL), and the main wave's sweep carries one reduction and one propagated value per
+  // level instead of seven and seven.  The data flow is one way (inertia -> main), so the host emulation runs the
+  // two roles one after the other on the same LDS image.
+  // ==========================================================================================
+  JXS_HD void run_inertia() const {
+    const VI lane = ln.lane();
+    ln.stamp(A, 0);
+    ln.stamp_hwid(A, 11);
+    const VI jtype = ln.lconsti(A.lti, LI_JTYPE);
+    const VI level = ln.lconsti(A.lti, LI_LEVEL);
+    const VI jrow = ln.lconsti(A.lti, LI_JROW);
+    VI jump[kMaxRounds];
+#pragma unroll
+    for (int k = 0; k < kMaxRounds; ++k) jump[k] = ln.lconsti(A.lti, LI_JUMP + k);
+    V q[4];
+    const bool stage_base = G >= 16;  // (this wave always has its LDS area)
+    V base_stage = V(T(0));
+    if (stage_base) {
+      base_stage = ln.gload(A.state_in, vsel(lane < 4, lane, lane * 0) + P.row_quat, P.n_rows);  // one load: lane k < 4 = row k
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) q[k] = ln.gload_u(A.state_in, P.row_quat + k, P.n_rows);
+    }
+    V ax[3], Rpre[9], ppre[3], cL[3], IL[6];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) ax[k] = ln.lconstf(A.ltf, LF_AXIS + k);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Rpre[k] = ln.lconstf(A.ltf, LF_RPRE + k);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) ppre[k] = ln.lconstf(A.ltf, LF_PPRE + k);
+    const V mass = ln.lconstf(A.ltf, LF_MASS);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) cL[k] = ln.lconstf(A.ltf, LF_COM + k);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) IL[k] = ln.lconstf(A.ltf, LF_ICOM + k);
+    V Rsuc[9], psuc[3];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Rsuc[k] = ln.lconstf(A.ltf, LF_RSUC + k);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) psuc[k] = ln.lconstf(A.ltf, LF_PSUC + k);
+    RowTabs rt;
+    load_row_tabs(rt);
+    const VI jrow_c = vsel(jrow >= 0, jrow, lane * 0);
+    V s = ln.gload(A.state_in, jrow_c + P.row_s, P.n_rows);
+    ln.fence();
+    if (stage_base) {
+      ln.lds_write(lane, base_stage, lane < 4);
+      ln.lds_sync();
+      ln.template lds_readv<4>(lane * 0, q);
+      ln.lds_sync();
+    }
+    const VM is_joint = jtype != 0, is_rev = jtype == 1, is_pri = jtype == 2, is_root = level == 0;
+    s = vsel(is_joint, s, V(T(0)));
+    ln.stamp(A, 1);
+    V R[9], r[3], R0[9];
+    base_dcm(q, R0);
+    local_transform(is_rev, is_pri, is_root, s, ax, Rpre, ppre, Rsuc, psuc, R0, R, r);
+    ln.stamp(A, 2);
+    fk_prefix(jump, R, r);
+    ln.stamp(A, 3);
+    const bool anch = P.anchored != 0;
+    V ra[3] = {V(T(0)), V(T(0)), V(T(0))}, dpl[3] = {V(T(0)), V(T(0)), V(T(0))};
+    if (anch) {
+      const VI anchor = ln.lconsti(A.lti, LI_ANCHOR), panchor = ln.lconsti(A.lti, LI_PANCHOR);
+      V rq[3];
+#pragma unroll
+      for (int e = 0; e < 3; ++e) ra[e] = ln.shfl(r[e], anchor), rq[e] = ln.shfl(r[e], panchor);
+#pragma unroll
+      for (int e = 0; e < 3; ++e) dpl[e] = ra[e] - rq[e];
+    }
+    {  // hand the kinematics to the main wave
+      const V rec[kDuoFkRec] = {R[0], R[1], R[2], R[3], R[4], R[5], R[6], R[7], R[8], r[0], r[1], r[2], ra[0], ra[1], ra[2],
+                                dpl[0], dpl[1], dpl[2], V(T(0)), V(T(0))};
+      ln.template lds_writev<kDuoFkRec>(lane * kDuoFkRec + duo_fk_off(G), rec);
+      ln.flag_post(kDuoFlagFk);
+    }
+    ln.stamp(A, 4);
+    // motion subspace in C (kin_dyn_parameters.py:239-261), referred to the lane's anchor
+    V Sl[3], Sa[3], Ra_[3];
+    mat3vec(R, ax, Ra_);
+    {
+      V rxa[3];
+      cross(r, Ra_, rxa);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        Sa[k] = vsel(is_rev, Ra_[k], V(T(0)));
+        Sl[k] = vsel(is_rev, rxa[k], vsel(is_pri, Ra_[k], V(T(0))));
+      }
+    }
+    V cw[3], Ic[6];
+    link_inertia_C(R, r, cL, IL, cw, Ic);
+    if (anch) {
+      V t[3];
+      cross(ra, Sa, t);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) Sl[k] = Sl[k] - t[k], cw[k] = cw[k] - ra[k];
+    }
+    V MA[21];
+    assemble_MA(mass, cw, Ic, MA);
+    const V S6[6] = {Sl[0], Sl[1], Sl[2], Sa[0], Sa[1], Sa[2]};
+    ln.stamp(A, 6);
+    aba_rows_inertia(lane, rt, MA, S6, anch, dpl);
+    ln.stamp(A, 10);
+  }
+
+  // lane constants of the row layout shared by the two roles
+  struct RowLaneIdx {
+    VI row, row6, j1, j2, xsrc1, xsrc2;
+    VM rowok, is_ang, is_lin;
+  };
+  JXS_HD void row_lane_idx(const VI& lane, RowLaneIdx& o) const {
+    o.row = lane & 7;
+    o.rowok = o.row < 6;
+    o.row6 = vsel(o.rowok, o.row, lane * 0);
+    o.is_ang = (o.row >= 3) && o.rowok, o.is_lin = o.row < 3;
+    const VI jj = vsel(o.is_ang, o.row - 3, o.row);      // index within the linear / angular triple
+    o.j1 = vsel(jj == 2, lane * 0, jj + 1);              // (j + 1) % 3
+    o.j2 = vsel(jj == 0, lane * 0 + 2, jj - 1);          // (j + 2) % 3
+    const VI slot0 = lane - o.row;                       // first lane of this slot
+    o.xsrc1 = slot0 + o.j1, o.xsrc2 = slot0 + o.j2;      // linear rows (j+1)%3, (j+2)%3 of this slot
+  }
+  static JXS_HD V pick3(const V* d3, const VI& idx) { return vsel(idx == 0, d3[0], vsel(idx == 1, d3[1], d3[2])); }
+
+  // The inertia wave: aba_rows() without everything that depends on velocities or forces.
+  JXS_HD void aba_rows_inertia(const VI& lane, const RowTabs& rt, const V* MA, const V* S6, const bool anch, const V* dpl) const {
+    const V zero = V(T(0));
+    const VI rec_me = lane * kRowRec;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const V rw[8] = {MA[sidx(i, 0)], MA[sidx(i, 1)], MA[sidx(i, 2)], MA[sidx(i, 3)], MA[sidx(i, 4)], MA[sidx(i, 5)], zero, S6[i]};
+      ln.template lds_writev<8>(rec_me + (RL_ROW + 8 * i), rw);
+    }
+    {
+      const V sc[6] = {S6[0], S6[1], S6[2], S6[3], S6[4], S6[5]};
+      ln.template lds_writev<6>(rec_me + RL_S, sc);
+      const V td[4] = {zero, anch ? dpl[0] : zero, anch ? dpl[1] : zero, anch ? dpl[2] : zero};
+      ln.template lds_writev<4>(rec_me + RL_TAU, td);
+    }
+    {  // the all-zero record
+      const V z4[4] = {zero, zero, zero, zero};
+#pragma unroll
+      for (int k = 0; k < (kRowRec / 4 + G - 1) / G; ++k)
+        ln.template lds_writev_if<4>((lane + k * G) * 4 + lds_zero_rec(G), z4, lane + k * G < kRowRec / 4);
+    }
+    const int XB = G * kRowRec;
+    const int XL = duo_xl_off(G);
+    RowLaneIdx ix;
+    row_lane_idx(lane, ix);
+    const int max_depth = P.max_depth;
+    const unsigned cross_levels = ln.pin(P.row_cross_levels);
+    const unsigned pull_counts = ln.pin(P.row_pull_counts);
+    const int floating = ln.pin(P.floating);
+    struct Lvl {
+      V Mrow[6], S[6], S_r, dp[3];
+    };
+    auto load_level = [&](const VI& rec, Lvl& o) {
+      V rw[8], sc[6], td[4];
+      ln.template lds_readv<8>(rec + ix.row6 * 8, rw);
+      ln.template lds_readv<6>(rec + RL_S, sc);
+      ln.template lds_readv<4>(rec + RL_TAU, td);
+#pragma unroll
+      for (int j = 0; j < 6; ++j) o.Mrow[j] = rw[j], o.S[j] = sc[j];
+      o.S_r = rw[RL_ROW_S];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) o.dp[k] = td[1 + k];
+    };
+    V accM[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) accM[j] = zero;
+    Lvl cur, nxt;
+    load_level(rt.rec[kRowLevels - 1], cur);
+#pragma unroll
+    for (int Lv = kRowLevels - 1; Lv >= 0; --Lv) {
+      if (Lv >= 1) load_level(rt.rec[Lv - 1], nxt);
+      if (Lv <= max_depth && (Lv >= 1 || floating)) {
+        const VM has = rt.rec[Lv] != lds_zero_rec(G);
+        V MArow[6];
+        if (!L::add6_packed(cur.Mrow, accM, MArow)) {
+#pragma unroll
+          for (int j = 0; j < 6; ++j) MArow[j] = cur.Mrow[j] + accM[j];
+        }
+        if (Lv == 0) {
+          // the articulated base inertia: its rows meet in the LDS, every lane factorises the same 6x6 (LDL^T) and
+          // lane 0 leaves the factor for the main wave's base solve (which then is two substitutions)
+          const V rw[8] = {MArow[0], MArow[1], MArow[2], MArow[3], MArow[4], MArow[5], zero, zero};
+          ln.template lds_writev_if<8>(ix.row6 * 8 + XB, rw, lane < 6);
+          ln.lds_sync();
+          V MAs[21];
+          const VI z = lane * 0;
+#pragma unroll
+          for (int i = 0; i < 6; ++i) {
+            V r8[8];
+            ln.template lds_readv<8>(z + (XB + 8 * i), r8);
+#pragma unroll
+            for (int j = i; j < 6; ++j) MAs[sidx(i, j)] = r8[j];
+          }
+          ln.lds_sync();
+          TreeFac tf;
+          ldl6_factor(MAs, tf, true);
+          const V fac[24] = {tf.Lm[0], tf.Lm[1], tf.Lm[2], tf.Lm[3], tf.Lm[4], tf.Lm[5], tf.Lm[6], tf.Lm[7], tf.Lm[8], tf.Lm[9], tf.Lm[10], tf.Lm[11],
+                             tf.Lm[12], tf.Lm[13], tf.Lm[14], tf.Di[0], tf.Di[1], tf.Di[2], tf.Di[3], tf.Di[4], tf.Di[5], zero, zero, zero};
+          ln.template lds_writev_if<24>(z + XB, fac, lane == 0);
+        } else {
+          const V S_r = cur.S_r;
+          V U[6];
+          if (!L::scale6_packed(MArow, S_r, U)) {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) U[j] = MArow[j] * S_r;
+          }
+          ln.allreduce8x6(U);
+          V U_r, d;
+          if (!(L::dot6_packed(MArow, cur.S, &U_r) && L::dot6_packed(cur.S, U, &d))) {
+            U_r = MArow[0] * cur.S[0], d = cur.S[0] * U[0];
+#pragma unroll
+            for (int j = 1; j < 6; ++j) {
+              U_r = U_r + MArow[j] * cur.S[j];
+              d = d + cur.S[j] * U[j];
+            }
+          }
+          const V inv = vsel(has, vrcp_acc(vsel(has, d, V(T(1)))), zero);
+          const V Ud = U_r * inv;
+          V Ma[6];
+          if (!L::axpy6_packed(MArow, -Ud, U, Ma)) {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) Ma[j] = MArow[j] - Ud * U[j];
+          }
+          {
+            const V xl[8] = {Ma[0], Ma[1], Ma[2], Ma[3], Ma[4], Ma[5], U_r, inv};
+            ln.template lds_writev<8>((lane + Lv * G) * kDuoXlRec + XL, xl);
+          }
+          if (Lv >= 2 || floating) {
+            if (anch && ((cross_levels >> Lv) & 1u)) {
+              V d3[3];
+#pragma unroll
+              for (int k = 0; k < 3; ++k) d3[k] = cur.dp[k];
+              {  // row[3:6] -= row[0:3] x d
+                const V t0 = Ma[1] * d3[2] - Ma[2] * d3[1], t1 = Ma[2] * d3[0] - Ma[0] * d3[2], t2 = Ma[0] * d3[1] - Ma[1] * d3[0];
+                Ma[3] = Ma[3] - t0, Ma[4] = Ma[4] - t1, Ma[5] = Ma[5] - t2;
+              }
+              const V c1 = vsel(ix.is_ang, pick3(d3, ix.j1), zero);
+              const V c2 = vsel(ix.is_ang, -pick3(d3, ix.j2), zero);
+              V g1[6], g2[6];
+#pragma unroll
+              for (int j = 0; j < 6; ++j) g1[j] = ln.shfl(Ma[j], ix.xsrc1), g2[j] = ln.shfl(Ma[j], ix.xsrc2);
+              ln.fence();
+#pragma unroll
+              for (int j = 0; j < 6; ++j) Ma[j] = Ma[j] + c1 * g2[j] + c2 * g1[j];
+            }
+            const VM fc = ((rt.fcbits >> Lv) & 1) != 0;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) accM[j] = vsel(fc, Ma[j], zero);
+            if ((cross_levels >> Lv) & 1u) {
+              const int npull = (int)((pull_counts >> (4 * Lv)) & 15u);
+#pragma unroll
+              for (int k = 0; k < kRowExtra; ++k) {
+                if (k >= npull) break;
+                const VI src = rt.pull[Lv][k];
+                const VM ok = src >= 0;
+                V g[6];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) g[j] = ln.shfl(Ma[j], src);
+                ln.fence();
+#pragma unroll
+                for (int j = 0; j < 6; ++j) accM[j] = accM[j] + vsel(ok, g[j], zero);
+              }
+            }
+          }
+        }
+        ln.flag_post(kDuoFlagFk + kRowLevels - Lv);  // level Lv (and every deeper one) is in the LDS
+      }
+      cur = nxt;
+      ln.stamp(A, 24 + Lv);
+    }
+    ln.stamp(A, 7);
+  }
+
+  // The main wave's side of passes 2 and 3: bias recursion with the rows of Ma, U_r and 1 / d taken from XL.
+  JXS_HD void aba_rows_main(const VI& lane, const RowTabs& rt, const V* pA, const V* S6, const V* c6, const V& tau,
+                            const bool anch, const V* dpl, V& sdd, V* a0) const {
+    const V zero = V(T(0));
+    constexpr int AR = duo_main_off(G);  // this wave's LDS area
+    const VI rec_me = lane * kRowRec + AR;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const V ps[2] = {pA[i], S6[i]};
+      ln.template lds_writev<2>(rec_me + (RL_ROW + 8 * i + RL_ROW_PA), ps);
+    }
+    {
+      const V sc[12] = {S6[0], S6[1], S6[2], S6[3], S6[4], S6[5], c6[0], c6[1], c6[2], c6[3], c6[4], c6[5]};
+      ln.template lds_writev<12>(rec_me + RL_S, sc);
+      const V td[4] = {tau, anch ? dpl[0] : zero, anch ? dpl[1] : zero, anch ? dpl[2] : zero};
+      ln.template lds_writev<4>(rec_me + RL_TAU, td);
+    }
+    ln.lds_write(rec_me + RL_SDD, zero);
+    {  // the all-zero record of this area
+      const V z4[4] = {zero, zero, zero, zero};
+#pragma unroll
+      for (int k = 0; k < (kRowRec / 4 + G - 1) / G; ++k)
+        ln.template lds_writev_if<4>((lane + k * G) * 4 + (lds_zero_rec(G) + AR), z4, lane + k * G < kRowRec / 4);
+    }
+    const int XB = G * kRowRec;  // base rows: the inertia wave's area holds the inertia, this area the bias force
+    const int XL = duo_xl_off(G);
+    RowLaneIdx ix;
+    row_lane_idx(lane, ix);
+    const int max_depth = P.max_depth;
+    const unsigned cross_levels = ln.pin(P.row_cross_levels);
+    const unsigned ppull_levels = ln.pin(P.row_ppull_levels);
+    const unsigned pull_counts = ln.pin(P.row_pull_counts);
+    const int floating = ln.pin(P.floating);
+    struct Lvl {
+      V pr, S_r, c_r, c[6], tau, dp[3];
+    };
+    auto load_level = [&](const VI& rec0, Lvl& o) {
+      const VI rec = rec0 + AR;
+      V ps[2], sc[8], td[4];
+      ln.template lds_readv<2>(rec + ix.row6 * 8 + RL_ROW_PA, ps);
+      ln.template lds_readv<8>(rec + (RL_C - 2), sc);  // {S4, S5, c0..c5}: two aligned 128-bit reads
+      ln.template lds_readv<4>(rec + RL_TAU, td);
+      o.c_r = ln.lds_read(rec + ix.row6 + RL_C);
+      o.pr = ps[0], o.S_r = ps[1];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) o.c[j] = sc[2 + j];
+      o.tau = td[0];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) o.dp[k] = td[1 + k];
+    };
+    V Ur[kRowLevels], Sr[kRowLevels], cr[kRowLevels], invd[kRowLevels], uu[kRowLevels];
+    V accp = zero, p0 = zero;
+    V dkeep[kRowLevels][3];
+    Lvl cur, nxt;
+    load_level(rt.rec[kRowLevels - 1], cur);
+    V xl_next[8];
+    bool xl_ahead = false;  // (wave-uniform)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) xl_next[j] = zero;
+#pragma unroll
+    for (int Lv = kRowLevels - 1; Lv >= 0; --Lv) {
+      Ur[Lv] = zero, Sr[Lv] = zero, cr[Lv] = zero, invd[Lv] = zero, uu[Lv] = zero;
+      if (Lv >= 1) load_level(rt.rec[Lv - 1], nxt);
+      if (Lv <= max_depth && (Lv >= 1 || floating)) {
+        const V pr = cur.pr + accp;
+        if (Lv == 0) {
+          p0 = pr;
+        } else {
+          // what the inertia wave handed over for this level: already here when the previous level found it
+          // published (the progress word is only read again when the last value seen does not cover the level)
+          V xl[8];
+          if (xl_ahead) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xl[j] = xl_next[j];
+          } else {
+            ln.flag_wait(kDuoFlagFk + kRowLevels - Lv, duo_seen_);
+            ln.template lds_readv<8>((lane + Lv * G) * kDuoXlRec + XL, xl);
+          }
+          xl_ahead = false;
+          if (Lv >= 2 && duo_seen_ >= kDuoFlagFk + kRowLevels - (Lv - 1)) {
+            ln.template lds_readv<8>((lane + (Lv - 1) * G) * kDuoXlRec + XL, xl_next);
+            xl_ahead = true;
+          }
+          const V S_r = cur.S_r;
+          const V sp = ln.allreduce8(S_r * pr);
+          const V u = cur.tau - sp;
+          const V U_r = xl[6], inv = xl[7];
+          const V Ud = U_r * inv;
+          V pa = pr + Ud * u;
+          {
+            V t;
+            if (L::dot6_packed(xl, cur.c, &t)) {
+              pa = pa + t;
+            } else {
+#pragma unroll
+              for (int j = 0; j < 6; ++j) pa = pa + xl[j] * cur.c[j];
+            }
+          }
+          Ur[Lv] = U_r, Sr[Lv] = S_r, cr[Lv] = cur.c_r, invd[Lv] = inv, uu[Lv] = u;
+          if (Lv >= 2 || floating) {
+            if (anch && ((cross_levels >> Lv) & 1u)) {
+              V d3[3];
+#pragma unroll
+              for (int k = 0; k < 3; ++k) d3[k] = cur.dp[k], dkeep[Lv][k] = d3[k];
+              const V c1 = vsel(ix.is_ang, pick3(d3, ix.j1), zero);
+              const V c2 = vsel(ix.is_ang, -pick3(d3, ix.j2), zero);
+              const V g1 = ln.shfl(pa, ix.xsrc1), g2 = ln.shfl(pa, ix.xsrc2);
+              ln.fence();
+              pa = pa + c1 * g2 + c2 * g1;
+            }
+            const VM fc = ((rt.fcbits >> Lv) & 1) != 0;
+            accp = vsel(fc, pa, zero);
+            if ((cross_levels >> Lv) & 1u) {
+              const int npull = (int)((pull_counts >> (4 * Lv)) & 15u);
+#pragma unroll
+              for (int k = 0; k < kRowExtra; ++k) {
+                if (k >= npull) break;
+                const VI src = rt.pull[Lv][k];
+                const VM ok = src >= 0;
+                const V g = ln.shfl(pa, src);
+                ln.fence();
+                accp = accp + vsel(ok, g, zero);
+              }
+            }
+          }
+        }
+      }
+      cur = nxt;
+      ln.stamp(A, 24 + Lv);
+    }
+    ln.stamp(A, 7);  // pass 2 (bias recursion)
+    // ---- base acceleration (rbda/aba.py:240-243) --------------------------------------------
+    if (floating) {
+      ln.lds_write(ix.row6 + (XB + AR), p0, lane < 6);
+      ln.lds_sync();
+      ln.flag_wait(kDuoFlagFk + kRowLevels, duo_seen_);  // the factor of the articulated base inertia is in the inertia wave's area
+      const VI z = lane * 0;
+      V fac[24], pAs[8];
+      ln.template lds_readv<24>(z + XB, fac);
+      ln.template lds_readv<8>(z + (XB + AR), pAs);
+      TreeFac tf;
+#pragma unroll
+      for (int k = 0; k < 15; ++k) tf.Lm[k] = fac[k];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) tf.Di[k] = fac[15 + k];
+      V rhs[6] = {pAs[0], pAs[1], pAs[2], pAs[3], pAs[4], pAs[5]};
+      ldl6_solve_neg(tf, rhs, a0);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) a0[k] = zero;
+      a0[2] = V(-P.g);
+    }
+    ln.stamp(A, 8);  // base solve
+    // ---- pass 3, base to leaves (rbda/aba.py:251-267): as in aba_rows -----------------------------
+    V acar = vsel(ix.row == 0, a0[0], vsel(ix.row == 1, a0[1], vsel(ix.row == 2, a0[2],
+             vsel(ix.row == 3, a0[3], vsel(ix.row == 4, a0[4], vsel(ix.row == 5, a0[5], zero))))));
+#pragma unroll
+    for (int Lv = 1; Lv < kRowLevels; ++Lv) {
+      if (Lv <= max_depth) {
+        const VM has = rt.rec[Lv] != lds_zero_rec(G);
+        V apar = acar;
+        if ((ppull_levels >> Lv) & 1u) {
+          const VM pulled = rt.ppull[Lv] >= 0;
+          const V q = ln.shfl(acar, rt.ppull[Lv]);
+          if (anch) {
+            const VI pslot = vsel(pulled, rt.ppull[Lv] - ix.row, lane * 0);
+            const V al1 = ln.shfl(acar, pslot + 3 + ix.j1), al2 = ln.shfl(acar, pslot + 3 + ix.j2);
+            ln.fence();
+            const V* d3 = dkeep[Lv];
+            const V sh = al1 * pick3(d3, ix.j2) - al2 * pick3(d3, ix.j1);
+            apar = vsel(pulled, q + vsel(ix.is_lin, sh, zero), acar);
+          } else {
+            ln.fence();
+            apar = vsel(pulled, q, acar);
+          }
+        }
+        V ai = apar + cr[Lv];
+        const V tot = ln.allreduce8(Ur[Lv] * ai);
+        const V sd = (uu[Lv] - tot) * invd[Lv];
+        ai = ai + Sr[Lv] * sd;
+        acar = vsel(has, ai, acar);
+        ln.lds_write(rt.rec[Lv] + (RL_SDD + AR), sd, has && (ix.row == 0));
       }
     }
     sdd = ln.lds_read(rec_me + RL_SDD);
@@ -1787,6 +2331,8 @@ struct Core {
   // factorisation (pass 2 above: U, 1/d, the LDL^T of the articulated base inertia) to the unit generalized
   // force e_c -- a unit wrench on the base link for c < 6, a unit joint torque otherwise -- three columns per
   // sweep.  Like the mass-matrix kernel the result is in MIXED representation (frame C); out_a = [(6+n)^2][N].
+  // As in the reference the base link is a free body for EVERY model -- fixed-base ones too -- so the result is
+  // the inverse of the full (6+n) free-floating mass matrix and its joint block the Schur-complement inverse.
   JXS_HD void mass_inverse(const VI& lane, const VI& level, const VI& parent, const VI* child, const VI& jrow,
                            const VM& is_joint, const VM& is_root, const V* MA, const V* U, const V* S6,
                            const V& inv_d) const {
@@ -1794,7 +2340,7 @@ struct Core {
 #pragma unroll
     for (int k = 0; k < 6; ++k) tf.U[k] = U[k], tf.S6[k] = S6[k];
     tf.inv_d = inv_d;
-    if (P.floating) ldl6_factor(MA, tf);
+    ldl6_factor(MA, tf);  // the base is a free 6-DoF body for every model here (D0 = I_A[0], mass_inverse.py:160-166)
     const int nv = 6 + P.n, rows = nv * nv;
     const VI zl = lane * 0;
     const V zero = V(T(0)), one = V(T(1));
@@ -1807,14 +2353,13 @@ struct Core {
         for (int i = 0; i < 6; ++i) pAr[r][i] = vsel(is_root && (zl + c == i), -one, zero);  // pA = -wrench
         taur[r] = vsel(is_joint && (jrow + 6 == zl + c), one, zero);
       }
-      response<3>(lane, level, parent, child, tf, pAr, ar, sddr, taur);
+      response<3>(lane, level, parent, child, tf, pAr, ar, sddr, taur, 1);
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
         const int c = c0 + r;
         if (c < nv) {
-          // a fixed base does not accelerate (rbda/aba.py:284-292): its six rows stay zero
 #pragma unroll
-          for (int i = 0; i < 6; ++i) ln.gstore(A.out_a, zl + (i * nv + c), ar[r][i], is_root && (P.floating != 0), rows);
+          for (int i = 0; i < 6; ++i) ln.gstore(A.out_a, zl + (i * nv + c), ar[r][i], is_root, rows);
           ln.gstore(A.out_a, (jrow + 6) * nv + c, sddr[r], is_joint, rows);
         }
       }

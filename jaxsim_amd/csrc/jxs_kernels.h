@@ -72,7 +72,13 @@ __global__ __launch_bounds__(64, VARIANT == KV_OCC2 ? 2 : 1) void jxs_kernel(con
 #ifdef JXS_SPEC_ASSIGN
   // model-specialised build (jxs_spec.hip): the integer model flags are compile-time constants from here on
   JXS_SPEC_ASSIGN;
+  constexpr bool kFlagsKnown = true;
+#else
+  constexpr bool kFlagsKnown = VARIANT == KV_COMMON;
 #endif
+  // (launch_one allocates the LDS area of the row layout for exactly these modes when P.row_mode is set; only where
+  // that flag is a compile-time constant, so that the first loads of the generic kernel need no scalar load)
+  A.has_lds = (kFlagsKnown && P.row_mode && (MODE == jxs::MODE_STEP || MODE == jxs::MODE_ROLLOUT || MODE == jxs::MODE_FD || MODE == jxs::MODE_STEP_RK4)) ? 1 : 0;
   extern __shared__ __align__(16) unsigned char jxs_smem[];
   const jxs::DeviceLanes<T, G> ln(A.N, reinterpret_cast<T*>(jxs_smem),
                                   (MODE == jxs::MODE_STEP_RIGID || MODE == jxs::MODE_STEP_RK4_RIGID) ? jxs::rigid_lds_words_per_env(P.n_cp, P.rigid)
@@ -80,6 +86,48 @@ __global__ __launch_bounds__(64, VARIANT == KV_OCC2 ? 2 : 1) void jxs_kernel(con
   jxs::Core<jxs::DeviceLanes<T, G>> core(P, A, ln);
   core.template run<MODE>();
 }
+
+// Two-wave workgroups (jxs_core.h, "Two-wave workgroups"): a main wave and an inertia wave work on the same
+// 64 / G environments; a workgroup holds two such pairs (see DeviceLanes: even placement).  Picked by the launcher for the soft-contact step of row-layout models while the grid
+// leaves SIMDs idle (one wave per workgroup fills at most blocks of the chip's 1024 SIMDs).
+template <typename T, int G, int MODE>
+__global__ __launch_bounds__(256, 1) void jxs_kernel_duo(const T* pre_state_in, T* pre_state_out, const unsigned char* __restrict__ pre_mblk,
+                                                       const T* pre_tau, const T* pre_link_f, int pre_N, int pre_n_rows,
+                                                       int pre_n, int pre_force_repr, int pre_n_steps,
+                                                       const KTail<T> tail) {
+  jxs::KParams<T> P = *reinterpret_cast<const jxs::KParams<T>*>(pre_mblk);
+  jxs::KArgs<T> A{};
+  A.state_in = pre_state_in, A.state_out = pre_state_out, A.tau = pre_tau, A.link_f = pre_link_f;
+  A.N = pre_N, A.force_repr = pre_force_repr, A.n_steps = pre_n_steps;
+  A.ltf = reinterpret_cast<const T*>(pre_mblk + jxs::mblk_off_ltf<T>());
+  A.lti = reinterpret_cast<const int*>(pre_mblk + jxs::mblk_off_lti<T>(G));
+  A.rti = reinterpret_cast<const int*>(pre_mblk + jxs::mblk_off_rti<T>(G));
+  A.chunks = pre_mblk + jxs::mblk_off_chunks<T>(G);
+  A.in_a = tail.in_a, A.out_a = tail.out_a, A.out_H = tail.out_H, A.out_V = tail.out_V, A.out_tau = tail.out_tau;
+  A.id_zero_vel = tail.id_zero_vel, A.dbg = tail.dbg, A.faults = tail.faults;
+  P.n_rows = pre_n_rows, P.n = pre_n;
+  P.row_pos = 0, P.row_quat = 3, P.row_s = 7, P.row_vlin = 7 + pre_n, P.row_vang = 10 + pre_n, P.row_sd = 13 + pre_n;
+  P.row_m = 13 + 2 * pre_n;
+  // the launcher picks this kernel only for models with exactly these features
+  P.row_mode = 1, P.rigid = 0, P.rk4fast = 0;
+  A.has_lds = 1;
+#ifdef JXS_SPEC_ASSIGN
+  JXS_SPEC_ASSIGN;
+#endif
+  extern __shared__ __align__(16) unsigned char jxs_smem[];
+  // four waves = two pairs (main, inertia) on consecutive tiles; the second pair of the last workgroup may be empty
+  const jxs::DeviceLanes<T, G> ln(A.N, reinterpret_cast<T*>(jxs_smem), jxs::duo_words_per_env(G), true);
+  const bool inertia_wave = (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) & 1) != 0;
+  ln.flag_reset_and_barrier(inertia_wave);
+  if (__builtin_amdgcn_readfirstlane(ln.blk_) * (64 / G) >= A.N) return;
+  jxs::Core<jxs::DeviceLanes<T, G>> core(P, A, ln);
+  if (inertia_wave)
+    core.run_inertia();
+  else
+    core.template run<MODE, jxs::ROLE_MAIN>();
+}
+template <typename T>
+inline size_t duo_lds_bytes(int G) { return 2 * sizeof(T) * ((size_t)(64 / G) * jxs::duo_words_per_env(G) + jxs::kDuoFlagWords); }
 
 // `mblk`: device model block of the model (KParams | tables), `P`: its host copy (launch geometry only)
 template <typename T, int G, int MODE>
@@ -103,6 +151,29 @@ hipError_t launch_one(const jxs::KParams<T>& P, const unsigned char* mblk, const
     if (kHasOcc2 && blocks > 1024 && lds_bytes * 8 <= 160 * 1024 && P.n_cp <= 8) {
       hipLaunchKernelGGL((jxs_kernel<T, G, MODE, kHasOcc2 ? KV_OCC2 : KV_GENERIC>), dim3(blocks), dim3(64), lds_bytes, s, A.state_in, A.state_out, mblk,
                          A.tau, A.link_f, A.N, P.n_rows, P.n, A.force_repr, A.n_steps, tail);
+      return hipGetLastError();
+    }
+  }
+  // Two-wave workgroups while one wave per workgroup would leave SIMDs idle (at most 1024 workgroups: 256 CUs x 4
+  // SIMDs; beyond that the duplicated kinematics cost throughput).  JXS_DUO=0 / 1 forces the choice (developer A/B).
+  if constexpr (MODE == jxs::MODE_STEP && G >= 8) {
+    // (read per launch, not cached: the tests switch it between launches; a replayed hipGraph keeps what it captured)
+    const char* const duo_e = std::getenv("JXS_DUO");
+    const char* const duo_b = std::getenv("JXS_DUO_MAX_BLOCKS");
+    const int duo_env = duo_e == nullptr ? -1 : std::atoi(duo_e);
+    const int duo_max_blocks = duo_b == nullptr ? 1024 : std::atoi(duo_b);
+    const bool fits = P.row_mode == 1 && P.rigid == 0 && P.n_chunks <= 1 && duo_lds_bytes<T>(G) <= (size_t)160 * 1024;
+    if (fits && duo_env != 0 && (duo_env > 0 || blocks <= duo_max_blocks)) {
+      const size_t bytes = duo_lds_bytes<T>(G);
+      static bool attr_set = false;
+      if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&jxs_kernel_duo<T, G, MODE>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+      }
+      hipLaunchKernelGGL((jxs_kernel_duo<T, G, MODE>), dim3((blocks + 1) / 2), dim3(256), bytes, s, A.state_in, A.state_out, mblk, A.tau,
+                         A.link_f, A.N, P.n_rows, P.n, A.force_repr, A.n_steps, tail);
       return hipGetLastError();
     }
   }

@@ -153,15 +153,62 @@ struct DeviceLanes {
   bool env_ok_;
   int N_;
   T* lds_;      // LDS scratch of this environment (row-distributed ABA), else unused
+  int* flag_;   // two-wave workgroups: progress word of the inertia wave (behind the environments' areas), else null
 
-  __device__ __forceinline__ DeviceLanes(int N, T* lds_base, int lds_words_per_env) : N_(N) {
+  int blk_;     // tile of every batched array this wave works on (= blockIdx.x for single-wave workgroups)
+  int wslot_;   // developer profiling build: stamp column block of this wave (the inertia wave stamps at +32)
+
+  // `duo`: two-wave workgroups -- a workgroup of four waves holds TWO pairs (waves 0, 1: main and inertia wave of tile
+  // 2 b; waves 2, 3: of tile 2 b + 1), each pair with its own LDS region and progress word.  Four-wave workgroups
+  // because the dispatcher spreads 256 of them evenly over the chip (one wave per SIMD), while 512 two-wave
+  // workgroups land unevenly (measured: tools/ubench/cu_share.hip).
+  __device__ __forceinline__ DeviceLanes(int N, T* lds_base, int lds_words_per_env, bool duo = false) : N_(N) {
     const int wl = threadIdx.x & 63;
     lane_ = wl & (G - 1);
     base4_ = (wl & ~(G - 1)) << 2;
-    env_ = blockIdx.x * (64 / G) + (wl / G);
+    const int pair = duo ? (int)(threadIdx.x >> 7) : 0;
+    blk_ = duo ? (int)blockIdx.x * 2 + pair : (int)blockIdx.x;
+    wslot_ = duo ? (int)((threadIdx.x >> 6) & 1) * 32 : 0;
+    env_ = blk_ * (64 / G) + (wl / G);
     env_ok_ = env_ < N;
     sub_ = wl / G;
-    lds_ = lds_base + sub_ * lds_words_per_env;
+    T* const pair_base = lds_base + (size_t)pair * ((64 / G) * lds_words_per_env + kDuoFlagWords);
+    lds_ = pair_base + sub_ * lds_words_per_env;
+    flag_ = duo ? reinterpret_cast<int*>(pair_base + (64 / G) * lds_words_per_env) : nullptr;
+  }
+
+  // ---- two-wave workgroups (jxs_core.h, run_inertia / aba_rows_main): one-way hand-over through the LDS.
+  // The inertia wave publishes data with ordinary ds_write and then the number of finished levels with a
+  // release store; the main wave polls that word (acquire) before it reads.  The DS queue of a CU executes the
+  // operations of one wave in order, so a reader that sees the count sees the data.  The poll is bounded: a
+  // missing publisher must never hang the GPU (the result is then wrong and the parity tests say so).
+  __device__ __forceinline__ void flag_reset_and_barrier(bool publisher) const {
+    if (publisher) {
+      __hip_atomic_store(flag_, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+  }
+  // (wavefront-scope fences are compiler barriers only: no s_waitcnt is needed between LDS operations of one
+  // wave, and a workgroup-scope release would cost the publisher an exposed LDS round trip per level)
+  __device__ __forceinline__ void flag_post(int value) const {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_sched_barrier(0);
+    __hip_atomic_store(flag_, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // `seen`: the last value read (the publisher only counts up): no LDS round trip when it already covers `need`
+  __device__ __forceinline__ void flag_wait(int need, int& seen) const {
+    if (seen >= need) return;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+    for (int spin = 0; spin < (1 << 18); ++spin) {
+      seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(flag_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+      if (seen >= need) break;
+      __builtin_amdgcn_s_sleep(1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_sched_barrier(0);
   }
 
   __device__ __forceinline__ VI lane() const { return lane_; }
@@ -174,7 +221,7 @@ struct DeviceLanes {
   __device__ __forceinline__ void stamp(const KA& A, int i) const {
 #ifdef JXS_PHASE_TIMING
     __builtin_amdgcn_sched_barrier(0);
-    if (A.dbg != nullptr && threadIdx.x == 0) A.dbg[(size_t)blockIdx.x * kDbgSlots + i] = (long long)__builtin_readcyclecounter();
+    if (A.dbg != nullptr && (threadIdx.x & 63) == 0) A.dbg[(size_t)blk_ * kDbgSlots + wslot_ + i] = (long long)__builtin_readcyclecounter();
     __builtin_amdgcn_sched_barrier(0);
 #else
     (void)A;
@@ -182,11 +229,21 @@ struct DeviceLanes {
 #endif
   }
 
+  // developer profiling build: slot `i` = where this wave runs (HW_ID | XCC_ID << 16)
+  template <class KA>
+  __device__ __forceinline__ void stamp_hwid(const KA& A, int i) const {
+#ifdef JXS_PHASE_TIMING
+    const unsigned id = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4), xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);
+    if (A.dbg != nullptr && (threadIdx.x & 63) == 0) A.dbg[(size_t)blk_ * kDbgSlots + wslot_ + i] = (long long)(id | (xcc << 16));
+#else
+    (void)A, (void)i;
+#endif
+  }
   // developer profiling build: slot `i` = max over the lanes / calls of `value` (iteration counts)
   template <class KA>
   __device__ __forceinline__ void debug_max(const KA& A, int i, int value) const {
 #ifdef JXS_PHASE_TIMING
-    if (A.dbg != nullptr) atomicMax(reinterpret_cast<unsigned long long*>(&A.dbg[(size_t)blockIdx.x * kDbgSlots + i]), (unsigned long long)value);
+    if (A.dbg != nullptr) atomicMax(reinterpret_cast<unsigned long long*>(&A.dbg[(size_t)blk_ * kDbgSlots + i]), (unsigned long long)value);
 #else
     (void)A, (void)i, (void)value;
 #endif
@@ -291,6 +348,29 @@ struct DeviceLanes {
     asm volatile("s_nop 1\n\t" JXS_DPP7("quad_perm:[1,0,3,2]") JXS_DPP7("quad_perm:[2,3,0,1]") JXS_DPP7("row_half_mirror")
                  : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]));
 #undef JXS_DPP7
+  }
+  // six reductions (the inertia wave of a two-wave workgroup: U = MA S without the bias entry)
+  __device__ __forceinline__ void allreduce8x6(float* x) const {
+#define JXS_DPP6(CTRL)                                                                                       \
+  "v_add_f32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                           \
+  "v_add_f32_dpp %1, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                           \
+  "v_add_f32_dpp %2, %2, %2 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                           \
+  "v_add_f32_dpp %3, %3, %3 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                           \
+  "v_add_f32_dpp %4, %4, %4 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                           \
+  "v_add_f32_dpp %5, %5, %5 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+    asm volatile("s_nop 1\n\t" JXS_DPP6("quad_perm:[1,0,3,2]") JXS_DPP6("quad_perm:[2,3,0,1]") JXS_DPP6("row_half_mirror")
+                 : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]));
+#undef JXS_DPP6
+  }
+  __device__ __forceinline__ void allreduce8x6(double* x) const {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) x[k] = x[k] + dpp<0xB1>(x[k]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) x[k] = x[k] + dpp<0x4E>(x[k]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) x[k] = x[k] + dpp<0x141>(x[k]);
   }
   __device__ __forceinline__ void allreduce8x7(double* x) const {
 #pragma unroll
@@ -422,8 +502,9 @@ struct DeviceLanes {
   template <typename U>
   static __device__ __forceinline__ const U* al16(const U* p) { return static_cast<const U*>(__builtin_assume_aligned(p, 16)); }
   __device__ __forceinline__ V lconstf(const T* tbl, int field) const { return al16(tbl)[lane_ * kLtfStride + field]; }
-  __device__ __forceinline__ VI lconsti(const int* tbl, int field) const { return al16(tbl)[lane_ * kLtiStride + field]; }
-  __device__ __forceinline__ VI rconsti(const int* tbl, int field) const { return al16(tbl)[lane_ * kRtiStride + field]; }
+  // packed integer tables (jxs_params.h: lti_get / rti_get): the dword loads of one record merge into 128-bit loads
+  __device__ __forceinline__ VI lconsti(const int* tbl, int field) const { return lti_get(al16(tbl) + lane_ * kLtiPackWords, field); }
+  __device__ __forceinline__ VI rconsti(const int* tbl, int field) const { return rti_get(al16(tbl) + lane_ * kRtiPackWords, field); }
   __device__ __forceinline__ VI hconsti(const int* head, int chunk) const { return head[chunk * G + lane_]; }
   // per-slot point tables (slot-major, stride 4)
   __device__ __forceinline__ V ploadf(const T* tbl, int field, int slot) const { return al16(tbl)[slot * kPtStride + field]; }
@@ -436,7 +517,7 @@ struct DeviceLanes {
   // so the environments beyond N of the last tile are readable (their stores are masked).
   static constexpr int TILE = 64 / G;
   __device__ __forceinline__ size_t at(int row, int nrows) const {
-    return ((size_t)blockIdx.x * nrows + row) * TILE + sub_;
+    return ((size_t)blk_ * nrows + row) * TILE + sub_;
   }
   __device__ __forceinline__ V gload(const T* base, int row, int nrows) const { return base[at(row, nrows)]; }
   __device__ __forceinline__ V gload_u(const T* base, int row, int nrows) const { return base[at(row, nrows)]; }

@@ -21,7 +21,8 @@ struct Packed {
   KParams<T> P;
   int G = 0;
   std::vector<T> ltf;
-  std::vector<int> lti;
+  std::vector<int> lti;   // staging, one int per field: [G][kLtiStride]
+  std::vector<int> lti_packed, rti_packed;  // what the kernels read (jxs_params.h: lti_get / rti_get)
   std::vector<T> ptf;     // [slots][kPtStride]   (staging: the kernels read `chunks`)
   std::vector<int> pti;   // [slots][kPtStride]
   std::vector<int> head;  // [chunks][G]
@@ -32,8 +33,8 @@ struct Packed {
     std::vector<unsigned char> b((size_t)mblk_off_chunks<T>(G) + chunks.size(), 0);
     std::memcpy(b.data(), &P, sizeof(P));
     std::memcpy(b.data() + mblk_off_ltf<T>(), ltf.data(), ltf.size() * sizeof(T));
-    std::memcpy(b.data() + mblk_off_lti<T>(G), lti.data(), lti.size() * sizeof(int));
-    std::memcpy(b.data() + mblk_off_rti<T>(G), rti.data(), rti.size() * sizeof(int));
+    std::memcpy(b.data() + mblk_off_lti<T>(G), lti_packed.data(), lti_packed.size() * sizeof(int));
+    std::memcpy(b.data() + mblk_off_rti<T>(G), rti_packed.data(), rti_packed.size() * sizeof(int));
     std::memcpy(b.data() + mblk_off_chunks<T>(G), chunks.data(), chunks.size());
     return b;
   }
@@ -482,6 +483,38 @@ std::string pack_model(const jxs_model_desc& d, Packed<T>& out) {
       std::memcpy(c, out.pti.data() + (size_t)ch * G * kPtStride, (size_t)G * kPtStride * sizeof(int));
       std::memcpy(c + (size_t)G * kPtStride * 4, out.ptf.data() + (size_t)ch * G * kPtStride, (size_t)G * kPtStride * sizeof(T));
       std::memcpy(c + (size_t)G * kPtStride * (4 + sizeof(T)), out.head.data() + (size_t)ch * G, (size_t)G * sizeof(int));
+    }
+  }
+  // packed integer tables (jxs_params.h): every value must fit its field, and must read back unchanged
+  out.lti_packed.assign((size_t)kLtiPackWords * G, 0);
+  out.rti_packed.assign((size_t)kRtiPackWords * G, 0);
+  for (int lane = 0; lane < G; ++lane) {
+    unsigned char* lb = reinterpret_cast<unsigned char*>(out.lti_packed.data() + (size_t)lane * kLtiPackWords);
+    for (int f = 0; f < LI_COUNT; ++f) {
+      const int v = out.lti[(size_t)lane * kLtiStride + f];
+      if (v < -128 || v > 127) return "internal: lane table value out of the packed range";
+      lb[f] = (unsigned char)(signed char)v;
+      if (lti_get(out.lti_packed.data() + (size_t)lane * kLtiPackWords, f) != v) return "internal: packed lane table does not read back";
+    }
+    unsigned char* rb = reinterpret_cast<unsigned char*>(out.rti_packed.data() + (size_t)lane * kRtiPackWords);
+    for (int f = 0; f < RT_COUNT; ++f) {
+      int v = out.rti[(size_t)lane * kRtiStride + f];
+      if (f < RT_FC) {
+        if (v < 0) v = lds_zero_rec(G);  // (tables of models outside the row layout are never read)
+        if (v > 0xffff) return "internal: LDS record offset out of the packed range";
+        rb[2 * f] = (unsigned char)(v & 0xff), rb[2 * f + 1] = (unsigned char)(v >> 8);
+      } else {
+        const int b = f == RT_FC ? 16 : (f < RT_PPULL ? 17 + (f - RT_PULL) : 41 + (f - RT_PPULL));
+        if (f == RT_FC) {
+          if (v < 0 || v > 255) v = 0;  // (no row layout: table unused)
+        } else if (v < -128 || v > 127) {
+          return "internal: row table value out of the packed range";
+        }
+        rb[b] = (unsigned char)v;
+      }
+      const int back = rti_get(out.rti_packed.data() + (size_t)lane * kRtiPackWords, f);
+      const int want = (f == RT_FC) ? (int)(signed char)(unsigned char)v : v;
+      if (back != want) return "internal: packed row table does not read back";
     }
   }
   int seg_steps = 0;

@@ -67,7 +67,18 @@ enum LaneI : int {
                                       // point whose parent link lies in the subtree of this link, -1 if none
   LI_COUNT = LI_RGPT + 1
 };
-constexpr int kLtiStride = (LI_COUNT + 3) / 4 * 4;
+constexpr int kLtiStride = (LI_COUNT + 3) / 4 * 4;  // staging table of the packer: one int per field
+// [round 3] What the kernels read is PACKED: every field is a signed byte (lanes, levels, link and joint indices
+// are all < 64 by construction), one 32-byte record per lane = two 128-bit loads instead of six.  The prologue of
+// the step kernel is bound by the CU's vector-memory pipeline, not by latency (tools/ubench/cu_share.hip: a
+// dwordx4 load costs the CU 16 ticks, a dword load 32, and the waves of a CU share the pipeline), so bytes fetched
+// per lane are step time; unpacking is one v_bfe_i32 per USED field.
+constexpr int kLtiPackWords = 8;  // dwords per lane in the packed table (LI_COUNT = 24 bytes used)
+static_assert(LI_COUNT <= 4 * kLtiPackWords, "packed lane-int record too small");
+JXS_HD int lti_get(const int* rec, int field) {  // rec: the lane's packed record
+  const unsigned w = (unsigned)rec[field >> 2];
+  return (int)(w << (24 - 8 * (field & 3))) >> 24;
+}
 
 // ---- per-point-slot tables (slots = n_chunks * G), slot-major with stride 4: ptf[slot * 4 + field] ----
 enum PointF : int { PF_POS = 0, PF_COUNT = 3 };
@@ -101,7 +112,20 @@ enum RowI : int {
   RT_PPULL = RT_PULL + kRowLevels * kRowExtra,  // [kRowLevels] lane holding the parent's row, -1 = same lane
   RT_COUNT = RT_PPULL + kRowLevels
 };
-constexpr int kRtiStride = (RT_COUNT + 3) / 4 * 4;  // rti[lane * kRtiStride + field]
+constexpr int kRtiStride = (RT_COUNT + 3) / 4 * 4;  // staging table of the packer: one int per field
+// packed form read by the kernels, one 64-byte record per lane (four 128-bit loads instead of eleven):
+//   bytes 0..15  RT_REC[8] as unsigned 16-bit LDS word offsets | byte 16 RT_FC | bytes 17..40 RT_PULL[8][3] (signed
+//   bytes) | bytes 41..48 RT_PPULL[8] (signed bytes)
+constexpr int kRtiPackWords = 16;
+JXS_HD int rti_get(const int* rec, int field) {
+  if (field < RT_FC) {
+    const unsigned w = (unsigned)rec[field >> 1];
+    return (int)((field & 1) ? (w >> 16) : (w & 0xffffu));
+  }
+  const int b = field == RT_FC ? 16 : (field < RT_PPULL ? 17 + (field - RT_PULL) : 41 + (field - RT_PPULL));
+  const unsigned w = (unsigned)rec[b >> 2];
+  return (int)(w << (24 - 8 * (b & 3))) >> 24;
+}
 // LDS record layout (words).  Every group a lane reads together is 16-byte aligned and contiguous, because
 // one ds instruction costs a lone wave ~14 cycles whether it moves 4 or 16 bytes (tools/ubench/issue_rate.hip):
 //   8 r + 0..5  row r of M (6x6),  8 r + 6  pA[r],  8 r + 7  S[r]      (r < 6: what row lane r reads, two b128)
@@ -113,12 +137,31 @@ enum RowLds : int { RL_ROW = 0, RL_ROW_PA = 6, RL_ROW_S = 7, RL_S = 48, RL_C = 5
 // The link kinematics staged for the contact phase ([G][kKinRec] words) ALIAS the record area: the contact phase
 // has read them back before the ABA publishes its records (a single-wave workgroup executes its LDS
 // operations in program order).  20.6 KB -> 16 KB per humanoid wave: ten waves per CU instead of seven.
-constexpr int kKinRec = 21;  // R (9), r (3), v_lin (3), v_ang (3), anchor of the link's chain (3)
+constexpr int kKinRec = 24;  // R (9), r (3), v_lin (3), v_ang (3), anchor of the link's chain (3), padding to whole 128-bit groups
 JXS_HD constexpr int lds_kin_offset(int) { return 0; }
 // records + base rows (48 words) + one all-zero record: row lanes without a link at a level read
 // zeros from it instead of selecting them (nine v_cndmask per level saved)
 JXS_HD constexpr int lds_zero_rec(int G) { return G * kRowRec + 48; }
 JXS_HD constexpr int lds_words_per_env(int G) { return (lds_zero_rec(G) + kRowRec + 3) / 4 * 4; }
+// ---- two-wave workgroups: the inertia wave and the main wave work on the same
+// environments; per environment the LDS holds
+//   [0, W)        the inertia wave's records, base rows and zero record (the single-wave layout above)
+//   [W, 2 W)      the main wave's records (same layout: its bias rows, S, c, tau), contact staging, base bias, zero record
+//   [2 W, ...)    XL[level][lane][8]: what the inertia wave hands over per tree level -- row r of Ma = MA - U U^T / d
+//                 (6 words), U_r, 1 / d -- read back by the same lane of the main wave
+// and, behind the environments of the workgroup, kDuoFlagWords words of flags (levels published so far).
+enum Role : int { ROLE_SOLO = 0, ROLE_MAIN = 1, ROLE_INERTIA = 2 };
+//   [.., ...)     FK[lane][kDuoFkRec]: the forward kinematics of the inertia wave -- R (9), r (3), the anchor of the
+//                 link's chain (3), anchor minus the parent chain's anchor (3) -- which the main wave does not repeat
+//   base area of the inertia wave (48 words behind its records): the LDL^T factor of the articulated base inertia
+constexpr int kDuoXlRec = 8;
+constexpr int kDuoFkRec = 20;
+constexpr int kDuoFlagWords = 4;
+constexpr int kDuoFlagFk = 1;  // progress word: 1 = kinematics published, 1 + (kRowLevels - L) = level L published
+JXS_HD constexpr int duo_main_off(int G) { return lds_words_per_env(G); }
+JXS_HD constexpr int duo_xl_off(int G) { return 2 * lds_words_per_env(G); }
+JXS_HD constexpr int duo_fk_off(int G) { return duo_xl_off(G) + kRowLevels * G * kDuoXlRec; }
+JXS_HD constexpr int duo_words_per_env(int G) { return duo_fk_off(G) + G * kDuoFkRec; }
 // rigid modes: Q and H packed lower triangles of order 3 n_cp + one exchange vector (jxs_rigid.inc)
 // RelaxedRigidContacts (rigid == 2) factorises in place of the Delassus matrix: one triangle
 // Problems of <= 4 points (the row-distributed register solver and the merged Delassus sweeps, jxs_rigid.inc) get
@@ -135,7 +178,7 @@ JXS_HD constexpr int rigid_lds_words_per_env(int n_cp, int rigid = 1) {
 }
 constexpr int kQpMaxIter = 30;    // interior-point iterations (oracle/refrigid.py QP_MAX_ITER)
 constexpr int kRigidMaxPoints = 32;
-constexpr int kDbgSlots = 32;      // developer profiling build: cycle stamps / counters per workgroup
+constexpr int kDbgSlots = 64;      // developer profiling build: cycle stamps / counters per workgroup (the second wave of a two-wave workgroup stamps at +32)
 constexpr int kImpactCgIters = 5;  // preconditioned CG iterations of the impact solve (jxs_rigid.inc)
 
 enum Mode : int {
@@ -217,9 +260,9 @@ struct KParams {
 template <typename T>
 struct KArgs {
   const T* ltf;        // [G][kLtfStride]
-  const int* lti;      // [G][kLtiStride]
+  const int* lti;      // [G][kLtiPackWords] packed lane-int records (lti_get)
   const unsigned char* chunks;  // [max(n_chunks, 1)] point-chunk records (chunk_bytes<T>(G) each)
-  const int* rti;      // [G][kRtiStride] row-distributed ABA tables (row_mode only)
+  const int* rti;      // [G][kRtiPackWords] packed row-distributed ABA tables (rti_get; row_mode only)
   const T* state_in;   // [n_rows][N]
   T* state_out;        // [n_rows][N] (may alias state_in)
   const T* tau;        // [n][N] or null            joint_force_references / joint_forces
@@ -235,6 +278,9 @@ struct KArgs {
   int id_zero_vel;     // MODE_ID: evaluate at zero velocity (gravity term g(q), api/model.py:1897-1931)
   long long* dbg;      // developer builds (-DJXS_PHASE_TIMING): [blocks][kDbgSlots] cycle stamps, else null
   int* faults;         // [2] environments whose QP contact-force solve / impact solve was discarded (non-finite), or null
+  int has_lds;         // the launch has the per-environment LDS area of the row layout (known when the wave starts: a
+                       // compile-time constant in the specialised / common-feature kernels): the thirteen
+                       // environment-uniform rows of the state are fetched by ONE load instruction and spread through it
 };
 
 // ---- device model block: ONE allocation per model that the kernels address from a single pointer -------
@@ -247,8 +293,8 @@ JXS_HD constexpr int mblk_off_ltf() { return ((int)sizeof(KParams<T>) + 255) / 2
 template <typename T>
 JXS_HD constexpr int mblk_off_lti(int G) { return mblk_off_ltf<T>() + G * kLtfStride * (int)sizeof(T); }
 template <typename T>
-JXS_HD constexpr int mblk_off_rti(int G) { return mblk_off_lti<T>(G) + G * kLtiStride * 4; }
+JXS_HD constexpr int mblk_off_rti(int G) { return mblk_off_lti<T>(G) + G * kLtiPackWords * 4; }
 template <typename T>
-JXS_HD constexpr int mblk_off_chunks(int G) { return mblk_off_rti<T>(G) + G * kRtiStride * 4; }
+JXS_HD constexpr int mblk_off_chunks(int G) { return mblk_off_rti<T>(G) + G * kRtiPackWords * 4; }
 
 }  // namespace jxs

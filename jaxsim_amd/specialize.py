@@ -12,13 +12,17 @@ stay run-time data: changing masses, gains, the time step or the contact paramet
   the description, the kernel sources and the compiler flags), built with hipcc (gfx950; ~20 s);
 * ``attach(device_model, model)``   route the launches of the mode through it (checked by the library).
 
-``runtime.device_model`` attaches a cached object when there is one; it compiles one only when asked to:
-``JAXSIM_AMD_SPECIALIZE=1`` in the environment or ``js.model.specialize(model)``.  ``JAXSIM_AMD_SPECIALIZE=0``
-disables the lookup.  ``__graft_entry__.build()`` pre-builds the objects of the benchmark configurations.
+``runtime.device_model`` attaches a cached object when there is one and, when hipcc is present, **builds the
+missing ones on first use** (the ``jax.jit`` experience: the first step of a new model compiles, ~20 s; later
+processes find the object in the cache).  ``JAXSIM_AMD_SPECIALIZE=cached`` never compiles, ``=0`` disables the
+lookup, ``=1`` insists on building.  ``__graft_entry__.build()`` pre-builds the objects of the benchmark
+configurations.  The test-suite pins ``cached`` (tests/conftest.py) so that both the specialised and the
+library's own kernels stay covered and no test waits for a compiler.
 """
 from __future__ import annotations
 
 import ctypes as C
+import functools
 import hashlib
 import os
 import pathlib
@@ -37,8 +41,9 @@ _FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fv
           "-mllvm", "-amdgpu-kernarg-preload-count=16", "-Wno-cuda-compat", "-Wno-pass-failed", "-Djxs_launch=jxs_launch_spec"]  # fmt: skip
 
 
+@functools.lru_cache(maxsize=1)
 def source_sha() -> str:
-    """Hash of the kernel sources a specialised object is compiled from."""
+    """Hash of the kernel sources a specialised object is compiled from (once per process)."""
     h = hashlib.sha256()
     for name in sorted(os.listdir(_CSRC)):
         if name.endswith((".h", ".inc")) or name == "jxs_spec.hip":
@@ -115,13 +120,27 @@ QUERY_MODES = (1, 2, 3, 8, 9, 10)
 
 def attach(dm, model, mode: int | None = None, *, build: bool = False) -> bool:
     """Attach the specialised kernels of the model (all modes of ``modes_of``, or one ``mode``) to the device
-    model ``dm``.  Without ``build`` only objects found in the cache are used.  True if any was attached."""
+    model ``dm``.  Without ``build`` only objects found in the cache are used; with it the missing ones are
+    compiled now, concurrently (one hipcc process per mode).  True if any was attached."""
     lib = _lib.load()
+    todo = modes_of(model) if mode is None else ([mode] if isinstance(mode, int) else list(mode))
+    paths: dict[int, pathlib.Path | None] = {m: cached(model, dm.dtype, m) for m in todo}
+    missing = [m for m in todo if paths[m] is None]
+    if build and missing:
+        if len(missing) == 1:
+            paths[missing[0]] = compile(model, dm.dtype, missing[0])
+        else:
+            from concurrent.futures import ThreadPoolExecutor
+
+            with ThreadPoolExecutor(len(missing)) as ex:
+                for m, p in zip(missing, ex.map(lambda mm: compile(model, dm.dtype, mm), missing)):
+                    paths[m] = p
     done = False
-    for m in modes_of(model) if mode is None else ([mode] if isinstance(mode, int) else list(mode)):
-        p = compile(model, dm.dtype, m) if build else cached(model, dm.dtype, m)
+    for m in todo:
+        p = paths[m]
         if p is not None:
             _lib.check(lib.jxs_model_attach_specialized(dm.handle, m, str(p).encode()), "jxs_model_attach_specialized")
+            dm.__dict__.setdefault("_spec_files", {})[m] = p.name
             done = True
     return done
 
@@ -133,7 +152,27 @@ def modes(dm) -> list[int]:
     return [k for k in range(16) if mask.value >> k & 1]
 
 
+def hipcc_available() -> bool:
+    return os.path.isfile(_HIPCC) and os.access(_HIPCC, os.X_OK)
+
+
 def policy() -> str:
-    """'off' (never), 'cached' (default: use an object that exists), 'build' (compile on first use)."""
+    """'off' (never), 'cached' (use an object that exists, never compile), 'build' (compile on first use).
+
+    Default [round 3]: **build on first use whenever hipcc is present** -- what ``jax.jit`` does for the reference
+    (the first ``js.model.step`` of a model compiles, src/jaxsim/api/model.py:2599-2601) -- and 'cached' on a machine
+    without the compiler.  ``JAXSIM_AMD_SPECIALIZE=0`` / ``cached`` / ``1`` force a choice.  A failed build is a
+    logged warning and the library's own ahead-of-time kernel runs (``KV_COMMON`` / generic): never a CPU path."""
     v = os.environ.get("JAXSIM_AMD_SPECIALIZE", "")
-    return "off" if v == "0" else "build" if v == "1" else "cached"
+    if v == "0":
+        return "off"
+    if v == "1":
+        return "build"
+    if v == "cached":
+        return "cached"
+    return "build" if hipcc_available() else "cached"
+
+
+def attached_files(dm) -> dict[int, str]:
+    """``{mode: file name}`` of the specialised objects attached to ``dm`` by this module."""
+    return dict(getattr(dm, "_spec_files", {}))

@@ -10,6 +10,14 @@ for p in (str(ROOT), str(ROOT / "tests")):
         sys.path.insert(0, p)
 
 
+# The product's default is to compile a model-specialised kernel on first use when hipcc is present
+# (jaxsim_amd/specialize.py::policy -- the jax.jit experience).  The suite pins 'cached': the zoo models whose objects
+# __graft_entry__.build() pre-built run specialised, every other model runs the library's own kernels, no test waits
+# ~20 s per new model for a compiler, and a kernel never changes between two calls a test compares bitwise.
+# tests/test_specialize.py covers build-on-first-use explicitly.
+os.environ.setdefault("JAXSIM_AMD_SPECIALIZE", "cached")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     # the developer knob of jaxsim_amd/_lib.py would let any library stand in for the product

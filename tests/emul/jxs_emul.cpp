@@ -21,12 +21,19 @@ void* g_dbg_ptr = nullptr;
 template <typename T, int G>
 void run_group(const jxs::Packed<T>& pk, jxs::KArgs<T> a, int mode) {
   a.ltf = pk.ltf.data();
-  a.lti = pk.lti.data();
+  a.lti = pk.lti_packed.data();
   a.chunks = pk.chunks.data();
-  a.rti = pk.rti.data();
+  a.rti = pk.rti_packed.data();
   for (int env = 0; env < a.N; ++env) {
-    jxs::HostLanes<T, G> ln(a.N, env, (size_t)std::max(jxs::rigid_lds_words_per_env(pk.P.n_cp, pk.P.rigid), jxs::lds_words_per_env(G)));
+    jxs::HostLanes<T, G> ln(a.N, env, (size_t)std::max(jxs::rigid_lds_words_per_env(pk.P.n_cp, pk.P.rigid), jxs::duo_words_per_env(G)));
     jxs::Core<jxs::HostLanes<T, G>> core(pk.P, a, ln);
+    if (mode == (jxs::MODE_STEP | 0x100)) {
+      // two-wave workgroup: the inertia wave, then the main wave, on the same LDS image
+      core.run_inertia();
+      core.template run<jxs::MODE_STEP, jxs::ROLE_MAIN>();
+      if (ln.flag_error_) g_err = "two-wave protocol: the main wave waited for a level the inertia wave had not published";
+      continue;
+    }
     switch (mode) {
       case jxs::MODE_STEP: core.template run<jxs::MODE_STEP>(); break;
       case jxs::MODE_FD: core.template run<jxs::MODE_FD>(); break;
@@ -66,12 +73,21 @@ int run_typed(const jxs_model_desc* d, int mode, const void* state_in, void* sta
   a.N = N;
   a.n_steps = n_steps;
   a.dbg = static_cast<long long*>(g_dbg_ptr);
-  if (mode == jxs::MODE_STEP && state_out != state_in && pk.n_disabled > 0)
+  a.has_lds = 1;  // (the host lanes always carry an LDS image: the staged base-state loads are exercised)
+  if ((mode & 0xff) == jxs::MODE_STEP && state_out != state_in && pk.n_disabled > 0)
 {
     const int tile = 64 / pk.G;
     std::memcpy(state_out, state_in, sizeof(T) * (size_t)((N + tile - 1) / tile) * tile * pk.P.n_rows);
   }
   int launches = 1;
+  const bool duo = (mode == (jxs::MODE_STEP | 0x100));  // emulate the two-wave workgroup variant of the step kernel
+  if (duo) {
+    mode = jxs::MODE_STEP;
+    if (!(pk.P.row_mode == 1 && pk.P.rigid == 0 && pk.P.n_chunks <= 1 && pk.integrator != JXS_INTEGRATOR_RUNGE_KUTTA4 && pk.G >= 8)) {
+      g_err = "the two-wave variant does not apply to this model";
+      return JXS_EINVAL;
+    }
+  }
   const bool rk4 = (mode == jxs::MODE_STEP && pk.integrator == JXS_INTEGRATOR_RUNGE_KUTTA4);
   if (rk4) mode = pk.P.rigid ? jxs::MODE_STEP_RK4_RIGID : jxs::MODE_STEP_RK4;
   const bool rigid = (mode == jxs::MODE_STEP && pk.P.rigid);
@@ -84,7 +100,13 @@ int run_typed(const jxs_model_desc* d, int mode, const void* state_in, void* sta
     launches = n_steps;
     a.n_steps = 1;
   }
-  if (mode == jxs::MODE_STEP && a.n_steps > 1) mode = jxs::MODE_ROLLOUT;
+  if (mode == jxs::MODE_STEP && a.n_steps > 1 && !duo) mode = jxs::MODE_ROLLOUT;
+  if (duo) {
+    launches = n_steps;
+    a.n_steps = 1;
+    mode = jxs::MODE_STEP | 0x100;
+  }
+  g_err.clear();
   for (int it = 0; it < launches; ++it) {
     if (it == 1) a.state_in = a.state_out;
   switch (pk.G) {
@@ -96,6 +118,7 @@ int run_typed(const jxs_model_desc* d, int mode, const void* state_in, void* sta
     default: g_err = "bad group size"; return JXS_EINVAL;
   }
   }
+  if (!g_err.empty()) return JXS_EINVAL;
   return JXS_OK;
 }
 

@@ -195,6 +195,8 @@ struct HostLanes {
   template <class KA, class X>
   void stamp_after(const KA&, int, const X&) const {}
   template <class KA>
+  void stamp_hwid(const KA&, int) const {}
+  template <class KA>
   void debug_max(const KA&, int, int) const {}
   void count_fault(int* counters, int which, const VM& faulty) const {
     if (counters != nullptr && faulty.v[0]) counters[which] += 1;
@@ -229,6 +231,18 @@ struct HostLanes {
   }
   void allreduce8x7(V* x) const {
     for (int k = 0; k < 7; ++k) x[k] = allreduce8(x[k]);
+  }
+  void allreduce8x6(V* x) const {
+    for (int k = 0; k < 6; ++k) x[k] = allreduce8(x[k]);
+  }
+  // two-wave workgroups: the emulation runs the inertia wave to completion, then the main wave, on the same
+  // LDS image; a wait that is not satisfied by then is a protocol error of the kernel source
+  mutable int flag_ = 0;
+  mutable bool flag_error_ = false;
+  void flag_post(int value) const { flag_ = value; }
+  void flag_wait(int need, int& seen) const {
+    seen = flag_;
+    if (flag_ < need) flag_error_ = true;
   }
   static unsigned pin(unsigned x) { return x; }
   static int pin(int x) { return x; }
@@ -272,12 +286,12 @@ struct HostLanes {
   }
   VI lconsti(const int* tbl, int field) const {
     VI r;
-    for (int i = 0; i < G; ++i) r.v[i] = tbl[i * kLtiStride + field];
+    for (int i = 0; i < G; ++i) r.v[i] = lti_get(tbl + i * kLtiPackWords, field);
     return r;
   }
   VI rconsti(const int* tbl, int field) const {
     VI r;
-    for (int i = 0; i < G; ++i) r.v[i] = tbl[i * kRtiStride + field];
+    for (int i = 0; i < G; ++i) r.v[i] = rti_get(tbl + i * kRtiPackWords, field);
     return r;
   }
   VI hconsti(const int* head, int chunk) const {

@@ -21,6 +21,7 @@ _SRC = _HERE / "emul" / "jxs_emul.cpp"
 _SO = _HERE / "emul" / "libjxs_emul.so"
 _ROOT = _HERE.parent
 MODE_STEP, MODE_FD, MODE_ID, MODE_KIN, MODE_CRBA, MODE_JAC, MODE_MINV = 0, 1, 2, 3, 8, 9, 10
+MODE_STEP_DUO = MODE_STEP | 0x100  # the two-wave workgroup variant of the step kernel (inertia wave, then main wave)
 
 
 def build(force: bool = False) -> pathlib.Path:
@@ -80,7 +81,7 @@ def run(model, mode, state, *, tau=None, link_forces=None, force_repr=0, in_acc=
         return np.zeros(nt * rows * tile, dtype=dtype)
 
     st, tau, link_forces, in_acc = up(state), up(tau), up(link_forces), up(in_acc)
-    state_out = st.copy() if mode == MODE_STEP else None
+    state_out = st.copy() if mode in (MODE_STEP, MODE_STEP_DUO) else None
     out_a = alloc(6 + n) if mode in (MODE_FD, MODE_ID) else (alloc((6 + n) ** 2) if mode in (MODE_CRBA, MODE_MINV) else None)
     if mode == MODE_JAC:
         out_a = alloc(12 * (6 + n))
@@ -92,7 +93,7 @@ def run(model, mode, state, *, tau=None, link_forces=None, force_repr=0, in_acc=
     )  # fmt: skip
     if rc != 0:
         raise RuntimeError(lib().jxs_emul_last_error().decode())
-    if mode == MODE_STEP:
+    if mode in (MODE_STEP, MODE_STEP_DUO):
         return untile_block(state_out, rows_state, N, tile)
     if mode == MODE_KIN:
         return untile_block(out_H, nL * 12, N, tile), untile_block(out_V, nL * 6, N, tile)

@@ -29,9 +29,26 @@ from jaxsim_amd import state as st
 #   9e-6) -- a noise-limited model kept as a stress case: 2e-2.
 # The reference calls its own 32-bit mode "still experimental" (src/jaxsim/__init__.py:37-41); the fp64
 # kernels are exact to rounding.
+# [round 3] The fp32 gates are PER MODEL: three times the worst element error measured on MI355X over 2 x 512 random
+# states per model (profiles/r02_fp32_error_gpu.txt; tools/fp32_error_gpu.py regenerates the table), instead of one
+# blanket 1e-3:
+#   model            measured worst    gate          reference formulation in fp32 (worst)
+#   pendulum         1.4e-7            5e-7          7.8e-8
+#   double_pendulum  7.8e-8            3e-7          7.8e-8
+#   cartpole         7.8e-8            3e-7          7.8e-8
+#   chain5           4.1e-7            1.5e-6        9.7e-8
+#   sphere           2.4e-4            7.5e-4        1.7e-4
+#   box              4.0e-4            1.2e-3        5.3e-4
+#   anymal           3.6e-4            1e-3          5.1e-5
+#   icub / icub16    3.8e-4 / 5.4e-4   1.5e-3 / 1.6e-3   7.0e-4 / 5.1e-4
+#   chain9f          9.7e-3            2e-2 (kept below 3 x: the stress case) 7.2e-3
+# FP32_TOL (1e-3) remains the gate of models without an entry.
 FP64_TOL = 1e-10
 FP32_TOL = 1e-3
-FP32_TOL_BY_MODEL = {"chain9f": 2e-2}
+FP32_TOL_BY_MODEL = {
+    "pendulum": 5e-7, "double_pendulum": 3e-7, "cartpole": 3e-7, "chain5": 1.5e-6, "sphere": 7.5e-4, "box": 1.2e-3,
+    "anymal": 1e-3, "icub": 1.5e-3, "icub16": 1.6e-3, "chain9f": 2e-2,
+}  # fmt: skip
 
 
 class ModelZoo:
@@ -123,9 +140,29 @@ def rel_err(a: np.ndarray, ref: np.ndarray) -> float:
     return float(np.max(np.abs(a - ref) / np.maximum(1.0, np.abs(ref)))) if a.size else 0.0
 
 
-def tol_of(dtype, name: str | None = None) -> float:
+def note(key: str, value: float) -> None:
+    """Developer aid: append a measured error to ``$JXS_ERR_LOG`` (the per-case gates are set from what the GPU
+    run records there: measured worst x 3)."""
+    import os
+
+    path = os.environ.get("JXS_ERR_LOG")
+    if path:
+        with open(path, "a") as f:
+            f.write(f"{key} {value:.3e}\n")
+
+
+# Single evaluations (forward / inverse dynamics, cached kinematics): the accelerations and torques of the small
+# contact-free models are O(10..100) and carry the plain fp32 rounding of the recursion (measured 8e-7 in IEEE
+# emulation), which a step multiplies by dt before it reaches the state: their step gates (3e-7) do not apply.
+FP32_EVAL_TOL_BY_MODEL = {"pendulum": 1e-5, "double_pendulum": 1e-5, "cartpole": 1e-5, "chain5": 1e-5}
+
+
+def tol_of(dtype, name: str | None = None, evaluation: bool = False) -> float:
+    """Stated tolerance of a step (default) or of a single evaluation (forward / inverse dynamics, kinematics)."""
     if np.dtype(dtype) == np.float64:
         return FP64_TOL
+    if evaluation and name in FP32_EVAL_TOL_BY_MODEL:
+        return FP32_EVAL_TOL_BY_MODEL[name]
     return FP32_TOL_BY_MODEL.get(name, FP32_TOL)
 
 

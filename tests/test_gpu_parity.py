@@ -111,7 +111,7 @@ def test_forward_dynamics_matches_oracle(models, name, dtype, rep):
     tau, f = helpers.random_inputs(model, N, 7, dtype)
     vd, sdd = oracle.forward_dynamics_aba(model, helpers.upcast(d), joint_forces=tau.astype(np.float64), link_forces=f.astype(np.float64))
     gvd, gsdd = js.model.forward_dynamics_aba(model, to_gpu(model, d), joint_forces=tau, link_forces=f)
-    tol = helpers.tol_of(dtype, name)
+    tol = helpers.tol_of(dtype, name, evaluation=True)
     assert helpers.rel_err(gsdd, sdd) < tol and helpers.rel_err(gvd, vd) < tol
 
 
@@ -131,7 +131,7 @@ def test_inverse_dynamics_matches_oracle(models, name, dtype, rep):
     ref = np.concatenate([fB if model.floating_base() else np.zeros_like(fB), tau], -1)
     got = np.concatenate([gfB if model.floating_base() else np.zeros_like(gfB), gtau], -1)
     scale = max(1.0, float(np.abs(ref).max()))
-    assert float(np.abs(got - ref).max()) / scale < helpers.tol_of(dtype, name)
+    assert float(np.abs(got - ref).max()) / scale < helpers.tol_of(dtype, name, evaluation=True)
 
 
 def test_bias_and_gravity_forces(models):
@@ -149,8 +149,8 @@ def test_cached_kinematics_match_oracle(models, name, dtype):
     d = models.random_data(name, 10, seed=31, dtype=dtype)
     g = to_gpu(model, d)
     t = helpers.upcast(d).update_caches(model)
-    assert helpers.rel_err(g._link_transforms, t.link_transforms) < helpers.tol_of(dtype, name)
-    assert helpers.rel_err(g._link_velocities, t.link_velocities) < helpers.tol_of(dtype, name)
+    assert helpers.rel_err(g._link_transforms, t.link_transforms) < helpers.tol_of(dtype, name, evaluation=True)
+    assert helpers.rel_err(g._link_velocities, t.link_velocities) < helpers.tol_of(dtype, name, evaluation=True)
 
 
 def test_data_build_and_properties(models):
@@ -270,8 +270,8 @@ def test_gpu_golden(models, name, dtype):
     out = js.model.step(model, data, link_forces=g["link_forces"], joint_force_references=g["tau"])
     assert helpers.rel_err(out.state_block(), g["step"]) < helpers.tol_of(dtype, name)
     vd, sdd = js.model.forward_dynamics_aba(model, data, joint_forces=g["tau"], link_forces=g["link_forces"])
-    assert helpers.rel_err(np.concatenate([vd, sdd], -1), g["fd"]) < helpers.tol_of(dtype, name)
-    assert helpers.rel_err(data._link_transforms, g["link_transforms"]) < helpers.tol_of(dtype, name)
+    assert helpers.rel_err(np.concatenate([vd, sdd], -1), g["fd"]) < helpers.tol_of(dtype, name, evaluation=True)
+    assert helpers.rel_err(data._link_transforms, g["link_transforms"]) < helpers.tol_of(dtype, name, evaluation=True)
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
@@ -284,14 +284,22 @@ def test_plane_terrain_gpu(models, dtype):
     assert helpers.rel_err(out.state_block(), helpers.odata_to_block(model, ref)) < helpers.tol_of(dtype)
 
 
-def test_fused_rollout_equals_repeated_steps_gpu(models):
+def test_fused_rollout_equals_repeated_steps_gpu(models, monkeypatch):
     model = models("icub")
     d = models.random_data("icub", 64, seed=14, dtype=np.float32)
     g = to_gpu(model, d)
     fused = js.model.rollout(model, g, 9).state_block()
+    # bitwise against the single-wave step kernel (the fused rollout is its loop); the two-wave variant small grids
+    # get by default forms the bias force from the handed-over rows of Ma in another order: rounding only
+    monkeypatch.setenv("JXS_DUO", "0")
+    g1 = g
+    for _ in range(9):
+        g1 = js.model.step(model, g1)
+    np.testing.assert_array_equal(fused, g1.state_block())
+    monkeypatch.delenv("JXS_DUO")
     for _ in range(9):
         g = js.model.step(model, g)
-    np.testing.assert_array_equal(fused, g.state_block())
+    assert helpers.rel_err(fused, g.state_block()) < 2e-3  # nine steps of a contact-rich fp32 trajectory
     # more collidable points than lanes (sphere: 50 points, 2 chunks): rollout falls back to launches
     sph = models("sphere")
     ds = models.random_data("sphere", 16, seed=3)
@@ -386,7 +394,17 @@ def test_rigid_step_matches_oracle_gpu(models, reduced_qp, key):
     assert helpers.rel_err(out.state_block(), helpers.odata_to_block(model, ref)) < 1e-7
 
 
-@pytest.mark.parametrize("key,tol", [("anymal4", 3e-3), ("icub8", 3e-3), ("anymal16", 3e-3), ("box4", 3e-3)])
+# fp32 gates of the rigid-contact steps, PER CASE [round 3]: measured on MI355X (gpurun_out/r03_b/errors.log, the
+# values in the comments) x 3, rounded up -- instead of a blanket 3e-3.  The box cases stay near 3e-3: 1 kg,
+# K = 1e5 with centimetres of penetration, contact forces of 1e3 N on four coplanar points whose 12x12 Delassus
+# matrix has rank 6 plus the 1e-6 shift.
+RIGID_FP32_TOL = {"anymal4": 3e-6, "icub8": 1.1e-4, "anymal16": 4.5e-5, "box4": 3e-3}  # 9.6e-7, 3.5e-5, 1.4e-5, 1.04e-3
+RIGID_RK4_FP32_TOL = {"box4": 2.5e-3, "anymal4": 3e-5, "icub8": 1.8e-4}  # 7.8e-4, 8.7e-6, 5.7e-5
+RK4FAST_FP32_TOL = {("relaxed", "box8"): 4.5e-5, ("relaxed", "anymal16"): 1.5e-5, ("relaxed", "icub16"): 9e-5, ("rigid", "box4"): 2.5e-3,
+                    ("rigid", "anymal4"): 7.5e-6}  # 1.4e-5, 4.6e-6, 2.9e-5, 8.2e-4, 2.4e-6  # fmt: skip
+
+
+@pytest.mark.parametrize("key,tol", list(RIGID_FP32_TOL.items()))
 def test_rigid_step_fp32_gpu(models, reduced_qp, key, tol):
     """fp32 against the fp64 oracle on the same inputs: 3e-3 like the soft-contact path (measured
     3e-6 .. 6e-5 on the articulated models, 1e-3 on the box: 1 kg, K = 1e5 with centimetres of
@@ -399,7 +417,9 @@ def test_rigid_step_fp32_gpu(models, reduced_qp, key, tol):
     out = js.model.step(model, to_gpu(model, d))
     blk = out.state_block()
     assert blk.dtype == np.float32 and np.isfinite(blk).all()
-    assert helpers.rel_err(blk, helpers.odata_to_block(model, ref)) < tol
+    err = helpers.rel_err(blk, helpers.odata_to_block(model, ref))
+    helpers.note(f"rigid_fp32/{key}", err)
+    assert err < tol
 
 
 @pytest.mark.parametrize("dtype,atol", [(np.float64, 1e-4), (np.float32, 2e-4)])
@@ -440,7 +460,9 @@ def test_rigid_rk4_step_matches_oracle_gpu(models, reduced_qp, key):
     d32 = models.random_data(name, N, seed=5, dtype=np.float32)
     out32 = js.model.step(model, to_gpu(model, d32)).state_block()
     ref32 = oracle.step(model, helpers.upcast(d32))
-    assert out32.dtype == np.float32 and helpers.rel_err(out32, helpers.odata_to_block(model, ref32)) < 3e-3
+    err32 = helpers.rel_err(out32, helpers.odata_to_block(model, ref32))
+    helpers.note(f"rigid_rk4_fp32/{key}", err32)
+    assert out32.dtype == np.float32 and err32 < RIGID_RK4_FP32_TOL[key]
 
 
 @pytest.mark.parametrize("dtype,atol", [(np.float64, 1e-4), (np.float32, 2e-4)])
@@ -470,7 +492,9 @@ def test_rk4fast_step_matches_oracle_gpu(models, reduced_qp, kind, key):
     d32 = models.random_data(name, N, seed=5, dtype=np.float32)
     out32 = js.model.step(model, to_gpu(model, d32)).state_block()
     ref32 = oracle.step(model, helpers.upcast(d32))
-    assert out32.dtype == np.float32 and helpers.rel_err(out32, helpers.odata_to_block(model, ref32)) < 3e-3
+    err32 = helpers.rel_err(out32, helpers.odata_to_block(model, ref32))
+    helpers.note(f"rk4fast_fp32/{kind}/{key}", err32)
+    assert out32.dtype == np.float32 and err32 < RK4FAST_FP32_TOL[(kind, key)]
 
 
 def test_rk4fast_is_refused_for_soft_contacts_gpu(models):
@@ -882,6 +906,23 @@ def test_step_repeat_graph_equals_single_launches(models):
             _lib.check(lib.jxs_step_repeat(dm.handle, C.c_void_p(g._state.ptr), None, None, 2, 50, n, stream.handle), "repeat")
         stream.synchronize()
         np.testing.assert_array_equal(g.state_block(), ref.state_block())
+
+
+@pytest.mark.parametrize("name", ["cartpole", "chain5", "double_pendulum"])
+@pytest.mark.parametrize("rep", [VelRepr.Inertial, VelRepr.Body, VelRepr.Mixed])
+def test_mass_matrix_inverse_of_fixed_base_models_is_the_full_inverse(models, name, rep):
+    """The reference's ``mass_inverse`` treats the base link of every model as a free 6-DoF body
+    (rbda/mass_inverse.py:118-178: the propagation reaches link 0 and D0 = I_A[0] is inverted), so
+    ``free_floating_mass_matrix_inverse`` of a FIXED-base model is the inverse of the full (6+n) matrix
+    ``free_floating_mass_matrix`` returns -- not a matrix with zero base rows [ADVICE r2]."""
+    model = models(name)
+    assert not model.floating_base()
+    d = models.random_data(name, 5, seed=47, rep=rep)
+    g = to_gpu(model, d)
+    M = js.model.free_floating_mass_matrix(model, g)
+    Mi = js.model.free_floating_mass_matrix_inverse(model, g)
+    np.testing.assert_allclose(M @ Mi, np.broadcast_to(np.eye(M.shape[-1]), M.shape), atol=1e-8)
+    assert helpers.rel_err(Mi, np.linalg.inv(M)) < 1e-8 * max(1.0, float(np.abs(np.linalg.inv(M)).max()))
 
 
 @pytest.mark.parametrize("name", ["chain9f", "anymal"])

@@ -18,15 +18,15 @@ lib = _lib.load()
 dm = runtime.device_model(model, np.float32)
 blocks = (N + 1) // 2
 buf = C.c_void_p()
-lib.jxs_malloc(C.byref(buf), blocks * 32 * 8)
-lib.jxs_memset(buf, 0, blocks * 32 * 8, None)
+lib.jxs_malloc(C.byref(buf), blocks * 64 * 8)
+lib.jxs_memset(buf, 0, blocks * 64 * 8, None)
 lib.jxs_debug_set_stamp_buffer.argtypes = [C.c_void_p]
 lib.jxs_debug_set_stamp_buffer(buf)
 ptr = C.c_void_p(data._state.ptr)
 for _ in range(20):
     lib.jxs_step(dm.handle, ptr, ptr, None, None, 2, N, None)
 runtime.synchronize()
-out = np.zeros((blocks, 32), dtype=np.int64)
+out = np.zeros((blocks, 64), dtype=np.int64)
 lib.jxs_memcpy_d2h(out.ctypes.data_as(C.c_void_p), buf, out.nbytes, None)
 d = np.diff(out[:, :11], axis=1)
 names = ["loads arrive", "actuation+local xform", "FK (pointer jumping)", "velocities", "contacts", "inertia+bias",
@@ -44,3 +44,30 @@ if out[:, 24].any():  # row-distributed pass 2: one stamp per tree level, deepes
     print("  pass 2 per level (deepest first): " + " ".join(f"{x:.0f}" for x in dl.mean(axis=0)))
 span = out[:, 10].max() - out[:, 0].min()
 print(f"  first start -> last end: {span} ticks")
+if out[:, 32].any():  # two-wave workgroups: the inertia wave stamps at +32
+    w = out[:, 32:]
+    t0 = out[:, 0:1]
+    print("  inertia wave, since the main wave's start: start %.0f  loads %.0f  xform %.0f  FK %.0f  inertia built %.0f  sweep done %.0f  end %.0f" % tuple(
+        (w[:, i] - t0[:, 0]).mean() for i in (0, 1, 2, 3, 6, 7, 10)))
+    lv = w[:, 31:23:-1]
+    print("  inertia wave, level published at (deepest first): " + " ".join(f"{x:.0f}" for x in (lv - t0).mean(axis=0)))
+    lvA = out[:, 31:23:-1]
+    print("  main wave, level finished at (deepest first):     " + " ".join(f"{x:.0f}" for x in (lvA - t0).mean(axis=0)))
+    print("  main wave stamps since start: " + " ".join(f"{i}:{(out[:, i] - out[:, 0]).mean():.0f}" for i in range(11)))
+    print("  inertia wave stamps since the main wave's start: " + " ".join(f"{i}:{(w[:, i] - out[:, 0]).mean():.0f}" for i in (0, 1, 2, 3, 4, 6, 7, 10)))
+if out[:, 11].any():  # placement of the waves: HW_ID (wave 3:0, simd 5:4, cu 11:8, sh 12, se 15:13) | XCC_ID << 16
+    def place(h):
+        cu = ((h >> 16) & 15) << 12 | ((h >> 13) & 7) << 8 | ((h >> 12) & 1) << 4 | ((h >> 8) & 15)
+        return cu, (h >> 4) & 3
+    ids = [out[:, 11]] + ([out[:, 43]] if out[:, 43].any() else [])
+    cus, simds = {}, {}
+    for col in ids:
+        for h in col:
+            cu, sd = place(int(h))
+            cus[cu] = cus.get(cu, 0) + 1
+            simds[(cu, sd)] = simds.get((cu, sd), 0) + 1
+    print(f"  placement: {len(cus)} CUs used (max {max(cus.values())} waves per CU), {len(simds)} SIMDs used (max {max(simds.values())} waves per SIMD)")
+    if len(ids) == 2:
+        same_simd = sum(1 for a, b in zip(ids[0], ids[1]) if place(int(a)) == place(int(b)))
+        same_cu = sum(1 for a, b in zip(ids[0], ids[1]) if place(int(a))[0] == place(int(b))[0])
+        print(f"  two-wave workgroups: {same_cu} of {blocks} on one CU (must be all), {same_simd} with both waves on the same SIMD")

@@ -34,16 +34,16 @@ lib = _lib.load()
 dm = runtime.device_model(model, np.float32)
 blocks = (N + dm.layout.tile - 1) // dm.layout.tile
 buf = C.c_void_p()
-lib.jxs_malloc(C.byref(buf), blocks * 32 * 8)
+lib.jxs_malloc(C.byref(buf), blocks * 64 * 8)
 lib.jxs_debug_set_stamp_buffer.argtypes = [C.c_void_p]
 ptr = C.c_void_p(data._state.ptr)
 for _ in range(60):
     lib.jxs_step(dm.handle, ptr, ptr, None, None, 2, N, None)
-lib.jxs_memset(buf, 0, blocks * 32 * 8, None)
+lib.jxs_memset(buf, 0, blocks * 64 * 8, None)
 lib.jxs_debug_set_stamp_buffer(buf)
 lib.jxs_step(dm.handle, ptr, ptr, None, None, 2, N, None)
 runtime.synchronize()
-out = np.zeros((blocks, 32), dtype=np.int64)
+out = np.zeros((blocks, 64), dtype=np.int64)
 lib.jxs_memcpy_d2h(out.ctypes.data_as(C.c_void_p), buf, out.nbytes, None)
 if kind == "relaxed":
     has = (out[:, 11] > 0) & (out[:, 13] > 0)
