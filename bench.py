@@ -381,6 +381,50 @@ def other_configs(stream, steps=200):
     return out
 
 
+def default_contact_params_variant(model_name, n_local, dtype, stream, window=40, windows=50):
+    """Secondary figure: the SECOND input set SURVEY.md section 8(d) names -- the reference's DEFAULT soft-contact
+    parameters (K = 1e6, D = 2000, src/jaxsim/rbda/contacts/soft.py:28-46), no joint damping / limit springs beyond
+    the URDF's.  With dt = 1e-3 these sit at the stability limit of the explicit integration (DESIGN.md section 7:
+    they diverge in the fp64 oracle too within ~50-1000 steps), so the figure is taken over short windows: `windows`
+    windows of `window` (<= 40) steps, each from a FRESH copy of the synthetic state, kernel time by HIP events over
+    the launches of one window.  Same kernel, same instruction stream as the headline; reported so that both input
+    sets the survey names have a number."""
+    import ctypes as C
+
+    import jaxsim_amd as ja
+    from jaxsim_amd import _lib, robots, runtime
+
+    lib = _lib.load()
+    model = ja.JaxSimModel.build_from_model_description(robots.icub23_urdf(sole_boxes_per_foot=2) if model_name == "icub23" else None)
+    assert float(model.contact_params.K) == 1e6 and float(model.contact_params.D) == 2000.0  # the reference defaults
+    data0 = synthetic_state(model, n_local, seed=0, dtype=dtype)
+    dm = runtime.device_model(model, dtype)
+    block0 = data0._state.copy()
+    work = data0._state
+    sp = C.c_void_p(work.ptr)
+    us, finite = [], []
+    for w in range(windows + 2):
+        _lib.check(lib.jxs_memcpy_d2d(sp, C.c_void_p(block0.ptr), block0.nbytes, stream.handle), "jxs_memcpy_d2d")
+        stream.synchronize()
+        e0, e1 = runtime.Event(), runtime.Event()
+        e0.record(stream)
+        _lib.check(lib.jxs_step_repeat(dm.handle, sp, None, None, 2, n_local, window, stream.handle), "jxs_step_repeat")
+        e1.record(stream)
+        stream.synchronize()
+        if w >= 2:  # (the first windows capture the replay graph)
+            us.append(e0.elapsed_ms(e1) / window * 1e3)
+    fin = float(np.isfinite(data0.state_block()).all(axis=0).mean())
+    u = float(np.median(us))
+    lay = dm.layout
+    alg = (2 * (13 + 2 * lay.n_joints + 3 * lay.n_points) + lay.n_joints) * np.dtype(dtype).itemsize
+    return {"contact_params": {"K": 1e6, "D": 2000.0, "mu": float(model.contact_params.mu)}, "window_steps": window, "windows": windows,
+            "us_per_step": u, "env_steps_per_s": n_local / (u * 1e-6), "finite_envs_after_a_window": fin,
+            "roofline": {"bound": "hbm", "achieved": alg * n_local / (u * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": alg * n_local / (u * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_env_step": alg},
+            "note": "SURVEY 8(d) variant `default_contact_params`: reference default K / D, windows of <= 40 steps from a fresh state "
+                    "(longer runs leave the finite range, in the fp64 oracle too); HIP events per window, median; secondary figure, not `value`"}  # fmt: skip
+
+
 def secondary_dtype(model_name, n_local, dtype, stream, steps=200):
     """Secondary figure: the same workload and launch pattern in the other precision (the reference's own
     default arithmetic is fp64, src/jaxsim/__init__.py:17-35; the headline follows SURVEY.md section 8 = fp32)."""
@@ -528,8 +572,11 @@ def main():
     # region of a short request, e.g. --steps 20 = 0.2 ms, is otherwise at the mercy of one host hiccup).
     reps = 5 if args.steps >= 500 else 9
     wall, evs = timed_repetitions(timed_region, run_steps, args.steps, reps, stream, barrier, lib)
+    per_rank_ms = None
     if comm is not None:  # max over ranks, repetition by repetition
-        wall = [float(comm.all_gather_scalars(w).max()) for w in wall]
+        gathered = [np.asarray(comm.all_gather_scalars(w), dtype=np.float64) for w in wall]
+        wall = [float(g.max()) for g in gathered]
+        per_rank_ms = [float(x) / args.steps * 1e3 for x in np.median(np.stack(gathered), axis=0)]  # each rank's own median
     elapsed = float(np.median(wall))
     kernel_ms = float(np.median(evs)) * 1e3 / args.steps  # HIP events on the launch stream
 
@@ -673,6 +720,9 @@ def main():
                                    "constants, as jax.jit does for the reference; physical parameters are run-time data; `generic_kernel` is the library's run-time-flag kernel"
                                    if spec_modes else "generic (model flags read at run time)"),
                 "parallelism": f"batch-sharded x{world}, no per-step communication",
+                # which native object the timed launches ran through (jaxsim_amd/specialize.py; built on first use)
+                "specialised_object": specialize.attached_files(dm).get(specialize.MODE_STEP),
+                "specialised_for": specialize.spec(model, dtype, specialize.MODE_STEP) if spec_modes else None,
             },
             "timing": {
                 "repetitions": reps,
@@ -701,7 +751,8 @@ def main():
                               "that trajectory, DESIGN.md section 7",
             "allgather_ms": allgather_ms,
             "allgather_error": allgather_error,
-            "comm": None if comm is None else {"kind": type(comm).__name__, "ranks": comm_ranks, "error": comm_error},
+            "comm": None if comm is None else {"kind": type(comm).__name__, "ranks": comm_ranks, "error": comm_error,
+                                               "ms_per_step_per_rank": per_rank_ms},
             "steady_state": steady,
             "generic_kernel": generic,
             "fused_rollout": {"us_per_step": rollout_ms_per_step * 1e3, "env_steps_per_s_rank0": n_local / (rollout_ms_per_step * 1e-3),
@@ -714,6 +765,10 @@ def main():
                 saturated["note"] = "same step kernel, one GPU filled; secondary figure, not `value`"
             out["saturated"] = saturated
         if world == 1 and not args.no_other_contact_models:
+            try:
+                out["default_contact_params"] = default_contact_params_variant(args.model, n_local, dtype, stream)
+            except Exception as e:  # secondary: never lose the headline for it
+                out["default_contact_params"] = {"error": repr(e)}
             out["other_contact_models"] = other_contact_models(dtype, stream)
             try:
                 out["other_configs"] = other_configs(stream)

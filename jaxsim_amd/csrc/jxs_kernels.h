@@ -154,16 +154,18 @@ hipError_t launch_one(const jxs::KParams<T>& P, const unsigned char* mblk, const
       return hipGetLastError();
     }
   }
-  // Two-wave workgroups while one wave per workgroup would leave SIMDs idle (at most 1024 workgroups: 256 CUs x 4
-  // SIMDs; beyond that the duplicated kinematics cost throughput).  JXS_DUO=0 / 1 forces the choice (developer A/B).
+  // Two-wave workgroups (jxs_core.h): OPT-IN (JXS_DUO=1) after the round-3 measurement -- at 1024 environments the
+  // variant runs at parity with the single-wave kernel (7.70 vs 7.65 us, profiles/r03_two_wave_experiment.md): the
+  // inertia recursion stays the critical path and the waves of a CU share its LDS and vector-memory pipelines.
+  // JXS_DUO_MAX_BLOCKS bounds the grids it is used for.
   if constexpr (MODE == jxs::MODE_STEP && G >= 8) {
     // (read per launch, not cached: the tests switch it between launches; a replayed hipGraph keeps what it captured)
     const char* const duo_e = std::getenv("JXS_DUO");
     const char* const duo_b = std::getenv("JXS_DUO_MAX_BLOCKS");
     const int duo_env = duo_e == nullptr ? -1 : std::atoi(duo_e);
-    const int duo_max_blocks = duo_b == nullptr ? 1024 : std::atoi(duo_b);
+    const int duo_max_blocks = duo_b == nullptr ? (1 << 30) : std::atoi(duo_b);
     const bool fits = P.row_mode == 1 && P.rigid == 0 && P.n_chunks <= 1 && duo_lds_bytes<T>(G) <= (size_t)160 * 1024;
-    if (fits && duo_env != 0 && (duo_env > 0 || blocks <= duo_max_blocks)) {
+    if (fits && duo_env > 0 && blocks <= duo_max_blocks) {
       const size_t bytes = duo_lds_bytes<T>(G);
       static bool attr_set = false;
       if (!attr_set) {

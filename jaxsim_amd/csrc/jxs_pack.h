@@ -124,6 +124,10 @@ std::string pack_model(const jxs_model_desc& d, Packed<T>& out) {
   // RungeKutta4 keeps the tangential deformation of every point in registers across its stages: one
   // point chunk, so up to 64 points get a lane each (semi-implicit Euler prefers 32 lanes + 2 chunks)
   if (d.integrator != JXS_INTEGRATOR_SEMI_IMPLICIT_EULER && n_en > 32 && n_en <= 64) G = 64;
+  if (const char* e = std::getenv("JXS_MIN_LANES")) {  // developer knob: at least this many lanes per environment (A/B of the lane-group size)
+    const int g = std::atoi(e);
+    if (g == 8 || g == 16 || g == 32 || g == 64) G = std::max(G, g);
+  }
   out.G = G;
   const int n_chunks = (n_en + G - 1) / G;
   const int n_slots = n_chunks * G;

@@ -289,14 +289,14 @@ def test_fused_rollout_equals_repeated_steps_gpu(models, monkeypatch):
     d = models.random_data("icub", 64, seed=14, dtype=np.float32)
     g = to_gpu(model, d)
     fused = js.model.rollout(model, g, 9).state_block()
-    # bitwise against the single-wave step kernel (the fused rollout is its loop); the two-wave variant small grids
-    # get by default forms the bias force from the handed-over rows of Ma in another order: rounding only
+    # bitwise against the single-wave step kernel (the fused rollout is its loop)
     monkeypatch.setenv("JXS_DUO", "0")
     g1 = g
     for _ in range(9):
         g1 = js.model.step(model, g1)
     np.testing.assert_array_equal(fused, g1.state_block())
-    monkeypatch.delenv("JXS_DUO")
+    # the opt-in two-wave variant forms the bias force from the handed-over rows of Ma in another order: rounding only
+    monkeypatch.setenv("JXS_DUO", "1")
     for _ in range(9):
         g = js.model.step(model, g)
     assert helpers.rel_err(fused, g.state_block()) < 2e-3  # nine steps of a contact-rich fp32 trajectory
@@ -308,6 +308,28 @@ def test_fused_rollout_equals_repeated_steps_gpu(models, monkeypatch):
     for _ in range(5):
         ds = oracle.step(sph, ds)
     assert helpers.rel_err(fused, helpers.odata_to_block(sph, ds)) < 1e-9
+
+
+@pytest.mark.parametrize("name", ["anymal", "icub", "icub16"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_two_wave_step_matches_oracle_and_single_wave_gpu(models, name, dtype, monkeypatch):
+    """The opt-in two-wave workgroup variant of the step kernel (JXS_DUO=1; jxs_core.h run_inertia + run<MODE_STEP,
+    ROLE_MAIN>): against the oracle within the stated tolerance, against the single-wave kernel to rounding, for a
+    ragged batch (an odd number of tiles: the second pair of the last workgroup is empty)."""
+    model = models(name)
+    N = 2 * 37 + 1
+    d = models.random_data(name, N, seed=4, dtype=dtype)
+    tau, f = helpers.random_inputs(model, N, 5, dtype)
+    ref = oracle.step(model, helpers.upcast(d), link_forces=f.astype(np.float64), joint_force_references=tau.astype(np.float64))
+    monkeypatch.setenv("JXS_DUO", "0")
+    solo = js.model.step(model, to_gpu(model, d), link_forces=f, joint_force_references=tau).state_block()
+    monkeypatch.setenv("JXS_DUO", "1")
+    duo = js.model.step(model, to_gpu(model, d), link_forces=f, joint_force_references=tau).state_block()
+    assert helpers.rel_err(duo, helpers.odata_to_block(model, ref)) < helpers.tol_of(dtype, name)
+    # (fp32: other contraction choices in two instruction streams; measured 4e-5 on the humanoid's contact-rich states)
+    assert helpers.rel_err(duo, solo) < (1e-12 if dtype == np.float64 else 1e-4)
+    if dtype == np.float32:  # (fp64: two pairs of waves exceed the 160 KB of LDS of a CU, the single-wave kernel runs)
+        assert not np.array_equal(duo, solo), "the two-wave variant did not run"
 
 
 # ---- Runge-Kutta 4 (api/integrators.py:91-167) --------------------------------------------------

@@ -177,3 +177,42 @@ def test_specialised_random_trees_equal_the_generic_kernel(n_links, fixed, max_b
         # fp32 rounding with other contraction choices; deep random chains amplify it (they are 2e-2 from the fp64
         # oracle, tests/helpers.py) -- a folded branch gone wrong would be O(1)
         assert helpers.rel_err(x, y) < 5e-4
+
+
+def test_default_policy_builds_on_first_use_when_hipcc_is_present(monkeypatch):
+    """[round 3] What a drop-in user gets: without any environment variable the first step of a model compiles its
+    specialised kernel when the compiler is there (jax.jit semantics), and only looks into the cache otherwise."""
+    monkeypatch.delenv("JAXSIM_AMD_SPECIALIZE", raising=False)
+    assert specialize.policy() == ("build" if specialize.hipcc_available() else "cached")
+    monkeypatch.setattr(specialize, "_HIPCC", "/nonexistent/hipcc")
+    assert specialize.policy() == "cached"
+    for value, want in (("0", "off"), ("1", "build"), ("cached", "cached")):
+        monkeypatch.setenv("JAXSIM_AMD_SPECIALIZE", value)
+        assert specialize.policy() == want
+
+
+@pytest.mark.gpu
+def test_specialised_object_is_mapped_while_and_after_a_model_runs(models, monkeypatch):
+    """The specialised kernel object the step runs through is visible in /proc/self/maps -- while the device model is
+    alive and afterwards (objects are never unloaded: launches may still be in flight, jxs_api.hip ~ModelT) -- so a
+    driver that records which native code a process loaded sees spec_cache/libjxs_spec_*.so, not only the library."""
+    import gc
+
+    def mapped():
+        return {ln.split()[-1] for ln in open("/proc/self/maps") if "libjxs_spec_" in ln}
+
+    model = models("icub")
+    monkeypatch.setenv("JAXSIM_AMD_SPECIALIZE", "1")
+    model.__dict__.pop("_device", None)
+    d = models.random_data("icub", 8, seed=1, dtype=np.float32)
+    out = js.model.step(model, js.data.JaxSimModelData.from_state_block(model, helpers.odata_to_block(model, d), 2))
+    dm = runtime.device_model(model, np.float32)
+    files = specialize.attached_files(dm)
+    assert specialize.MODE_STEP in specialize.modes(dm) and files[specialize.MODE_STEP].startswith("libjxs_spec_")
+    want = str((specialize.CACHE / files[specialize.MODE_STEP]).resolve())
+    assert want in mapped(), (want, mapped())
+    assert np.isfinite(out.state_block()).all()
+    del dm, out
+    model.__dict__.pop("_device", None)
+    gc.collect()
+    assert want in mapped()

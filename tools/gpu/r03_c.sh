@@ -2,7 +2,7 @@
 # round 3, GPU call C: two-wave variant v2 (kinematics handed over, base factor by the inertia wave, even placement)
 set -u
 R=$PWD
-OUT=$R/gpurun_out/r03_d
+OUT=$R/gpurun_out/r03_e
 mkdir -p "$OUT"
 for cfg in "JXS_DUO=0" "JXS_DUO=1" "JXS_DUO=1 JXS_DUO_MAX_BLOCKS=4096"; do
   env $cfg timeout 300 python tools/sweep.py --sizes 1024,2048,4096 --steps 1000 2>&1 | sed "s/^/$cfg /" | tee -a "$OUT/summary.txt"
