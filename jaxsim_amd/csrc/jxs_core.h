@@ -44,6 +44,10 @@ struct Core {
   mutable unsigned rg_amask_ = 0xffffffffu;
   mutable VM rg_mine_;  // this lane's own point has its bit set
   mutable int rg_hoff_ = 0;  // LDS word offset of the working matrix H: behind Q, or Q itself (relaxed model)
+  // rigid contact models: active set the Delassus matrix in the LDS was last built for (rigid_contact_forces) and
+  // whether it is there at all -- the impact reuses it as its preconditioner when the set has not changed
+  mutable VM rg_act_last_;
+  mutable bool rg_q_valid_ = false;
   mutable int duo_seen_ = 0;  // two-wave workgroups, main wave: last value read from the inertia wave's progress word
 
   JXS_HD Core(const KParams<T>& p, const KArgs<T>& a, const L& l) : P(p), A(a), ln(l) {}

@@ -296,6 +296,28 @@ struct DeviceLanes {
     hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
   }
+  // value of lane `k` (0..15, a compile-time constant after unrolling) of this lane's 16-lane DPP row, in every lane of
+  // the row: DPP row_newbcast (gfx90a and later)
+  __device__ __forceinline__ V row_bcast(V x, int k) const {
+    switch (k & 15) {
+      case 0: return dpp<0x150>(x);
+      case 1: return dpp<0x151>(x);
+      case 2: return dpp<0x152>(x);
+      case 3: return dpp<0x153>(x);
+      case 4: return dpp<0x154>(x);
+      case 5: return dpp<0x155>(x);
+      case 6: return dpp<0x156>(x);
+      case 7: return dpp<0x157>(x);
+      case 8: return dpp<0x158>(x);
+      case 9: return dpp<0x159>(x);
+      case 10: return dpp<0x15A>(x);
+      case 11: return dpp<0x15B>(x);
+      case 12: return dpp<0x15C>(x);
+      case 13: return dpp<0x15D>(x);
+      case 14: return dpp<0x15E>(x);
+      default: return dpp<0x15F>(x);
+    }
+  }
   __device__ __forceinline__ V from_next(V x) const { return dpp<0x130>(x); }  // wave_shl:1, lane i <- i+1
   __device__ __forceinline__ V from_prev(V x) const { return dpp<0x138>(x); }  // wave_shr:1, lane i <- i-1
   template <int OFF>

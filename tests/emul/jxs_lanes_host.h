@@ -220,6 +220,11 @@ struct HostLanes {
     for (int i = 0; i < G; ++i) r.v[i] = (i >= 1) ? x.v[i - 1] : T(0);
     return r;
   }
+  V row_bcast(const V& x, int k) const {  // lane k of the 16-lane row of every lane
+    V r;
+    for (int i = 0; i < G; ++i) r.v[i] = x.v[((i & ~15) + (k & 15)) & (G - 1)];
+    return r;
+  }
   V allreduce8(const V& x) const {
     V r;
     for (int i = 0; i < G; ++i) {
