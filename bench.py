@@ -169,6 +169,10 @@ def other_contact_models(dtype, stream, steps=200, warmup=20):
         st = C.c_void_p(data._state.ptr)
         tau = runtime.DeviceArray(model.dofs(), n_envs, dtype, tile=data._state.tile, zero=True)
         tp = C.c_void_p(tau.ptr)
+        if with_tau:
+            from jaxsim_amd import specialize as _sp
+
+            _sp.ensure_mode(dm, model, _sp.MODE_GRAV)  # what js.model.gravity_compensation_torques does on first use
 
         def run(k, gravity=with_tau):
             for _ in range(k):

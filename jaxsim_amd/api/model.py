@@ -283,6 +283,9 @@ def gravity_compensation_torques(model: JaxSimModel, data: JaxSimModelData, out:
     accepts as ``joint_force_references`` without a host round trip (extension; the reference
     idiom is ``tau = js.model.free_floating_gravity_forces(model, data)[6:]`` followed by ``step``)."""
     dm = runtime.device_model(model, data.dtype)
+    from .. import specialize
+
+    specialize.ensure_mode(dm, model, specialize.MODE_GRAV)  # (first call: cached object, or built when hipcc is there)
     N, n = data.batch_size, model.dofs()
     out = out if out is not None else DeviceArray(n, N, data.dtype, tile=data._state.tile)
     _lib.check(

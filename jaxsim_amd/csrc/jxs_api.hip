@@ -60,6 +60,7 @@ hipError_t launch_mode(int mode, int G, const jxs::KParams<T>& P, const unsigned
     case jxs::MODE_CRBA: return launch_g<T, jxs::MODE_CRBA>(G, P, mblk, A, s);
     case jxs::MODE_JAC: return launch_g<T, jxs::MODE_JAC>(G, P, mblk, A, s);
     case jxs::MODE_MINV: return launch_g<T, jxs::MODE_MINV>(G, P, mblk, A, s);
+    case jxs::MODE_GRAV: return launch_g<T, jxs::MODE_GRAV>(G, P, mblk, A, s);
     default: return launch_g<T, jxs::MODE_KIN>(G, P, mblk, A, s);
   }
 }
@@ -617,7 +618,10 @@ int jxs_inverse_dynamics(jxs_model* model, const void* state, const void* in_acc
 }
 int jxs_gravity_torques(jxs_model* model, const void* state, void* out_tau, int N, void* stream) {
   if (out_tau == nullptr) return fail(JXS_EINVAL, "null out_tau");
-  return run_any(model, jxs::MODE_ID, state, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, N, 1, stream,
+  // [round 3] a kernel of its own (MODE_GRAV) instead of the general RNEA evaluated at zero velocity: with v = 0 and
+  // zero accelerations every link "accelerates" with -g, so the torques are subtree sums of the link weights --
+  // no velocity rows, no prefix sums, no rotated inertias (jxs_core.h gravity_torques)
+  return run_any(model, jxs::MODE_GRAV, state, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, N, 1, stream,
                  out_tau);
 }
 int jxs_solver_fault_counts(jxs_model* model, int* counts2, int reset, void* stream) {

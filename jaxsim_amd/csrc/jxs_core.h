@@ -401,6 +401,10 @@ struct Core {
       jacobians(lane, lnk, level, jrow, is_joint, is_root, R0, R, r, Sl, Sa, vl, va, vBc, om);
       return;
     }
+    if (MODE == MODE_GRAV) {
+      gravity_torques(lane, jrow, level, child, is_joint, R, r, cL, mass, Sl, Sa);
+      return;
+    }
 
     // ---- external link wrenches in C -----------------------------------------------------
     V fl[3] = {V(T(0)), V(T(0)), V(T(0))}, fa[3] = {V(T(0)), V(T(0)), V(T(0))};
@@ -2146,6 +2150,46 @@ struct Core {
       load_slot_state(ps);
       contact_chunk<false>(lane, ps, R, r, vl, va, ra, pB, doff, vBc, om, fl, fa);
     }
+  }
+
+  // ==========================================================================================
+  // Joint torques of the gravity term g(q) = RNEA(q, v = 0, vdot = 0) (api/model.py:1897-1931, rbda/rnea.py:12-238).
+  // With zero velocities and accelerations every link has the spatial acceleration a_0 = -W_g of the base
+  // (rnea.py:139-152: a_i = a_lambda + S sdd + v x vJ), so f_i = M_i a_0 = [m_i a ; c_i x m_i a] with a = (0, 0, -g)
+  // in the world-aligned frame C: three non-zero components (f_z, n_x, n_y).  Backward pass (rnea.py:193-219) =
+  // subtree sums, tau_i = S_i . f_i.  MODE_GRAV: no velocity rows, no prefix sums, no rotated inertias.
+  JXS_HD void gravity_torques(const VI& lane, const VI& jrow, const VI& level, const VI* child, const VM& is_joint,
+                              const V* R, const V* r, const V* cL, const V& mass, const V* Sl, const V* Sa) const {
+    const V zero = V(T(0));
+    V cw[3];
+    mat3vec(R, cL, cw);
+    const V fz = mass * V(-P.g);  // (padding lanes carry mass 0)
+    V f3[3] = {fz, (cw[1] + r[1]) * fz, -((cw[0] + r[0]) * fz)};  // f_z, n_x = c_y f_z, n_y = -c_x f_z
+    const int first_level = P.floating ? 1 : 2;
+    for (int Lv = P.max_depth; Lv >= first_level; --Lv) {
+      const VM is_par = level == (Lv - 1);
+      const int nch = P.maxch(Lv);
+      if (nch >= 1) {
+        const VM ok = is_par && (child[0] >= 0);
+#pragma unroll
+        for (int e = 0; e < 3; ++e) f3[e] = f3[e] + vsel(ok, ln.from_next(f3[e]), zero);
+      }
+#pragma unroll
+      for (int k = 1; k < kMaxChildren; ++k) {
+        if (k < nch) {
+          const VM ok = is_par && (child[k] >= 0);
+          V g3[3];
+#pragma unroll
+          for (int e = 0; e < 3; ++e) g3[e] = ln.shfl(f3[e], child[k]);
+          ln.fence();
+#pragma unroll
+          for (int e = 0; e < 3; ++e) f3[e] = f3[e] + vsel(ok, g3[e], zero);
+        }
+      }
+    }
+    const V tq = Sl[2] * f3[0] + Sa[0] * f3[1] + Sa[1] * f3[2];
+    if (A.out_tau != nullptr) ln.gstore(A.out_tau, jrow, tq, is_joint, P.n);
+    if (A.out_a != nullptr) ln.gstore(A.out_a, jrow + 6, tq, is_joint, 6 + P.n);
   }
 
   // ==========================================================================================

@@ -192,9 +192,11 @@ enum Mode : int {
   MODE_STEP_RK4_RIGID = 7,  // RungeKutta4 with RigidContacts / RelaxedRigidContacts (contact forces solved at every stage)
   MODE_CRBA = 8,  // free_floating_mass_matrix: composite-rigid-body algorithm  rbda/crba.py:10-170, api/model.py:1553-1590
   MODE_JAC = 9,   // doubly-left full Jacobian and its derivative  rbda/jacobian.py:128-339
-  MODE_MINV = 10  // free_floating_mass_matrix_inverse  rbda/mass_inverse.py:11-233, api/model.py:1593-1631
+  MODE_MINV = 10,  // free_floating_mass_matrix_inverse  rbda/mass_inverse.py:11-233, api/model.py:1593-1631
+  MODE_GRAV = 11   // joint torques of free_floating_gravity_forces (RNEA at zero velocity and acceleration,
+                   // api/model.py:1897-1931): a dedicated kernel -- kinematics, subtree sums of the link weights, S . f
 };
-constexpr int kNumModes = 11;
+constexpr int kNumModes = 12;
 
 enum ForceRepr : int { REPR_INERTIAL = 0, REPR_BODY = 1, REPR_MIXED = 2 };  // api/common.py:39-47
 

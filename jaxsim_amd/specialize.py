@@ -114,8 +114,8 @@ def compile(model, dtype, mode: int = MODE_STEP, *, force: bool = False) -> path
     return out
 
 
-# forward dynamics, inverse dynamics, cached kinematics, mass matrix, Jacobians, mass-matrix inverse: on request
-QUERY_MODES = (1, 2, 3, 8, 9, 10)
+# forward dynamics, inverse dynamics, cached kinematics, mass matrix, Jacobians, mass-matrix inverse, gravity torques: on request
+QUERY_MODES = (1, 2, 3, 8, 9, 10, 11)
 
 
 def attach(dm, model, mode: int | None = None, *, build: bool = False) -> bool:
@@ -143,6 +143,29 @@ def attach(dm, model, mode: int | None = None, *, build: bool = False) -> bool:
             dm.__dict__.setdefault("_spec_files", {})[m] = p.name
             done = True
     return done
+
+
+MODE_GRAV = 11
+
+
+def ensure_mode(dm, model, mode: int) -> bool:
+    """Attach the specialised kernel of a query mode on its first use, following ``policy()`` (cached object, or
+    built now when the compiler is there).  Called by the API functions whose kernels are not part of ``modes_of``
+    (e.g. the gravity-torque kernel behind ``gravity_compensation_torques``).  True if the mode runs specialised."""
+    tried = dm.__dict__.setdefault("_spec_tried", set())
+    if mode in tried:
+        return mode in attached_files(dm)
+    tried.add(mode)
+    how = policy()
+    if how == "off":
+        return False
+    try:
+        return attach(dm, model, mode, build=(how == "build"))
+    except (RuntimeError, OSError) as exc:
+        import warnings
+
+        warnings.warn(f"jaxsim_amd: no model-specialised kernel for mode {mode} ({exc}); using the generic one", RuntimeWarning, stacklevel=2)
+        return False
 
 
 def modes(dm) -> list[int]:

@@ -45,6 +45,7 @@ void run_group(const jxs::Packed<T>& pk, jxs::KArgs<T> a, int mode) {
       case jxs::MODE_CRBA: core.template run<jxs::MODE_CRBA>(); break;
       case jxs::MODE_JAC: core.template run<jxs::MODE_JAC>(); break;
       case jxs::MODE_MINV: core.template run<jxs::MODE_MINV>(); break;
+      case jxs::MODE_GRAV: core.template run<jxs::MODE_GRAV>(); break;
       default: core.template run<jxs::MODE_KIN>(); break;
     }
   }

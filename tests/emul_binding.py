@@ -20,7 +20,7 @@ _HERE = pathlib.Path(__file__).resolve().parent
 _SRC = _HERE / "emul" / "jxs_emul.cpp"
 _SO = _HERE / "emul" / "libjxs_emul.so"
 _ROOT = _HERE.parent
-MODE_STEP, MODE_FD, MODE_ID, MODE_KIN, MODE_CRBA, MODE_JAC, MODE_MINV = 0, 1, 2, 3, 8, 9, 10
+MODE_STEP, MODE_FD, MODE_ID, MODE_KIN, MODE_CRBA, MODE_JAC, MODE_MINV, MODE_GRAV = 0, 1, 2, 3, 8, 9, 10, 11
 MODE_STEP_DUO = MODE_STEP | 0x100  # the two-wave workgroup variant of the step kernel (inertia wave, then main wave)
 
 
@@ -82,7 +82,7 @@ def run(model, mode, state, *, tau=None, link_forces=None, force_repr=0, in_acc=
 
     st, tau, link_forces, in_acc = up(state), up(tau), up(link_forces), up(in_acc)
     state_out = st.copy() if mode in (MODE_STEP, MODE_STEP_DUO) else None
-    out_a = alloc(6 + n) if mode in (MODE_FD, MODE_ID) else (alloc((6 + n) ** 2) if mode in (MODE_CRBA, MODE_MINV) else None)
+    out_a = alloc(6 + n) if mode in (MODE_FD, MODE_ID, MODE_GRAV) else (alloc((6 + n) ** 2) if mode in (MODE_CRBA, MODE_MINV) else None)
     if mode == MODE_JAC:
         out_a = alloc(12 * (6 + n))
     out_H = alloc(nL * 12) if mode in (MODE_KIN, MODE_JAC) else None

@@ -866,3 +866,17 @@ def test_two_wave_rollout(models):
     for _ in range(25):
         d = oracle.step(model, d)
     assert helpers.rel_err(out, helpers.odata_to_block(model, d)) < 1e-8
+
+
+@pytest.mark.parametrize("name", ["double_pendulum", "cartpole", "chain5", "chain9f", "anymal", "icub"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_gravity_torque_kernel_matches_oracle(models, name, dtype):
+    """MODE_GRAV (jxs_gravity_torques): the joint part of ``free_floating_gravity_forces`` (api/model.py:1897-1931,
+    RNEA at zero velocity and acceleration) from the dedicated kernel -- subtree sums of the link weights."""
+    model = models(name)
+    N = 5
+    d = models.random_data(name, N, seed=21, dtype=dtype)
+    ref = oracle.free_floating_gravity_forces(model, helpers.upcast(d))[:, 6:]
+    out = eb.run(model, eb.MODE_GRAV, helpers.odata_to_block(model, d)).T[:, 6:]
+    scale = max(1.0, float(np.abs(ref).max()))
+    assert float(np.abs(out - ref).max()) / scale < (1e-12 if dtype == np.float64 else 2e-6)

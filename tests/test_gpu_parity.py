@@ -420,10 +420,14 @@ def test_rigid_step_matches_oracle_gpu(models, reduced_qp, key):
 # values in the comments) x 3, rounded up -- instead of a blanket 3e-3.  The box cases stay near 3e-3: 1 kg,
 # K = 1e5 with centimetres of penetration, contact forces of 1e3 N on four coplanar points whose 12x12 Delassus
 # matrix has rank 6 plus the 1e-6 shift.
-RIGID_FP32_TOL = {"anymal4": 3e-6, "icub8": 1.1e-4, "anymal16": 4.5e-5, "box4": 3e-3}  # 9.6e-7, 3.5e-5, 1.4e-5, 1.04e-3
-RIGID_RK4_FP32_TOL = {"box4": 2.5e-3, "anymal4": 3e-5, "icub8": 1.8e-4}  # 7.8e-4, 8.7e-6, 5.7e-5
+# anymal4 (one point per foot, the merged-sweep models): since the impact reuses the Delassus matrix of the force
+# solve as its preconditioner (jxs_rigid.inc rigid_impact) the conjugate gradients stop at their fp32 tolerance
+# (3e-5 of the initial residual) instead of landing on the solution in one step: 1.7e-5 where the rebuilt
+# preconditioner gave 9.6e-7 (fp64: 1e-9 either way).
+RIGID_FP32_TOL = {"anymal4": 5e-5, "icub8": 1.1e-4, "anymal16": 4.5e-5, "box4": 3e-3}  # 1.7e-5, 3.5e-5, 1.4e-5, 1.04e-3
+RIGID_RK4_FP32_TOL = {"box4": 2.5e-3, "anymal4": 5e-5, "icub8": 1.8e-4}  # 7.8e-4, < 3e-5, 5.7e-5
 RK4FAST_FP32_TOL = {("relaxed", "box8"): 4.5e-5, ("relaxed", "anymal16"): 1.5e-5, ("relaxed", "icub16"): 9e-5, ("rigid", "box4"): 2.5e-3,
-                    ("rigid", "anymal4"): 7.5e-6}  # 1.4e-5, 4.6e-6, 2.9e-5, 8.2e-4, 2.4e-6  # fmt: skip
+                    ("rigid", "anymal4"): 1.1e-4}  # 1.4e-5, 4.6e-6, 2.9e-5, 8.2e-4, 3.5e-5  # fmt: skip
 
 
 @pytest.mark.parametrize("key,tol", list(RIGID_FP32_TOL.items()))

@@ -54,6 +54,9 @@ def main():
         d = zoo.random_data(robot, args.envs, seed=0, dtype=dtype)
     data = js.data.JaxSimModelData.from_state_block(model, helpers.odata_to_block(model, d), 2)
     dm = runtime.device_model(model, dtype)
+    from jaxsim_amd import specialize
+
+    specialize.ensure_mode(dm, model, specialize.MODE_GRAV)
     lib = _lib.load()
     stream = runtime.Stream()
     runtime.set_stream(stream)
