@@ -51,7 +51,7 @@ def kernel_source_sha():
 
 def profiled_traffic(model_name, n_envs, dtype_name):
     """(bytes per launch | None, note) for the configuration that was profiled."""
-    for tag in ("r02", "r01"):
+    for tag in ("r03", "r02", "r01"):
         try:
             with open(os.path.join(ROOT, "profiles", f"{tag}_pmc.json")) as f:
                 prof = json.load(f)
@@ -64,6 +64,21 @@ def profiled_traffic(model_name, n_envs, dtype_name):
         if sha is not None and sha != kernel_source_sha():
             return None, f"profiles/{tag}_pmc.json was measured on other kernel sources ({sha}); re-run tools/profile_round.sh"
         return prof.get("traffic_bytes_per_launch"), f"profiles/{tag}_pmc.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, mean per launch)"
+    return None, "no PMC profile committed"
+
+
+def profiled_config5_traffic():
+    """HBM-side bytes per launch of the config-5 step kernel (tools/profile_round.sh c5_pmc_* passes), or None when the
+    committed profile was taken on other kernel sources."""
+    for tag in ("r03",):
+        try:
+            with open(os.path.join(ROOT, "profiles", f"{tag}_pmc.json")) as f:
+                prof = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if prof.get("kernel_source_sha") != kernel_source_sha():
+            return None, f"profiles/{tag}_pmc.json was measured on other kernel sources; re-run tools/profile_round.sh"
+        return prof.get("config5_traffic_bytes_per_launch"), f"profiles/{tag}_pmc.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE of jxs_kernel<float,16,MODE_STEP_RIGID>, mean per launch)"
     return None, "no PMC profile committed"
 
 
@@ -221,6 +236,10 @@ def other_contact_models(dtype, stream, steps=200, warmup=20):
         quad = build_quadruped_rigid()
         out["config5_rigid_contacts"] = timed(quad, 4096, 100, True, f"jxs_kernel<{tname},16,MODE_STEP_RIGID>") | {
             "workload": "anymal12 synthetic, RigidContacts (4 points), tau = RNEA gravity term every step (jxs_gravity_torques + jxs_step)"}  # fmt: skip
+        if np.dtype(dtype) == np.float32:
+            tr, note = profiled_config5_traffic()
+            out["config5_rigid_contacts"]["roofline"]["traffic"] = tr
+            out["config5_rigid_contacts"]["roofline"]["traffic_source"] = note
     except Exception as e:
         out["config5_rigid_contacts"] = {"error": repr(e)}
     try:

@@ -2,7 +2,7 @@
 # round 3, GPU call I: gravity-torque kernel (MODE_GRAV), config 5 loop, parity suite
 set -u
 R=$PWD
-OUT=$R/gpurun_out/r03_i
+OUT=$R/gpurun_out/r03_j
 mkdir -p "$OUT"
 timeout 900 python -m pytest tests -m gpu -q > "$OUT/pytest.log" 2>&1; echo "pytest rc=$?"
 tail -5 "$OUT/pytest.log"

@@ -23,6 +23,7 @@ python bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/bench_steps20.json" 2> "$
 # kernels of a timing build of the library (cd jaxsim_amd/csrc && JXS_EXTRA_FLAGS=-DJXS_PHASE_TIMING JXS_OUT=libjaxsim_amd_timing.so bash build.sh)
 export JAXSIM_AMD_SPEC_EXTRA_FLAGS=-DJXS_PHASE_TIMING
 JAXSIM_AMD_SPECIALIZE=1 python tools/phase_timing.py > "$OUT/phases.log" 2>&1
+JXS_DUO=1 JAXSIM_AMD_SPECIALIZE=1 python tools/phase_timing.py > "$OUT/phases_two_wave.log" 2>&1
 for a in "4 4096" "4 4096 rigid standing" "16 4096" "16 4096 relaxed standing" "32 1024 relaxed standing"; do
   JAXSIM_AMD_SPECIALIZE=1 python tools/phase_timing_rigid.py $a >> "$OUT/phases_contact_models.log" 2>&1
 done
@@ -32,6 +33,13 @@ if [ -f jaxsim_amd/csrc/libjaxsim_amd_timing.so ]; then
   JAXSIM_AMD_SPECIALIZE=0 JAXSIM_AMD_LIB=$R/jaxsim_amd/csrc/libjaxsim_amd_timing.so python tools/phase_timing_rigid.py 4 4096 > "$OUT/phases_contact_models_generic.log" 2>&1
 fi
 python tools/fp32_error_gpu.py 512 > "$OUT/fp32_error_gpu.log" 2>&1
-python tools/experiments/env_per_lane.py > "$OUT/env_per_lane.log" 2>&1
 timeout 60 tools/ubench/issue_rate > "$OUT/issue_rate.log" 2>&1
+timeout 120 tools/ubench/cu_share > "$OUT/cu_share.log" 2>&1
+for duo in 0 1; do JXS_DUO=$duo timeout 300 python tools/sweep.py --sizes 1024,2048,4096,65536 --steps 1000 2>&1 | sed "s/^/JXS_DUO=$duo /" >> "$OUT/sweep.log"; done
+# PMC pass for the config-5 kernel (HBM-side traffic of the rigid-contact step)
+cd /tmp
+BC="python $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline --saturated-envs 0"   # (with the secondary contact-model figures: config 5 runs inside)
+rocprofv3 --output-format csv --kernel-trace --pmc FETCH_SIZE -d "$OUT/c5_pmc_fetch" -- $BC > "$OUT/c5_pmc_fetch.log" 2>&1
+rocprofv3 --output-format csv --kernel-trace --pmc WRITE_SIZE -d "$OUT/c5_pmc_write" -- $BC > "$OUT/c5_pmc_write.log" 2>&1
+cd "$R"
 tail -c 600 "$OUT/bench_N1.json"

@@ -60,6 +60,25 @@ if summary:
     sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
     import bench
 
+    # config 5 (quadruped, RigidContacts): HBM-side traffic of its step kernel from the c5_pmc_* passes
+    c5 = {}
+    for d in sorted(run.glob("c5_pmc_*")):
+        f = glob.glob(str(d / "*" / "*counter_collection.csv"))
+        if not f:
+            continue
+        agg = collections.defaultdict(list)
+        for r in csv.DictReader(open(f[0])):
+            if "jxs_kernel<float, 16, 6," in r["Kernel_Name"]:
+                agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for k, v in agg.items():
+            c5[k] = sum(v) / len(v)
+    if "FETCH_SIZE" in c5 and "WRITE_SIZE" in c5:
+        summary["config5_traffic_bytes_per_launch"] = 2 * c5["FETCH_SIZE"] * 1024 + c5["WRITE_SIZE"] * 1024
+        lines_c5 = (f"Config 5 step kernel (`jxs_kernel<float,16,MODE_STEP_RIGID>`, 4096 environments): FETCH_SIZE {c5['FETCH_SIZE'] * 1024 / 1e6:.2f} MB raw "
+                    f"(x2 = {2 * c5['FETCH_SIZE'] * 1024 / 1e6:.2f} MB), WRITE_SIZE {c5['WRITE_SIZE'] * 1024 / 1e6:.2f} MB per launch.")
+        with open(out / f"{tag}_summary.md", "a") as fh:
+            pass
+        lines += [lines_c5, ""]
     summary["config"] = {"model": "icub23", "envs": 1024, "dtype": "float32"}
     summary["kernel_source_sha"] = bench.kernel_source_sha()
     summary["kernel"] = headline_kernel
@@ -76,6 +95,7 @@ for src, dst in (("phases.log", "phase_cycles.txt"), ("phases_generic.log", "pha
                  ("phases_contact_models.log", "phase_cycles_contact_models.txt"),
                  ("phases_contact_models_generic.log", "phase_cycles_contact_models_generic_kernel.txt"),
                  ("bench_N1.json", "bench_N1.json"), ("bench_steps20.json", "bench_steps20.json"),
-                 ("fp32_error_gpu.log", "fp32_error_gpu.txt"), ("issue_rate.log", "issue_rate_ubench.txt"), ("c5.log", "c5_bench.txt")):  # fmt: skip
+                 ("fp32_error_gpu.log", "fp32_error_gpu.txt"), ("issue_rate.log", "issue_rate_ubench.txt"), ("c5.log", "c5_bench.txt"),
+                 ("phases_two_wave.log", "phase_cycles_two_wave.txt"), ("cu_share.log", "cu_share_ubench.txt"), ("sweep.log", "sweep_batch_sizes.txt")):  # fmt: skip
     if (run / src).exists():
         shutil.copy(run / src, out / f"{tag}_{dst}")
