@@ -136,6 +136,21 @@ struct DeviceLanes {
     *o = r.x + r.y;
     return true;
   }
+  // o[j] = a[j] + s * b[j] for j in [lo, hi): pairs as v_pk_fma_f32, an odd tail as one v_fma (bounds are constants after
+  // unrolling at every call site)
+  static __device__ __forceinline__ bool axpy_range_packed(const float* a, float s, const float* b, float* o, int lo, int hi) {
+    const f2 ss = {s, s};
+    int j = lo;
+#pragma unroll
+    for (; j + 1 < hi; j += 2) {
+      const f2 r = __builtin_elementwise_fma(ss, f2{b[j], b[j + 1]}, f2{a[j], a[j + 1]});
+      o[j] = r.x, o[j + 1] = r.y;
+    }
+    if (j < hi) o[j] = __builtin_fmaf(s, b[j], a[j]);
+    return true;
+  }
+  template <typename... Args>
+  static __device__ __forceinline__ bool axpy_range_packed(const double*, Args...) { return false; }
   template <typename... Args>
   static __device__ __forceinline__ bool axpy6_packed(const double*, Args...) { return false; }
   template <typename... Args>

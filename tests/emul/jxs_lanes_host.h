@@ -139,6 +139,8 @@ struct HostLanes {
   template <typename... Args>
   static bool axpy6_packed(Args...) { return false; }
   template <typename... Args>
+  static bool axpy_range_packed(Args...) { return false; }
+  template <typename... Args>
   static bool scale6_packed(Args...) { return false; }
   template <typename... Args>
   static bool add6_packed(Args...) { return false; }
