@@ -29,6 +29,7 @@ struct KTail {
   int id_zero_vel;
   long long* dbg;
   int* faults;
+  int flags;
 };
 
 // OCC2 (rigid contact modes only): compiled for two waves per SIMD (at most 256 registers; a few values go
@@ -60,7 +61,8 @@ __global__ __launch_bounds__(64, VARIANT == KV_OCC2 ? 2 : 1) void jxs_kernel(con
   A.rti = reinterpret_cast<const int*>(pre_mblk + jxs::mblk_off_rti<T>(G));
   A.chunks = pre_mblk + jxs::mblk_off_chunks<T>(G);
   A.in_a = tail.in_a, A.out_a = tail.out_a, A.out_H = tail.out_H, A.out_V = tail.out_V, A.out_tau = tail.out_tau;
-  A.id_zero_vel = tail.id_zero_vel, A.dbg = tail.dbg, A.faults = tail.faults;
+  A.id_zero_vel = tail.id_zero_vel, A.dbg = tail.dbg, A.faults = tail.faults, A.flags = tail.flags;
+  if constexpr (VARIANT == KV_OCC2) A.flags |= 1;  // two waves per SIMD: 256 registers, no room for MFMA accumulator tiles
   // the state-block rows of SURVEY section 8(a) row D, derived from the preloaded joint count instead of loaded
   P.n_rows = pre_n_rows, P.n = pre_n;
   P.row_pos = 0, P.row_quat = 3, P.row_s = 7, P.row_vlin = 7 + pre_n, P.row_vang = 10 + pre_n, P.row_sd = 13 + pre_n;
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(256, 1) void jxs_kernel_duo(const T* pre_state_in, 
   A.rti = reinterpret_cast<const int*>(pre_mblk + jxs::mblk_off_rti<T>(G));
   A.chunks = pre_mblk + jxs::mblk_off_chunks<T>(G);
   A.in_a = tail.in_a, A.out_a = tail.out_a, A.out_H = tail.out_H, A.out_V = tail.out_V, A.out_tau = tail.out_tau;
-  A.id_zero_vel = tail.id_zero_vel, A.dbg = tail.dbg, A.faults = tail.faults;
+  A.id_zero_vel = tail.id_zero_vel, A.dbg = tail.dbg, A.faults = tail.faults, A.flags = tail.flags;
   P.n_rows = pre_n_rows, P.n = pre_n;
   P.row_pos = 0, P.row_quat = 3, P.row_s = 7, P.row_vlin = 7 + pre_n, P.row_vang = 10 + pre_n, P.row_sd = 13 + pre_n;
   P.row_m = 13 + 2 * pre_n;
@@ -137,7 +139,9 @@ hipError_t launch_one(const jxs::KParams<T>& P, const unsigned char* mblk, const
   const bool rows = P.row_mode && (MODE == jxs::MODE_STEP || MODE == jxs::MODE_ROLLOUT || MODE == jxs::MODE_FD ||
                                    MODE == jxs::MODE_STEP_RK4);
   size_t lds_bytes = rows ? sizeof(T) * (size_t)envs_per_wave * jxs::lds_words_per_env(G) : 0;
-  const KTail<T> tail{A.in_a, A.out_a, A.out_H, A.out_V, A.out_tau, A.id_zero_vel, A.dbg, A.faults};
+  const char* const no_mfma = std::getenv("JXS_NO_MFMA");  // developer A/B: the vector path of the contact solvers' Cholesky
+  const KTail<T> tail{A.in_a, A.out_a, A.out_H, A.out_V, A.out_tau, A.id_zero_vel, A.dbg, A.faults,
+                      A.flags | ((no_mfma != nullptr && std::atoi(no_mfma) != 0) ? 1 : 0)};
   if (MODE == jxs::MODE_STEP_RIGID || MODE == jxs::MODE_STEP_RK4_RIGID) {
     lds_bytes = sizeof(T) * (size_t)envs_per_wave * jxs::rigid_lds_words_per_env(P.n_cp, P.rigid);
     if (lds_bytes > 64 * 1024) {  // beyond the default dynamic-LDS window (gfx950 has 160 KiB per CU)

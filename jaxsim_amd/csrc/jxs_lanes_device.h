@@ -170,6 +170,7 @@ struct DeviceLanes {
   T* lds_;      // LDS scratch of this environment (row-distributed ABA), else unused
   int* flag_;   // two-wave workgroups: progress word of the inertia wave (behind the environments' areas), else null
 
+  int wpe_;     // LDS words per environment (the areas of the environments of a wave follow each other)
   int blk_;     // tile of every batched array this wave works on (= blockIdx.x for single-wave workgroups)
   int wslot_;   // developer profiling build: stamp column block of this wave (the inertia wave stamps at +32)
 
@@ -188,6 +189,7 @@ struct DeviceLanes {
     env_ok_ = env_ < N;
     sub_ = wl / G;
     T* const pair_base = lds_base + (size_t)pair * ((64 / G) * lds_words_per_env + kDuoFlagWords);
+    wpe_ = lds_words_per_env;
     lds_ = pair_base + sub_ * lds_words_per_env;
     flag_ = duo ? reinterpret_cast<int*>(pair_base + (64 / G) * lds_words_per_env) : nullptr;
   }
@@ -525,6 +527,101 @@ struct DeviceLanes {
     }
     if constexpr ((N - done) % 2 == 1) v[N - 1] = p[N - 1];
   }
+  // ---- MFMA tiles of the contact solvers' blocked Cholesky (jxs_rigid.inc rigid_cholesky) -------------------------
+  // The trailing matrix of the factorisation lives in v_mfma_f32_16x16x4_f32 accumulator tiles -- lower-triangular
+  // tile pairs (ti >= tj) of every environment of the wave -- and takes the rank-3 update of a block column
+  // A22 -= L21 L21^T as ONE matrix instruction per tile (K = 3 padded to 4) instead of 27 multiply-adds and 18 LDS
+  // reads per lane and previous block column (tools/ubench/mfma_trailing.hip: 10.5x on that work, bit-identical:
+  // an f32 MFMA is an exact chain of fused multiply-adds over k).  Lane layout, chosen so that the panel can be
+  // written straight into the packed lower triangle in the LDS (rows are contiguous there): with the operands
+  // swapped (A = rows of tile column tj, B = rows of tile row ti) lane (i16, k4) of the accumulator holds
+  // matrix ROW 16 ti + i16 and COLUMNS 16 tj + 4 k4 + v, v = 0..3.
+  static constexpr bool kHasMfma = sizeof(T) == 4;
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  template <int NTMAX>
+  struct ChTiles {
+    static constexpr int E = 64 / G;
+    static constexpr int NQ = NTMAX * (NTMAX + 1) / 2;
+    v4f C[E][NQ > 0 ? NQ : 1];  // (NTMAX = 0: the placeholder of builds without the matrix-core path)
+    float* base[E];  // the environments' LDS areas
+    int nt, n, i16, k4;
+    static __device__ __forceinline__ int tri(int i) { return (i * (i + 1)) / 2; }
+    __device__ __forceinline__ ChTiles(const DeviceLanes& ln, int nt_, int n_) : nt(nt_), n(n_) {
+      const int wl = threadIdx.x & 63;
+      i16 = wl & 15, k4 = wl >> 4;
+#pragma unroll
+      for (int e = 0; e < E; ++e) base[e] = reinterpret_cast<float*>(ln.lds_) + (e - ln.sub_) * ln.wpe_;
+    }
+    // C = H (lower triangle, zero elsewhere)
+    __device__ __forceinline__ void load() {
+#pragma unroll
+      for (int ti = 0; ti < NTMAX; ++ti) {
+        const int row = 16 * ti + i16;
+#pragma unroll
+        for (int tj = 0; tj <= ti; ++tj) {
+          if (16 * tj < n && 16 * ti < n) {
+#pragma unroll
+            for (int e = 0; e < E; ++e)
+#pragma unroll
+              for (int v = 0; v < 4; ++v) {
+                const int col = 16 * tj + 4 * k4 + v;
+                const bool ok = row < n && col <= row;
+                C[e][ti * (ti + 1) / 2 + tj][v] = ok ? base[e][nt + tri(ok ? row : 0) + (ok ? col : 0)] : 0.0f;
+              }
+          } else {
+#pragma unroll
+            for (int e = 0; e < E; ++e) C[e][ti * (ti + 1) / 2 + tj] = v4f{0, 0, 0, 0};
+          }
+        }
+      }
+    }
+    // columns 3 jc .. 3 jc + 2 of the trailing matrix (rows from the diagonal down) -> their places in the LDS triangle
+    __device__ __forceinline__ void extract(int jc) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const int col = 3 * jc + c, tjc = col >> 4, kq = (col >> 2) & 3, v = col & 3;
+#pragma unroll
+        for (int tj = 0; tj < NTMAX; ++tj) {
+          if (tj != tjc) continue;
+#pragma unroll
+          for (int ti = tj; ti < NTMAX; ++ti) {
+            if (16 * ti >= n) continue;
+            const int row = 16 * ti + i16;
+            const bool mine = (k4 == kq) && row >= col && row < n;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+              const v4f t = C[e][ti * (ti + 1) / 2 + tj];
+              const float val = v == 0 ? t.x : v == 1 ? t.y : v == 2 ? t.z : t.w;
+              if (mine) base[e][nt + tri(row) + col] = val;
+            }
+          }
+        }
+      }
+    }
+    // A22 -= L21 L21^T with the factor block column jc (just written to the LDS)
+    __device__ __forceinline__ void update(int jc) {
+      const int done = 3 * (jc + 1);  // rows / columns below `done` are finished
+      float op[E][NTMAX];
+#pragma unroll
+      for (int ti = 0; ti < NTMAX; ++ti) {
+        const bool need = 16 * (ti + 1) > done && 16 * ti < n;
+        const int row = 16 * ti + i16;
+        const bool ok = need && k4 < 3 && row >= done && row < n;
+#pragma unroll
+        for (int e = 0; e < E; ++e) op[e][ti] = ok ? base[e][nt + tri(ok ? row : 0) + (ok ? 3 * jc + k4 : 0)] : 0.0f;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ti = 0; ti < NTMAX; ++ti)
+#pragma unroll
+        for (int tj = 0; tj <= ti; ++tj) {
+          if (!(16 * (tj + 1) > done && 16 * ti < n)) continue;  // (wave-uniform) finished tile column / beyond the matrix
+#pragma unroll
+          for (int e = 0; e < E; ++e)
+            C[e][ti * (ti + 1) / 2 + tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(-op[e][tj], op[e][ti], C[e][ti * (ti + 1) / 2 + tj], 0, 0, 0);
+        }
+    }
+  };
   // Between LDS writes and reads of ANOTHER lane's data: the hardware keeps the DS queue of a wave in
   // order, but the compiler reasons per thread (it may forward a masked store to the following load, or
   // order the two sides of a lane-divergent branch either way) -- this fence pins program order.

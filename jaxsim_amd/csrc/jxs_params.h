@@ -280,6 +280,7 @@ struct KArgs {
   int id_zero_vel;     // MODE_ID: evaluate at zero velocity (gravity term g(q), api/model.py:1897-1931)
   long long* dbg;      // developer builds (-DJXS_PHASE_TIMING): [blocks][kDbgSlots] cycle stamps, else null
   int* faults;         // [2] environments whose QP contact-force solve / impact solve was discarded (non-finite), or null
+  int flags;           // developer switches of a launch: bit 0 = no MFMA in the contact solvers' Cholesky (A/B against the vector path)
   int has_lds;         // the launch has the per-environment LDS area of the row layout (known when the wave starts: a
                        // compile-time constant in the specialised / common-feature kernels): the thirteen
                        // environment-uniform rows of the state are fetched by ONE load instruction and spread through it

@@ -147,6 +147,16 @@ struct HostLanes {
   template <typename... Args>
   static bool dot6_packed(Args...) { return false; }
 
+  // (the MFMA tiles of the contact solvers' Cholesky exist on the device only: the emulation runs the vector path,
+  // which performs the same fused multiply-adds in the same order)
+  static constexpr bool kHasMfma = false;
+  template <int NTMAX>
+  struct ChTiles {
+    ChTiles(const HostLanes&, int, int) {}
+    void load() {}
+    void extract(int) {}
+    void update(int) {}
+  };
   int env_;
   int N_;
   mutable std::vector<T_> lds_;

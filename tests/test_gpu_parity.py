@@ -523,6 +523,45 @@ def test_rk4fast_step_matches_oracle_gpu(models, reduced_qp, kind, key):
     assert out32.dtype == np.float32 and err32 < RK4FAST_FP32_TOL[(kind, key)]
 
 
+@pytest.mark.parametrize("kind,key", [("rigid", "anymal16"), ("relaxed", "icub16")])
+def test_mfma_cholesky_equals_the_vector_path_bitwise_gpu(models, kind, key, monkeypatch):
+    """[round 3] The blocked Cholesky of the contact solvers with its trailing updates on the matrix cores
+    (v_mfma_f32_16x16x4_f32 accumulator tiles, jxs_lanes_device.h ChTiles) -- an opt-in build (-DJXS_MFMA_CHOLESKY,
+    measured slower end to end, profiles/r03_mfma_cholesky_experiment.md), here as a model-specialised kernel built
+    with that flag.  It performs the same fused multiply-adds in the same order as the vector path: the fp32 step
+    results must be IDENTICAL to the default build's and to its own vector path (JXS_NO_MFMA=1), over several steps of
+    random states and of standing ones (every sole point active)."""
+    from jaxsim_amd import runtime, specialize
+
+    name, idx, params = (RELAXED_CASES if kind == "relaxed" else RIGID_CASES)[key]
+    make = helpers.relaxed_model if kind == "relaxed" else helpers.rigid_model
+    model = make(models(name), idx, **params)
+
+    def run(d):
+        g = to_gpu(model, d)
+        for _ in range(3):
+            g = js.model.step(model, g)
+        return g.state_block()
+
+    datas = (models.random_data(name, 37, seed=5, dtype=np.float32), helpers.standing_data(model, 37, seed=2, dtype=np.float32, noise=0.003))
+    model.__dict__.pop("_device", None)
+    default = [run(d) for d in datas]
+    monkeypatch.setenv("JAXSIM_AMD_SPEC_EXTRA_FLAGS", "-DJXS_MFMA_CHOLESKY")
+    monkeypatch.setenv("JAXSIM_AMD_SPECIALIZE", "1")  # (pre-built by __graft_entry__.build(); built here otherwise)
+    model.__dict__.pop("_device", None)
+    try:
+        assert specialize.modes(runtime.device_model(model, np.float32)) == [specialize.MODE_STEP_RIGID]
+        tiles = [run(d) for d in datas]
+        monkeypatch.setenv("JXS_NO_MFMA", "1")
+        vector = [run(d) for d in datas]
+    finally:
+        model.__dict__.pop("_device", None)
+    for a, b, c in zip(default, tiles, vector):
+        assert np.isfinite(b).all()
+        np.testing.assert_array_equal(b, c)
+        np.testing.assert_array_equal(b, a)
+
+
 def test_rk4fast_is_refused_for_soft_contacts_gpu(models):
     with pytest.raises(Exception, match="RungeKutta4Fast"):
         model = helpers.with_params(models("box"), integrator=ja.IntegratorType.RungeKutta4Fast)

@@ -43,3 +43,10 @@ rocprofv3 --output-format csv --kernel-trace --pmc FETCH_SIZE -d "$OUT/c5_pmc_fe
 rocprofv3 --output-format csv --kernel-trace --pmc WRITE_SIZE -d "$OUT/c5_pmc_write" -- $BC > "$OUT/c5_pmc_write.log" 2>&1
 cd "$R"
 tail -c 600 "$OUT/bench_N1.json"
+# summarise on the box (the raw per-dispatch CSVs are tens of MB; only gpurun_out/ <= 64 MiB travels back), keep the
+# kernel statistics, drop the raw traces
+python tools/summarize_profiles.py "gpurun_out/$1" "${2:-r03}" "$OUT/profiles" > "$OUT/summarize.log" 2>&1
+find "$OUT" -name "*counter_collection.csv" -delete
+find "$OUT" -name "*kernel_trace.csv" -delete
+find "$OUT" -name "*.db" -delete
+du -sh "$OUT"

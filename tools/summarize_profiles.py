@@ -10,8 +10,8 @@ import sys
 
 run = pathlib.Path(sys.argv[1])  # e.g. gpurun_out/r8
 tag = sys.argv[2]  # e.g. r01
-out = pathlib.Path(__file__).resolve().parent.parent / "profiles"
-out.mkdir(exist_ok=True)
+out = pathlib.Path(sys.argv[3]) if len(sys.argv) > 3 else pathlib.Path(__file__).resolve().parent.parent / "profiles"
+out.mkdir(exist_ok=True, parents=True)
 lines = [f"# rocprofv3 summary {tag} (source: {run})", ""]
 ks = glob.glob(str(run / "stats" / "*" / "*_kernel_stats.csv"))
 if ks:
