@@ -633,7 +633,10 @@ struct Core {
       for (int k = 0; k < 6; ++k) U[k] = V(T(0));
       // fixed base: nothing propagates into link 0 -- except for the mass-matrix inverse, where the reference treats
       // the base of every model as a free body (rbda/mass_inverse.py:118-178)
-      const int first_level = (P.floating || MODE == MODE_MINV) ? 1 : 2;
+      // ... and for the rigid contact models, whose contact solve uses the inverse of the FULL free-floating mass matrix
+      // for every model (rbda/contacts/rigid.py:296, relaxed_rigid.py:370): the base factor below answers unit wrenches
+      // as a free body there, while the dynamics themselves (pass 3, the response to the solved forces) keep it fixed
+      const int first_level = (P.floating || MODE == MODE_MINV || kRigid) ? 1 : 2;
       const int max_depth = P.max_depth;
       const unsigned long long mc0 = P.maxch_nib[0], mc1 = P.maxch_nib[1], mc2 = P.maxch_nib[2], mc3 = P.maxch_nib[3];
       const unsigned long long nonadj = P.nonadj_levels;
@@ -796,9 +799,9 @@ struct Core {
   #pragma unroll
         for (int k = 0; k < 6; ++k) tf.U[k] = U[k], tf.S6[k] = S6[k];
         tf.inv_d = inv_d;
-        if (P.floating) ldl6_factor(MA, tf);
+        ldl6_factor(MA, tf);  // (fixed-base models too: the contact solves treat the base as a free body, see pass 2)
         RigidPoints rp;
-        rigid_points(ps0, R, r, vl, va, pB, rp);
+        rigid_points(ps0, R, r, vl, va, pB, vBc, om, rp);
         const VI zero_lane = lane * 0;
         if (stage < kImpactStage) {
           // contact forces, then nudot = nudot_free + M^-1 J^T f  (api/ode.py:57-131); with RungeKutta4 at

@@ -154,7 +154,6 @@ std::string pack_model(const jxs_model_desc& d, Packed<T>& out) {
     // one point per lane, three rows of the QP per point, both matrices in LDS (jxs_rigid.inc)
     if (n_en > kRigidMaxPoints) return "RigidContacts / RelaxedRigidContacts: at most 32 enabled collidable points are supported";
     if (n_chunks > 1) return "RigidContacts needs every enabled collidable point in one lane group";
-    if (!d.floating_base) return "RigidContacts on a fixed-base model is not supported";
     if (P.rigid == 1 && (!(d.regularization_delassus >= 0.0) || !(d.solver_tol > 0.0))) return "invalid RigidContacts options";
     if (P.rigid == 2) {
       // RelaxedRigidContactsParams.valid (relaxed_rigid.py:184-200); a zero time constant or width, or a

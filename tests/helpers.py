@@ -248,3 +248,35 @@ def actuation_state(models, name, model, N, seed, dtype):
     return d
 
 
+
+
+# ---- fixed-base models with the rigid contact models [round 3] ---------------------------------------
+def fixed_cart_model(kind="rigid", **params):
+    """The cartpole with collision shapes (fixed base: a rail, a cart on a prismatic joint, a pole) with the four
+    BOTTOM corners of the cart as rigid / relaxed contact points: a fixed-base mechanism touching the ground."""
+    m = ja.JaxSimModel.build_from_model_description(robots.cartpole_urdf(with_collisions=True))
+    kdp = m.kin_dyn_parameters
+    idx = [int(i) for i in np.flatnonzero((np.asarray(kdp.contact_body) == 1) & (np.asarray(kdp.contact_point)[:, 2] < 0))][:4]
+    assert len(idx) == 4 and not m.floating_base()
+    return (rigid_model if kind == "rigid" else relaxed_model)(m, idx, **params)
+
+
+def fixed_cart_data(model, N, seed=0, dtype=np.float64, base_velocity=0.0):
+    """States of ``fixed_cart_model`` whose cart corners straddle the ground (the rail is 1 m above the base origin,
+    so the base sits about 1 m below the terrain), with an optional stored base velocity -- which the reference's
+    impact writes into fixed-base states anyway (rbda/contacts/rigid.py:391-446)."""
+    d = oracle.random_model_data(model, batch_size=N, seed=seed, dtype=dtype,
+                                 base_pos_bounds=((-1, -1, -1.0), (1, 1, -1.0)), base_rpy_bounds=((-0.15, -0.15, -3), (0.15, 0.15, 3)))  # fmt: skip
+    # lower every environment until its lowest enabled point is 0 .. 8 mm under the ground (half of them stay above)
+    rng0 = np.random.default_rng(seed + 500)
+    pz, _ = oracle.collidable_points_pos_vel(model, link_transforms=d.link_transforms, link_velocities=d.link_velocities)
+    en = np.flatnonzero(model.kin_dyn_parameters.contact_enabled)
+    shift = -pz[:, en, 2].min(axis=1) - rng0.uniform(0.0, 0.008, N)
+    pos = np.array(d.base_position, dtype=np.float64)
+    pos[:, 2] += shift
+    d = dataclasses.replace(d, base_position=pos.astype(dtype)).update_caches(model)
+    if base_velocity:
+        rng = np.random.default_rng(seed + 1000)
+        d = dataclasses.replace(d, base_linear_velocity=(base_velocity * rng.uniform(-1, 1, (N, 3))).astype(dtype),
+                                base_angular_velocity=(base_velocity * rng.uniform(-1, 1, (N, 3))).astype(dtype)).update_caches(model)
+    return d

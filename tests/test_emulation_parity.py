@@ -709,9 +709,9 @@ def test_rigid_unsupported_configurations_are_rejected(models):
 
     with pytest.raises(RuntimeError, match="at most 32"):
         eb.layout(helpers.rigid_model(models("sphere"), list(range(50))))
-    with pytest.raises(RuntimeError, match="fixed-base"):
-        fixed = ja.JaxSimModel.build_from_model_description(ja.robots.cartpole_urdf(with_collisions=True))
-        eb.layout(helpers.rigid_model(fixed, [0, 1, 2, 3]))
+    # [round 3] fixed-base models are accepted (test_fixed_base_rigid_contacts_match_oracle)
+    fixed = ja.JaxSimModel.build_from_model_description(ja.robots.cartpole_urdf(with_collisions=True))
+    assert eb.layout(helpers.rigid_model(fixed, [0, 1, 2, 3])).group >= 4
 
 
 @pytest.mark.parametrize("fixed_base,max_back", [(True, 1), (False, 1), (False, 3)])
@@ -880,3 +880,28 @@ def test_gravity_torque_kernel_matches_oracle(models, name, dtype):
     out = eb.run(model, eb.MODE_GRAV, helpers.odata_to_block(model, d)).T[:, 6:]
     scale = max(1.0, float(np.abs(ref).max()))
     assert float(np.abs(out - ref).max()) / scale < (1e-12 if dtype == np.float64 else 2e-6)
+
+
+@pytest.mark.parametrize("kind", ["rigid", "relaxed"])
+@pytest.mark.parametrize("base_velocity", [0.0, 0.3])
+def test_fixed_base_rigid_contacts_match_oracle(reduced_qp, kind, base_velocity):
+    """[round 3] RigidContacts / RelaxedRigidContacts on a FIXED-base model (a cart on a rail touching the ground).
+    The reference solves the contact problem with the inverse of the full free-floating mass matrix -- the base
+    answers as a free body -- while the forward dynamics keep it fixed, evaluates J nu and Jdot nu with the stored
+    base velocity, and its impact writes a base velocity into the state (rbda/contacts/rigid.py:222-446,
+    relaxed_rigid.py:330-420, rbda/mass_inverse.py:118-178): reproduced, checked over several steps so that the
+    base velocity written by the first impact feeds the next steps."""
+    model = helpers.fixed_cart_model(kind) if kind == "rigid" else helpers.fixed_cart_model(kind, mu=0.5)
+    N = 6
+    d = helpers.fixed_cart_data(model, N, seed=3, base_velocity=base_velocity)
+    p, _ = oracle.collidable_points_pos_vel(model, link_transforms=d.link_transforms, link_velocities=d.link_velocities)
+    en = np.flatnonzero(model.kin_dyn_parameters.contact_enabled)
+    assert (p[:, en, 2] < 0).any() and (p[:, en, 2] > 0).any()
+    blk = helpers.odata_to_block(model, d)
+    ref = d
+    for _ in range(3):
+        ref = oracle.step(model, ref)
+        blk = eb.run(model, eb.MODE_STEP, blk)
+    assert helpers.rel_err(blk, helpers.odata_to_block(model, ref)) < 1e-7
+    if kind == "rigid":  # the impact moved the "fixed" base, as in the reference
+        assert np.abs(ref.base_linear_velocity).max() > 1e-8

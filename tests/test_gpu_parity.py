@@ -562,6 +562,30 @@ def test_mfma_cholesky_equals_the_vector_path_bitwise_gpu(models, kind, key, mon
         np.testing.assert_array_equal(b, a)
 
 
+@pytest.mark.parametrize("kind", ["rigid", "relaxed"])
+@pytest.mark.parametrize("base_velocity", [0.0, 0.3])
+def test_fixed_base_rigid_contacts_match_oracle_gpu(reduced_qp, kind, base_velocity):
+    """[round 3] RigidContacts / RelaxedRigidContacts on a FIXED-base model (a cart on a rail touching the ground):
+    the contact solve with the base as a free body (the reference inverts the full free-floating mass matrix for every
+    model), fixed-base forward dynamics, J nu / Jdot nu with the stored base velocity, and an impact that writes a
+    base velocity into the state -- as rbda/contacts/rigid.py:222-446 and relaxed_rigid.py:330-420 do.  Three steps,
+    fp64 1e-7 against the oracle; fp32 within 1e-3."""
+    model = helpers.fixed_cart_model(kind) if kind == "rigid" else helpers.fixed_cart_model(kind, mu=0.5)
+    d = helpers.fixed_cart_data(model, 41, seed=3, base_velocity=base_velocity)
+    ref, g = d, to_gpu(model, d)
+    for _ in range(3):
+        ref = oracle.step(model, ref)
+        g = js.model.step(model, g)
+    assert helpers.rel_err(g.state_block(), helpers.odata_to_block(model, ref)) < 1e-7
+    if kind == "rigid":
+        assert np.abs(ref.base_linear_velocity).max() > 1e-8  # the impact moved the "fixed" base, as in the reference
+    d32 = helpers.fixed_cart_data(model, 41, seed=3, dtype=np.float32, base_velocity=base_velocity)
+    out32 = js.model.step(model, to_gpu(model, d32)).state_block()
+    err32 = helpers.rel_err(out32, helpers.odata_to_block(model, oracle.step(model, helpers.upcast(d32))))
+    helpers.note(f"fixed_base_fp32/{kind}/{base_velocity}", err32)
+    assert out32.dtype == np.float32 and err32 < 1e-3
+
+
 def test_rk4fast_is_refused_for_soft_contacts_gpu(models):
     with pytest.raises(Exception, match="RungeKutta4Fast"):
         model = helpers.with_params(models("box"), integrator=ja.IntegratorType.RungeKutta4Fast)
