@@ -41,7 +41,8 @@ struct Core {
   const L& ln;
   // rigid contact models: bit j set = point j is active in some environment of this wave (set by
   // rigid_delassus; block columns of the other points are skipped by the factorisation and the solves)
-  mutable unsigned rg_amask_ = 0xffffffffu;
+  using PointMask = unsigned long long;  // one bit per collidable point of the rigid contact models (<= 64)
+  mutable PointMask rg_amask_ = ~0ull;
   mutable VM rg_mine_;  // this lane's own point has its bit set
   mutable int rg_hoff_ = 0;  // LDS word offset of the working matrix H: behind Q, or Q itself (relaxed model)
   // rigid contact models: active set the Delassus matrix in the LDS was last built for (rigid_contact_forces) and

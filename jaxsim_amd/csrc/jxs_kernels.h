@@ -185,7 +185,7 @@ hipError_t launch_one(const jxs::KParams<T>& P, const unsigned char* mblk, const
   }
 #ifndef JXS_SPEC_ASSIGN  // (a model-specialised build has these constants anyway)
   constexpr bool kHasCommon = (MODE == jxs::MODE_STEP || MODE == jxs::MODE_ROLLOUT) && G >= 8;
-  static const bool common_off = std::getenv("JXS_DISABLE_COMMON_VARIANT") != nullptr;  // developer knob: A/B against KV_GENERIC
+  const bool common_off = std::getenv("JXS_DISABLE_COMMON_VARIANT") != nullptr;  // developer knob, read per launch: A/B against KV_GENERIC
   if (kHasCommon && !common_off && P.floating == 1 && P.any_suc == 0 && P.seg_dpp_ok == 1 && P.row_mode == 1 && P.flat == 1 && P.pq_half == 1 &&
       P.anchored == 1 && P.rigid == 0 && P.rk4fast == 0 && P.n_chunks == 1) {
     hipLaunchKernelGGL((jxs_kernel<T, G, MODE, kHasCommon ? KV_COMMON : KV_GENERIC>), dim3(blocks), dim3(64), lds_bytes, s, A.state_in,

@@ -474,6 +474,10 @@ struct DeviceLanes {
   // a value that is the same in every lane by construction, handed to the compiler as a scalar (loops
   // over it become SALU loops instead of exec-masked ones)
   static __device__ __forceinline__ unsigned uniform(unsigned x) { return (unsigned)__builtin_amdgcn_readfirstlane((int)x); }
+  static __device__ __forceinline__ unsigned long long uniform(unsigned long long x) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)x), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(x >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+  }
   // LDS scratch of this group's environment (the workgroup is one wave: program order is the
   // only synchronisation needed between a ds_write and a later ds_read of another lane)
   __device__ __forceinline__ void lds_write(int addr, T v) const { lds_[addr] = v; }

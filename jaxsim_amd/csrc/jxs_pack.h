@@ -124,6 +124,8 @@ std::string pack_model(const jxs_model_desc& d, Packed<T>& out) {
   // RungeKutta4 keeps the tangential deformation of every point in registers across its stages: one
   // point chunk, so up to 64 points get a lane each (semi-implicit Euler prefers 32 lanes + 2 chunks)
   if (d.integrator != JXS_INTEGRATOR_SEMI_IMPLICIT_EULER && n_en > 32 && n_en <= 64) G = 64;
+  // the rigid contact models solve for all enabled points at once: one lane each
+  if (d.contact_model != JXS_CONTACT_SOFT && n_en > 32 && n_en <= 64) G = 64;
   if (const char* e = std::getenv("JXS_MIN_LANES")) {  // developer knob: at least this many lanes per environment (A/B of the lane-group size)
     const int g = std::atoi(e);
     if (g == 8 || g == 16 || g == 32 || g == 64) G = std::max(G, g);
@@ -152,7 +154,14 @@ std::string pack_model(const jxs_model_desc& d, Packed<T>& out) {
            "version corrupts the tangential deformation of SoftContacts and fails without collidable points";
   if (P.rigid) {
     // one point per lane, three rows of the QP per point, both matrices in LDS (jxs_rigid.inc)
-    if (n_en > kRigidMaxPoints) return "RigidContacts / RelaxedRigidContacts: at most 32 enabled collidable points are supported";
+    if (n_en > kRigidMaxPoints) return "RigidContacts / RelaxedRigidContacts: at most 64 enabled collidable points are supported";
+    {
+      // the Delassus matrix (and the working factor of RigidContacts) of one environment must fit the LDS of a CU
+      const size_t bytes = sizeof(T) * (size_t)(64 / G) * (size_t)rigid_lds_words_per_env(n_en, d.contact_model == JXS_CONTACT_RELAXED_RIGID ? 2 : 1);
+      if (bytes > (size_t)160 * 1024 && std::getenv("JXS_IGNORE_LDS_BUDGET") == nullptr)  // (the knob: host emulation of the tests only)
+        return "RigidContacts / RelaxedRigidContacts: the contact problem of this many enabled points does not fit the 160 KB of LDS of a CU "
+               "in this precision (64 points: fp32, or RelaxedRigidContacts in fp64)";
+    }
     if (n_chunks > 1) return "RigidContacts needs every enabled collidable point in one lane group";
     if (P.rigid == 1 && (!(d.regularization_delassus >= 0.0) || !(d.solver_tol > 0.0))) return "invalid RigidContacts options";
     if (P.rigid == 2) {

@@ -177,7 +177,7 @@ JXS_HD constexpr int rigid_lds_words_per_env(int n_cp, int rigid = 1) {
   return rigid_lds_merge_off(n_cp, rigid) + (n_cp <= 4 ? 4 * kRgMergeRec : 0);
 }
 constexpr int kQpMaxIter = 30;    // interior-point iterations (oracle/refrigid.py QP_MAX_ITER)
-constexpr int kRigidMaxPoints = 32;
+constexpr int kRigidMaxPoints = 64;  // one lane per point: a full wave ([round 3]: 32 -> 64; the point masks are 64 bits wide)
 constexpr int kDbgSlots = 64;      // developer profiling build: cycle stamps / counters per workgroup (the second wave of a two-wave workgroup stamps at +32)
 constexpr int kImpactCgIters = 5;  // preconditioned CG iterations of the impact solve (jxs_rigid.inc)
 

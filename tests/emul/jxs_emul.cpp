@@ -125,14 +125,10 @@ int run_typed(const jxs_model_desc* d, int mode, const void* state_in, void* sta
 
 }  // namespace
 
-extern "C" {
-
-const char* jxs_emul_last_error(void) { return g_err.c_str(); }
-void jxs_emul_set_debug(void* p) { g_dbg_ptr = p; }
-
-int jxs_emul_layout(const jxs_model_desc* d, jxs_layout* out) {
-  jxs::Packed<double> pk;
-  const std::string err = jxs::pack_model<double>(*d, pk);
+template <typename T>
+static int layout_typed(const jxs_model_desc* d, jxs_layout* out) {
+  jxs::Packed<T> pk;
+  const std::string err = jxs::pack_model<T>(*d, pk);
   if (!err.empty()) {
     g_err = err;
     return JXS_EINVAL;
@@ -141,6 +137,16 @@ int jxs_emul_layout(const jxs_model_desc* d, jxs_layout* out) {
   *out = jxs_layout{P.nL, P.n, P.n_points, P.n_rows, P.row_pos, P.row_quat, P.row_s,
                     P.row_vlin, P.row_vang, P.row_sd, P.row_m, pk.G, 64 / pk.G, d->dtype, P.row_mode};
   return JXS_OK;
+}
+
+extern "C" {
+
+const char* jxs_emul_last_error(void) { return g_err.c_str(); }
+void jxs_emul_set_debug(void* p) { g_dbg_ptr = p; }
+
+int jxs_emul_layout(const jxs_model_desc* d, jxs_layout* out) {
+  // (the precision matters: some limits -- the LDS budget of the rigid contact models -- depend on it)
+  return d->dtype == JXS_F64 ? layout_typed<double>(d, out) : layout_typed<float>(d, out);
 }
 
 int jxs_emul_run(const jxs_model_desc* d, int mode, const void* state_in, void* state_out, const void* tau,

@@ -184,6 +184,7 @@ struct HostLanes {
   }
   V env_bcast16(const V& x, int src) const { return V(x.v[src]); }
   static unsigned uniform(unsigned x) { return x; }
+  static unsigned long long uniform(unsigned long long x) { return x; }
   VI env_bits(const VM& m) const {
     int b = 0;
     for (int i = 0; i < G && i < 32; ++i) b |= m.v[i] ? (1 << i) : 0;

@@ -579,8 +579,8 @@ def test_relaxed_box_settles_known_answer(models, dtype):
 def test_relaxed_unsupported_configurations_are_rejected(models):
     import jaxsim_amd as ja
 
-    with pytest.raises(RuntimeError, match="at most 32"):
-        eb.layout(helpers.relaxed_model(models("sphere"), list(range(50))))
+    # [round 3] up to 64 enabled points (one lane each): the 50-point sphere is accepted
+    assert eb.layout(helpers.relaxed_model(models("sphere"), list(range(50)))).group == 64
     with pytest.raises(RuntimeError, match="RelaxedRigidContactsParams"):
         eb.layout(helpers.relaxed_model(models("box"), [0, 1, 2, 3], time_constant=0.0))
 
@@ -707,8 +707,11 @@ def test_rk4fast_is_refused_where_the_reference_is_broken(models):
 def test_rigid_unsupported_configurations_are_rejected(models):
     import jaxsim_amd as ja
 
-    with pytest.raises(RuntimeError, match="at most 32"):
-        eb.layout(helpers.rigid_model(models("sphere"), list(range(50))))
+    # [round 3] up to 64 enabled points; the two triangles of RigidContacts for 50 points are 182 KB in fp64: more than
+    # the LDS of a CU -- refused with the reason (fp32 fits: 91 KB)
+    with pytest.raises(RuntimeError, match="does not fit"):
+        eb.layout(helpers.rigid_model(models("sphere"), list(range(50))), np.float64)
+    assert eb.layout(helpers.rigid_model(models("sphere"), list(range(50))), np.float32).group == 64
     # [round 3] fixed-base models are accepted (test_fixed_base_rigid_contacts_match_oracle)
     fixed = ja.JaxSimModel.build_from_model_description(ja.robots.cartpole_urdf(with_collisions=True))
     assert eb.layout(helpers.rigid_model(fixed, [0, 1, 2, 3])).group >= 4
@@ -905,3 +908,22 @@ def test_fixed_base_rigid_contacts_match_oracle(reduced_qp, kind, base_velocity)
     assert helpers.rel_err(blk, helpers.odata_to_block(model, ref)) < 1e-7
     if kind == "rigid":  # the impact moved the "fixed" base, as in the reference
         assert np.abs(ref.base_linear_velocity).max() > 1e-8
+
+
+@pytest.mark.parametrize("kind", ["rigid", "relaxed"])
+def test_fifty_point_sphere_matches_oracle(models, reduced_qp, kind, monkeypatch):
+    """[round 3] More than 32 enabled points (one lane per point, 64-bit point masks): the reference's sphere collision
+    shape is 50 points (parsers/rod/utils.py:200-204).  fp64 against the oracle: 1e-7 (RigidContacts: QP + impact) /
+    1e-9 (RelaxedRigidContacts).  (The emulation ignores the LDS budget that refuses 50-point RigidContacts in fp64 on
+    the device -- two 150 x 150 triangles of doubles are 182 KB; the GPU test runs that case in fp32.)"""
+    monkeypatch.setenv("JXS_IGNORE_LDS_BUDGET", "1")
+    make = helpers.rigid_model if kind == "rigid" else helpers.relaxed_model
+    model = make(models("sphere"), list(range(50)), **(dict(K=1e5) if kind == "rigid" else dict(mu=0.5)))
+    N = 3
+    d = oracle.random_model_data(model, batch_size=N, seed=6, base_pos_bounds=((-1, -1, 0.04), (1, 1, 0.07)),
+                                 base_rpy_bounds=((-3, -3, -3), (3, 3, 3)))  # sunk 3 .. 6 cm: the bottom cap of points touches
+    p, _ = oracle.collidable_points_pos_vel(model, link_transforms=d.link_transforms, link_velocities=d.link_velocities)
+    assert (p[..., 2] < 0).sum(axis=1).min() >= 5
+    ref = oracle.step(model, d)
+    out = eb.run(model, eb.MODE_STEP, helpers.odata_to_block(model, d))
+    assert helpers.rel_err(out, helpers.odata_to_block(model, ref)) < (1e-7 if kind == "rigid" else 1e-9)

@@ -175,6 +175,33 @@ def test_data_build_and_properties(models):
         js.data.JaxSimModelData.build(model, joint_positions=np.zeros(5))
 
 
+@pytest.mark.parametrize("name", ["icub", "anymal", "cartpole", "double_pendulum"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("kernels", ["common_variant", "run_time_flags"])
+def test_step_matches_oracle_through_the_librarys_own_kernels(models, name, dtype, kernels, monkeypatch):
+    """[ADVICE r2] The zoo models above have pre-built model-specialised kernels, so every other step test runs those.
+    Here the same step goes through what a model WITHOUT a specialised object gets: the ahead-of-time common-feature
+    variant (`KV_COMMON`, floating-base soft-contact models in the row layout) and the kernel that reads every flag at
+    run time (`KV_GENERIC`)."""
+    from jaxsim_amd import runtime, specialize
+
+    model = models(name)
+    monkeypatch.setenv("JAXSIM_AMD_SPECIALIZE", "0")
+    if kernels == "run_time_flags":
+        monkeypatch.setenv("JXS_DISABLE_COMMON_VARIANT", "1")
+    model.__dict__.pop("_device", None)
+    try:
+        N = 70
+        d = models.random_data(name, N, seed=4, dtype=dtype)
+        tau, f = helpers.random_inputs(model, N, 5, dtype)
+        ref = oracle.step(model, helpers.upcast(d), link_forces=f.astype(np.float64), joint_force_references=tau.astype(np.float64))
+        out = js.model.step(model, to_gpu(model, d), link_forces=f, joint_force_references=tau)
+        assert specialize.modes(runtime.device_model(model, dtype)) == []
+        assert helpers.rel_err(out.state_block(), helpers.odata_to_block(model, ref)) < helpers.tol_of(dtype, name)
+    finally:
+        model.__dict__.pop("_device", None)
+
+
 # ---- BASELINE.json full sizes: size-independent properties ---------------------------------------
 
 
@@ -598,6 +625,30 @@ def test_fixed_base_rigid_contacts_match_oracle_gpu(reduced_qp, kind, base_veloc
     err32 = helpers.rel_err(out32, helpers.odata_to_block(model, oracle.step(model, helpers.upcast(d32))))
     helpers.note(f"fixed_base_fp32/{kind}/{base_velocity}", err32)
     assert out32.dtype == np.float32 and err32 < 1e-3
+
+
+@pytest.mark.parametrize("kind", ["rigid", "relaxed"])
+def test_fifty_point_sphere_matches_oracle_gpu(models, reduced_qp, kind):
+    """[round 3] More than 32 enabled points with the rigid contact models: the reference's 50-point sphere collision
+    shape (parsers/rod/utils.py:200-204), one lane per point in a 64-lane group.  RelaxedRigidContacts in fp64 (1e-9)
+    and fp32; RigidContacts in fp32 only -- its two 150 x 150 triangles of doubles (182 KB) exceed the LDS of a CU and
+    the model is refused in fp64 with that reason (the host emulation checks the fp64 arithmetic, tests/
+    test_emulation_parity.py::test_fifty_point_sphere_matches_oracle)."""
+    make = helpers.rigid_model if kind == "rigid" else helpers.relaxed_model
+    model = make(models("sphere"), list(range(50)), **(dict(K=1e5) if kind == "rigid" else dict(mu=0.5)))
+    kw = dict(base_pos_bounds=((-1, -1, 0.04), (1, 1, 0.07)), base_rpy_bounds=((-3, -3, -3), (3, 3, 3)))
+    if kind == "relaxed":
+        d = oracle.random_model_data(model, batch_size=9, seed=6, **kw)
+        out = js.model.step(model, to_gpu(model, d))
+        assert helpers.rel_err(out.state_block(), helpers.odata_to_block(model, oracle.step(model, d))) < 1e-9
+    else:
+        with pytest.raises(Exception, match="does not fit"):
+            js.model.step(model, to_gpu(model, oracle.random_model_data(model, batch_size=2, seed=6, **kw)))
+    d32 = oracle.random_model_data(model, batch_size=9, seed=6, dtype=np.float32, **kw)
+    out32 = js.model.step(model, to_gpu(model, d32)).state_block()
+    err32 = helpers.rel_err(out32, helpers.odata_to_block(model, oracle.step(model, helpers.upcast(d32))))
+    helpers.note(f"sphere50_fp32/{kind}", err32)
+    assert out32.dtype == np.float32 and np.isfinite(out32).all() and err32 < 3e-3
 
 
 def test_rk4fast_is_refused_for_soft_contacts_gpu(models):

@@ -2,7 +2,7 @@
 # round 3, GPU call M: default build after making the matrix-core Cholesky an opt-in build; full parity suite
 set -u
 R=$PWD
-OUT=$R/gpurun_out/r03_n
+OUT=$R/gpurun_out/r03_o
 mkdir -p "$OUT"
 timeout 900 python -m pytest tests -m gpu -q > "$OUT/pytest.log" 2>&1; echo "pytest rc=$?"
 tail -4 "$OUT/pytest.log"

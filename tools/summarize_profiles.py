@@ -76,8 +76,6 @@ if summary:
         summary["config5_traffic_bytes_per_launch"] = 2 * c5["FETCH_SIZE"] * 1024 + c5["WRITE_SIZE"] * 1024
         lines_c5 = (f"Config 5 step kernel (`jxs_kernel<float,16,MODE_STEP_RIGID>`, 4096 environments): FETCH_SIZE {c5['FETCH_SIZE'] * 1024 / 1e6:.2f} MB raw "
                     f"(x2 = {2 * c5['FETCH_SIZE'] * 1024 / 1e6:.2f} MB), WRITE_SIZE {c5['WRITE_SIZE'] * 1024 / 1e6:.2f} MB per launch.")
-        with open(out / f"{tag}_summary.md", "a") as fh:
-            pass
         lines += [lines_c5, ""]
     summary["config"] = {"model": "icub23", "envs": 1024, "dtype": "float32"}
     summary["kernel_source_sha"] = bench.kernel_source_sha()
