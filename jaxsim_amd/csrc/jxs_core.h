@@ -1081,10 +1081,17 @@ struct Core {
         V Rn[9], rn[3];
         mat3mul(Ra, R, Rn);
         mat3vec(Ra, r, rn);
+        if (P.jump_pad) {  // sources beyond the base are a padding lane with the identity transform: no select
 #pragma unroll
-        for (int e = 0; e < 9; ++e) R[e] = vsel(ok, Rn[e], R[e]);
+          for (int e = 0; e < 9; ++e) R[e] = Rn[e];
 #pragma unroll
-        for (int e = 0; e < 3; ++e) r[e] = vsel(ok, rn[e] + ra[e], r[e]);
+          for (int e = 0; e < 3; ++e) r[e] = rn[e] + ra[e];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 9; ++e) R[e] = vsel(ok, Rn[e], R[e]);
+#pragma unroll
+          for (int e = 0; e < 3; ++e) r[e] = vsel(ok, rn[e] + ra[e], r[e]);
+        }
       }
     }
   }
@@ -1153,10 +1160,15 @@ struct Core {
           ta[e] = ln.shfl(xa[e], src);
         }
         ln.fence();
+        if (P.jump_pad) {  // (sources beyond the base are a padding lane holding zeros)
 #pragma unroll
-        for (int e = 0; e < 3; ++e) {
-          xl[e] = xl[e] + vsel(ok, tl[e], V(T(0)));
-          xa[e] = xa[e] + vsel(ok, ta[e], V(T(0)));
+          for (int e = 0; e < 3; ++e) xl[e] = xl[e] + tl[e], xa[e] = xa[e] + ta[e];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 3; ++e) {
+            xl[e] = xl[e] + vsel(ok, tl[e], V(T(0)));
+            xa[e] = xa[e] + vsel(ok, ta[e], V(T(0)));
+          }
         }
       }
     }
@@ -1390,16 +1402,15 @@ struct Core {
 #pragma unroll
               for (int k = 0; k < kRowExtra; ++k) {
                 if (k >= npull) break;
-                const VI src = rt.pull[Lv][k];
-                const VM ok = src >= 0;
+                const VI src = rt.pull[Lv][k];  // (nothing to pull: an idle row lane, whose values are zero)
                 V g[7];
 #pragma unroll
                 for (int j = 0; j < 6; ++j) g[j] = ln.shfl(Ma[j], src);
                 g[6] = ln.shfl(pa, src);
                 ln.fence();
 #pragma unroll
-                for (int j = 0; j < 6; ++j) accM[j] = accM[j] + vsel(ok, g[j], zero);
-                accp = accp + vsel(ok, g[6], zero);
+                for (int j = 0; j < 6; ++j) accM[j] = accM[j] + g[j];
+                accp = accp + g[6];
               }
             }
           }
@@ -1734,14 +1745,13 @@ struct Core {
 #pragma unroll
               for (int k = 0; k < kRowExtra; ++k) {
                 if (k >= npull) break;
-                const VI src = rt.pull[Lv][k];
-                const VM ok = src >= 0;
+                const VI src = rt.pull[Lv][k];  // (nothing to pull: an idle row lane, zeros)
                 V g[6];
 #pragma unroll
                 for (int j = 0; j < 6; ++j) g[j] = ln.shfl(Ma[j], src);
                 ln.fence();
 #pragma unroll
-                for (int j = 0; j < 6; ++j) accM[j] = accM[j] + vsel(ok, g[j], zero);
+                for (int j = 0; j < 6; ++j) accM[j] = accM[j] + g[j];
               }
             }
           }
@@ -1871,11 +1881,10 @@ struct Core {
 #pragma unroll
               for (int k = 0; k < kRowExtra; ++k) {
                 if (k >= npull) break;
-                const VI src = rt.pull[Lv][k];
-                const VM ok = src >= 0;
+                const VI src = rt.pull[Lv][k];  // (nothing to pull: an idle row lane, zero)
                 const V g = ln.shfl(pa, src);
                 ln.fence();
-                accp = accp + vsel(ok, g, zero);
+                accp = accp + g;
               }
             }
           }

@@ -641,8 +641,13 @@ struct DeviceLanes {
   static __device__ __forceinline__ const U* al16(const U* p) { return static_cast<const U*>(__builtin_assume_aligned(p, 16)); }
   __device__ __forceinline__ V lconstf(const T* tbl, int field) const { return al16(tbl)[lane_ * kLtfStride + field]; }
   // packed integer tables (jxs_params.h: lti_get / rti_get): the dword loads of one record merge into 128-bit loads
-  __device__ __forceinline__ VI lconsti(const int* tbl, int field) const { return lti_get(al16(tbl) + lane_ * kLtiPackWords, field); }
-  __device__ __forceinline__ VI rconsti(const int* tbl, int field) const { return rti_get(al16(tbl) + lane_ * kRtiPackWords, field); }
+  // (indexed from the uniform table pointer: scalar-base addressing, no 64-bit vector address per record)
+  __device__ __forceinline__ VI lconsti(const int* tbl, int field) const {
+    return lti_unpack((unsigned)al16(tbl)[lane_ * kLtiPackWords + lti_word(field)], field);
+  }
+  __device__ __forceinline__ VI rconsti(const int* tbl, int field) const {
+    return rti_unpack((unsigned)al16(tbl)[lane_ * kRtiPackWords + rti_word(field)], field);
+  }
   __device__ __forceinline__ VI hconsti(const int* head, int chunk) const { return head[chunk * G + lane_]; }
   // per-slot point tables (slot-major, stride 4)
   __device__ __forceinline__ V ploadf(const T* tbl, int field, int slot) const { return al16(tbl)[slot * kPtStride + field]; }
@@ -654,13 +659,19 @@ struct DeviceLanes {
   // exec-mask branch, and every load can be issued up front.  Arrays are allocated in whole tiles,
   // so the environments beyond N of the last tile are readable (their stores are masked).
   static constexpr int TILE = 64 / G;
-  __device__ __forceinline__ size_t at(int row, int nrows) const {
-    return ((size_t)blk_ * nrows + row) * TILE + sub_;
+  // [round 3] address = (wave-uniform start of this wave's tile, SGPRs) + (32-bit lane offset): the loads and stores
+  // then use the scalar-base addressing mode and need no 64-bit vector arithmetic per access (the prologue and the
+  // epilogue of the step kernel each carried ~3 such instructions per row: ~70 of 1950 vector instructions).
+  template <typename U>
+  __device__ __forceinline__ U* tile_base(U* base, int nrows) const {
+    const unsigned b = (unsigned)__builtin_amdgcn_readfirstlane(blk_);  // (uniform by construction; tell the compiler)
+    return base + (size_t)b * (size_t)((unsigned)nrows * (unsigned)TILE);
   }
-  __device__ __forceinline__ V gload(const T* base, int row, int nrows) const { return base[at(row, nrows)]; }
-  __device__ __forceinline__ V gload_u(const T* base, int row, int nrows) const { return base[at(row, nrows)]; }
+  __device__ __forceinline__ unsigned lane_off(int row) const { return (unsigned)row * (unsigned)TILE + (unsigned)sub_; }
+  __device__ __forceinline__ V gload(const T* base, int row, int nrows) const { return tile_base(base, nrows)[lane_off(row)]; }
+  __device__ __forceinline__ V gload_u(const T* base, int row, int nrows) const { return tile_base(base, nrows)[lane_off(row)]; }
   __device__ __forceinline__ void gstore(T* base, int row, T val, bool mask, int nrows) const {
-    if (mask && env_ok_) base[at(row, nrows)] = val;
+    if (mask && env_ok_) tile_base(base, nrows)[lane_off(row)] = val;
   }
 };
 

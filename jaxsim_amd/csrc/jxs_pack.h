@@ -66,6 +66,7 @@ std::string kernel_spec_string(const Packed<T>& pk, int mode) {
   }
   add("flat", P.flat), add("enable_friction", P.enable_friction), add("pq_half", P.pq_half), add("anchored", P.anchored);
   add("rigid", P.rigid), add("n_cp", P.n_cp), add("rg_merge", P.rg_merge), add("rr_refine", P.rr_refine), add("rk4fast", P.rk4fast);
+  add("jump_pad", P.jump_pad);
   s.pop_back();
   return s;
 }
@@ -415,6 +416,18 @@ std::string pack_model(const jxs_model_desc& d, Packed<T>& out) {
       s = e + 1;
     }
   }
+  // [round 3] Pointer jumping without selects: when the group has a padding lane, every source "beyond the base"
+  // (and every source of the padding lanes themselves) points at the first padding lane.  Padding lanes carry the
+  // identity transform and zero velocity / acceleration contributions (defaults above: no joint, identity pre- and
+  // successor transforms), and composing with them changes nothing -- so the rounds of forward kinematics and of
+  // the 6-vector prefix sums need no `source valid ?` selects (54 of the step kernel's 273 v_cndmask).
+  P.jump_pad = 0;
+  if (nL < G) {
+    P.jump_pad = 1;
+    for (int lane = 0; lane < G; ++lane)
+      for (int k = 0; k < kMaxRounds; ++k)
+        if (out.lti[(size_t)lane * kLtiStride + LI_JUMP + k] < 0) out.lti[(size_t)lane * kLtiStride + LI_JUMP + k] = nL;
+  }
   // ---- row-distributed ABA tables ---------------------------------------------------------------
   P.row_mode = 0;
   P.row_cross_levels = 0;
@@ -482,6 +495,11 @@ std::string pack_model(const jxs_model_desc& d, Packed<T>& out) {
       for (int lane = 0; lane < G; ++lane)
         for (int L = 0; L < kRowLevels; ++L)
           if (RI(RT_REC + L, lane) < 0) RI(RT_REC + L, lane) = lds_zero_rec(G);
+      // [round 3] "no extra child to pull" = pull from lane 6: an idle row lane (rows 6 and 7 of a slot read the zero
+      // record at every level), whose row of Ma and whose pa are zero -- the pulled values are added without a select
+      for (int lane = 0; lane < G; ++lane)
+        for (int f = RT_PULL; f < RT_PULL + kRowLevels * kRowExtra; ++f)
+          if (RI(f, lane) < 0) RI(f, lane) = 6;
       P.row_mode = 1;
     }
   }

@@ -75,9 +75,10 @@ constexpr int kLtiStride = (LI_COUNT + 3) / 4 * 4;  // staging table of the pack
 // per lane are step time; unpacking is one v_bfe_i32 per USED field.
 constexpr int kLtiPackWords = 8;  // dwords per lane in the packed table (LI_COUNT = 24 bytes used)
 static_assert(LI_COUNT <= 4 * kLtiPackWords, "packed lane-int record too small");
+JXS_HD constexpr int lti_word(int field) { return field >> 2; }  // word of the lane's record that holds the field
+JXS_HD int lti_unpack(unsigned w, int field) { return (int)(w << (24 - 8 * (field & 3))) >> 24; }
 JXS_HD int lti_get(const int* rec, int field) {  // rec: the lane's packed record
-  const unsigned w = (unsigned)rec[field >> 2];
-  return (int)(w << (24 - 8 * (field & 3))) >> 24;
+  return lti_unpack((unsigned)rec[lti_word(field)], field);
 }
 
 // ---- per-point-slot tables (slots = n_chunks * G), slot-major with stride 4: ptf[slot * 4 + field] ----
@@ -117,15 +118,13 @@ constexpr int kRtiStride = (RT_COUNT + 3) / 4 * 4;  // staging table of the pack
 //   bytes 0..15  RT_REC[8] as unsigned 16-bit LDS word offsets | byte 16 RT_FC | bytes 17..40 RT_PULL[8][3] (signed
 //   bytes) | bytes 41..48 RT_PPULL[8] (signed bytes)
 constexpr int kRtiPackWords = 16;
-JXS_HD int rti_get(const int* rec, int field) {
-  if (field < RT_FC) {
-    const unsigned w = (unsigned)rec[field >> 1];
-    return (int)((field & 1) ? (w >> 16) : (w & 0xffffu));
-  }
-  const int b = field == RT_FC ? 16 : (field < RT_PPULL ? 17 + (field - RT_PULL) : 41 + (field - RT_PPULL));
-  const unsigned w = (unsigned)rec[b >> 2];
-  return (int)(w << (24 - 8 * (b & 3))) >> 24;
+JXS_HD constexpr int rti_byte(int field) { return field == RT_FC ? 16 : (field < RT_PPULL ? 17 + (field - RT_PULL) : 41 + (field - RT_PPULL)); }
+JXS_HD constexpr int rti_word(int field) { return field < RT_FC ? (field >> 1) : (rti_byte(field) >> 2); }
+JXS_HD int rti_unpack(unsigned w, int field) {
+  if (field < RT_FC) return (int)((field & 1) ? (w >> 16) : (w & 0xffffu));
+  return (int)(w << (24 - 8 * (rti_byte(field) & 3))) >> 24;
 }
+JXS_HD int rti_get(const int* rec, int field) { return rti_unpack((unsigned)rec[rti_word(field)], field); }
 // LDS record layout (words).  Every group a lane reads together is 16-byte aligned and contiguous, because
 // one ds instruction costs a lone wave ~14 cycles whether it moves 4 or 16 bytes (tools/ubench/issue_rate.hip):
 //   8 r + 0..5  row r of M (6x6),  8 r + 6  pA[r],  8 r + 7  S[r]      (r < 6: what row lane r reads, two b128)
@@ -254,6 +253,8 @@ struct KParams {
   T rr_rcoef;                    // 2 mu^2 (1 + mu^2)
   T rr_tiny;                     // smallest positive normal number (guards pow of a non-positive base)
   int rr_refine;                 // refinement steps against the operator applied through the tree
+  int jump_pad;                  // 1: pointer-jumping sources beyond the base point at a padding lane that holds the identity
+                                 // transform and zero vectors (no selects in the rounds); 0: they are -1 (no padding lane: nL == G)
   int rk4fast;                   // RungeKutta4Fast: contact forces and position derivatives of the initial state (api/integrators.py:170-276)
   int anchored;                  // 1: the ABA of step / forward dynamics refers every first-child chain to its leaf link (fp32 conditioning)
 };
