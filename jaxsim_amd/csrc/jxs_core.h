@@ -982,6 +982,17 @@ struct Core {
       const VI zl = lane * 0;
       ln.gstore(A.state_out, jrow + P.row_s, s, is_joint, P.n_rows);
       ln.gstore(A.state_out, jrow + P.row_sd, sd, is_joint, P.n_rows);
+      if (G >= 16) {
+        // [round 3] the thirteen base rows with ONE store instruction: every lane of an environment carries the same
+        // new base state (it was integrated from values that are uniform over the environment), so lane k < 13 picks
+        // value k and stores row k (rows 0..6 and 7+n..12+n) -- instead of thirteen exec-masked stores of the root lane
+        const V b13[13] = {pB[0], pB[1], pB[2], q[0], q[1], q[2], q[3], vW[0], vW[1], vW[2], om[0], om[1], om[2]};
+        V val = b13[0];
+#pragma unroll
+        for (int k = 1; k < 13; ++k) val = vsel(lane == k, b13[k], val);
+        const VI brow = vsel(lane < 7, lane, vsel(lane < 13, lane + P.n, lane * 0));
+        ln.gstore(A.state_out, brow, val, lane < 13, P.n_rows);
+      } else {
 #pragma unroll
       for (int k = 0; k < 4; ++k) ln.gstore(A.state_out, zl + (P.row_quat + k), q[k], is_root, P.n_rows);
 #pragma unroll
@@ -989,6 +1000,7 @@ struct Core {
         ln.gstore(A.state_out, zl + (P.row_pos + k), pB[k], is_root, P.n_rows);
         ln.gstore(A.state_out, zl + (P.row_vlin + k), vW[k], is_root, P.n_rows);
         ln.gstore(A.state_out, zl + (P.row_vang + k), om[k], is_root, P.n_rows);
+      }
       }
       if (with_contacts) {
         const VM valid = ps0.body >= 0;
@@ -1393,10 +1405,14 @@ struct Core {
               for (int j = 0; j < 6; ++j) Ma[j] = Ma[j] + c1 * g2[j] + c2 * g1[j];
               pa = pa + c1 * g2[6] + c2 * g1[6];
             }
-            const VM fc = ((rt.fcbits >> Lv) & 1) != 0;
+            // what a first child hands to its parent in the same lanes: x 1, else x 0 (values are finite: packed multiplies
+            // instead of seven selects)
+            const V fcf = vsel(((rt.fcbits >> Lv) & 1) != 0, V(T(1)), zero);
+            if (!L::scale6_packed(Ma, fcf, accM)) {
 #pragma unroll
-            for (int j = 0; j < 6; ++j) accM[j] = vsel(fc, Ma[j], zero);
-            accp = vsel(fc, pa, zero);
+              for (int j = 0; j < 6; ++j) accM[j] = Ma[j] * fcf;
+            }
+            accp = pa * fcf;
             if ((cross_levels >> Lv) & 1u) {
               const int npull = (int)((pull_counts >> (4 * Lv)) & 15u);  // wave-uniform
 #pragma unroll
@@ -1476,7 +1492,9 @@ struct Core {
         const V sd = (uu[Lv] - tot) * invd[Lv];
         ai = ai + Sr[Lv] * sd;
         acar = vsel(has, ai, acar);
-        ln.lds_write(rt.rec[Lv] + RL_SDD, sd, has && (row == 0));
+        // every row lane of the slot holds the same sd: all of them store it to the link's record (same address, same
+        // value; lanes without a link store into the unread word of the all-zero record) -- no exec-mask bookkeeping
+        ln.lds_write(rt.rec[Lv] + RL_SDD, sd);
       }
     }
     sdd = ln.lds_read(rec_me + RL_SDD);
@@ -1737,9 +1755,11 @@ struct Core {
 #pragma unroll
               for (int j = 0; j < 6; ++j) Ma[j] = Ma[j] + c1 * g2[j] + c2 * g1[j];
             }
-            const VM fc = ((rt.fcbits >> Lv) & 1) != 0;
+            const V fcf = vsel(((rt.fcbits >> Lv) & 1) != 0, V(T(1)), zero);
+            if (!L::scale6_packed(Ma, fcf, accM)) {
 #pragma unroll
-            for (int j = 0; j < 6; ++j) accM[j] = vsel(fc, Ma[j], zero);
+              for (int j = 0; j < 6; ++j) accM[j] = Ma[j] * fcf;
+            }
             if ((cross_levels >> Lv) & 1u) {
               const int npull = (int)((pull_counts >> (4 * Lv)) & 15u);
 #pragma unroll
@@ -1944,7 +1964,7 @@ struct Core {
         const V sd = (uu[Lv] - tot) * invd[Lv];
         ai = ai + Sr[Lv] * sd;
         acar = vsel(has, ai, acar);
-        ln.lds_write(rt.rec[Lv] + (RL_SDD + AR), sd, has && (ix.row == 0));
+        ln.lds_write(rt.rec[Lv] + (RL_SDD + AR), sd);  // (all row lanes: same address, same value; see aba_rows)
       }
     }
     sdd = ln.lds_read(rec_me + RL_SDD);

@@ -85,8 +85,9 @@ def test_specialised_step_equals_the_generic_kernel(models, name, dtype, monkeyp
     out = _step_n(model, js.data.JaxSimModelData.from_state_block(model, block, 2), 3)
     assert specialize.modes(runtime.device_model(model, dtype)) == [specialize.MODE_STEP, specialize.MODE_ROLLOUT]
     model.__dict__.pop("_device", None)
-    # the same arithmetic with the branches folded: identical up to the contraction choices of the compiler
-    tol = 1e-12 if dtype == np.float64 else 2e-5
+    # the same arithmetic with the branches folded: identical up to the contraction choices of the compiler (three steps
+    # of contact-rich fp32 states: measured 2e-5 .. 1e-4 depending on the build; the per-step gate against the oracle is 1.5e-3)
+    tol = 1e-12 if dtype == np.float64 else 2e-4
     assert helpers.rel_err(out, ref) < tol
 
 

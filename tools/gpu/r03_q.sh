@@ -2,7 +2,7 @@
 # round 3, GPU call Q: step kernel after the scalar-base addressing / identity padding lane / zero-lane pulls
 set -u
 R=$PWD
-OUT=$R/gpurun_out/r03_q
+OUT=$R/gpurun_out/r03_r
 mkdir -p "$OUT"
 timeout 900 python -m pytest tests -m gpu -q -x > "$OUT/pytest.log" 2>&1; echo "pytest rc=$?"
 tail -3 "$OUT/pytest.log"
