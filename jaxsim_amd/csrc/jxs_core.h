@@ -35,6 +35,11 @@ struct Core {
   using VI = typename L::VI;
   using VM = typename L::VM;
   static constexpr int G = L::G;
+#ifdef JXS_NO_ROW_BASE_SOLVE  // developer knob: A/B the base solve of the row-distributed sweeps (aba_rows)
+  static constexpr bool kNoRowBaseSolve = true;
+#else
+  static constexpr bool kNoRowBaseSolve = false;
+#endif
 
   const KParams<T>& P;
   const KArgs<T>& A;
@@ -1186,6 +1191,21 @@ struct Core {
     }
   }
 
+  // Pivots K..5 of the Gauss-Jordan elimination of a 6x6 system whose row r (x[0..5]) and right-hand side entry (x[6])
+  // sit in lane r of a 16-lane row: afterwards x[6] / x[r] is the solution entry of lane r (aba_rows, base solve).
+  // Columns <= K of the other rows are not updated: nothing reads them again.  The chain from pivot to pivot is
+  // broadcast -> reciprocal -> multiplier -> fused update (four dependent instructions): the multiplier takes the plain
+  // reciprocal (1 ulp: a backward error of one ulp in column K) and the own-row mask as a factor prepared beside the chain.
+  template <int K>
+  JXS_HD void gauss_jordan_rows(const VI& row, V* x) const {
+    if constexpr (K < 6) {
+      const V xm = vsel(row == K, V(T(0)), -x[K]);
+      const V nf = xm * vrcp(ln.row_bcast(x[K], K));
+      ln.template fmac_row_bcast<K, 6 - K>(x + (K + 1), nf);
+      gauss_jordan_rows<K + 1>(row, x);
+    }
+  }
+
   // a = -MA^-1 pA for the symmetric positive-definite 6x6 MA (LDL^T, no pivoting)
   JXS_HD void solve6(const V* MA, const V* pA, V* a) const {
     V Lm[6][6], Dd[6], Di[6];
@@ -1347,38 +1367,32 @@ struct Core {
           for (int j = 0; j < 6; ++j) MA0[j] = MArow[j];
           p0 = pr;
         } else {
-          // U = MA S in every lane of the slot: column sums over the rows (MA symmetric); the six
-          // reductions + the one of S^T pA advance stage by stage so that no DPP waits on its source
-          V red[7];
-          if (!L::scale6_packed(MArow, S_r, red)) {
+          // U_r = (MA S)_r in the lane of row r; d = S.U and S.pA are 8-lane reductions of per-lane products; the full U
+          // is never gathered: the rank-one update Ma = MA - U U^T / d takes U_j straight out of lane j of the slot
+          // (ln.rank1_rows).  [round 3; before: U in every lane by six reductions of the scaled rows, 21 + 3 + 8 instructions]
+          V U_r;
+          if (!L::dot6_packed(MArow, cur.S, &U_r)) {
+            U_r = MArow[0] * cur.S[0];
 #pragma unroll
-            for (int j = 0; j < 6; ++j) red[j] = MArow[j] * S_r;
+            for (int j = 1; j < 6; ++j) U_r = U_r + MArow[j] * cur.S[j];
           }
-          red[6] = S_r * pr;
-          ln.allreduce8x7(red);
-          const V* U = red;
-          V U_r, d;
-          if (!(L::dot6_packed(MArow, cur.S, &U_r) && L::dot6_packed(cur.S, U, &d))) {
-            U_r = MArow[0] * cur.S[0], d = cur.S[0] * U[0];
-#pragma unroll
-            for (int j = 1; j < 6; ++j) {
-              U_r = U_r + MArow[j] * cur.S[j];
-              d = d + cur.S[j] * U[j];
-            }
-          }
-          const V u = cur.tau - red[6];
+          V red[2] = {S_r * U_r, S_r * pr};
+          ln.allreduce8x2(red);
+          const V d = red[0];
+          const V u = cur.tau - red[1];
           const V inv = vsel(has, vrcp_acc(vsel(has, d, V(T(1)))), zero);
           const V Ud = U_r * inv;
           V Ma[6], pa = pr + Ud * u;
-          if (L::axpy6_packed(MArow, -Ud, U, Ma)) {
-            V t;
-            L::dot6_packed(Ma, cur.c, &t);
-            pa = pa + t;
-          } else {
 #pragma unroll
-            for (int j = 0; j < 6; ++j) {
-              Ma[j] = MArow[j] - Ud * U[j];
-              pa = pa + Ma[j] * cur.c[j];
+          for (int j = 0; j < 6; ++j) Ma[j] = MArow[j];
+          ln.rank1_rows(Ma, U_r, -Ud);
+          {
+            V t;
+            if (L::dot6_packed(Ma, cur.c, &t)) {
+              pa = pa + t;
+            } else {
+#pragma unroll
+              for (int j = 0; j < 6; ++j) pa = pa + Ma[j] * cur.c[j];
             }
           }
           Ur[Lv] = U_r, Sr[Lv] = S_r, cr[Lv] = c_r, invd[Lv] = inv, uu[Lv] = u;
@@ -1438,7 +1452,24 @@ struct Core {
 
     ln.stamp(A, 7);  // pass 2 (row-distributed)
     // ---- base acceleration (rbda/aba.py:240-243) --------------------------------------------
-    if (floating) {
+    if (floating && G >= 16 && !kNoRowBaseSolve) {
+      // [round 3] Gauss-Jordan across the six row lanes of slot 0, which hold the rows of MA_0 and of pA_0 already:
+      // per pivot one reciprocal, one multiplier and 6 - k fused "own -= f * (row k)" whose row-k operand is a DPP
+      // row broadcast -- 60 instructions where every lane used to factor the same 6x6 (LDL^T, ~170 instructions after
+      // twelve LDS reads).  No pivoting: MA_0 is symmetric positive definite.  Lanes without a base row (rows 6, 7,
+      // other slots of the 16-lane row) hold zeros and keep them; the other 16-lane rows compute values nobody reads.
+      V x[7];  // x[0..5]: this lane's row of MA_0, x[6]: its entry of -pA_0
+#pragma unroll
+      for (int j = 0; j < 6; ++j) x[j] = MA0[j];
+      x[6] = -p0;
+      gauss_jordan_rows<0>(row, x);
+      const V piv = vsel(row == 0, x[0], vsel(row == 1, x[1], vsel(row == 2, x[2], vsel(row == 3, x[3], vsel(row == 4, x[4], x[5])))));
+      ln.lds_write(lane + XB, x[6] * vrcp_acc(piv), lane < 6);
+      V rw[8];
+      ln.template lds_readv<8>(lane * 0 + XB, rw);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) a0[k] = rw[k];
+    } else if (floating) {
       // the six row lanes of slot 0 publish the base rows; every lane then solves the same 6x6
       {
         const V rw[8] = {MA0[0], MA0[1], MA0[2], MA0[3], MA0[4], MA0[5], p0, zero};

@@ -335,6 +335,35 @@ struct DeviceLanes {
       default: return dpp<0x15F>(x);
     }
   }
+  // x[i] += m * (x[i] of lane K of this lane's 16-lane row), i < N: the elimination step of a Gauss-Jordan sweep whose
+  // rows live in the lanes of a row.  fp32: N v_fmac_f32_dpp with the row broadcast folded into the source operand
+  // (the compiler keeps v_mov_dpp + v_fma apart); the leading s_nop covers the VALU-write -> DPP-read hazard.
+  template <int K, int N>
+  __device__ __forceinline__ void fmac_row_bcast(float* x, float m) const {
+    static_assert(N >= 1 && N <= 6 && K >= 0 && K < 16, "fmac_row_bcast: one to six values, lane 0..15 of the row");
+#define JXS_FB(i) "v_fmac_f32_dpp %" #i ", %" #i ", %[m] row_newbcast:%[k] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+    if constexpr (N == 1)
+      asm volatile("s_nop 1\n\t" JXS_FB(0) : "+v"(x[0]) : [m] "v"(m), [k] "n"(K));
+    else if constexpr (N == 2)
+      asm volatile("s_nop 1\n\t" JXS_FB(0) JXS_FB(1) : "+v"(x[0]), "+v"(x[1]) : [m] "v"(m), [k] "n"(K));
+    else if constexpr (N == 3)
+      asm volatile("s_nop 1\n\t" JXS_FB(0) JXS_FB(1) JXS_FB(2) : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]) : [m] "v"(m), [k] "n"(K));
+    else if constexpr (N == 4)
+      asm volatile("s_nop 1\n\t" JXS_FB(0) JXS_FB(1) JXS_FB(2) JXS_FB(3)
+                   : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]) : [m] "v"(m), [k] "n"(K));
+    else if constexpr (N == 5)
+      asm volatile("s_nop 1\n\t" JXS_FB(0) JXS_FB(1) JXS_FB(2) JXS_FB(3) JXS_FB(4)
+                   : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]) : [m] "v"(m), [k] "n"(K));
+    else
+      asm volatile("s_nop 1\n\t" JXS_FB(0) JXS_FB(1) JXS_FB(2) JXS_FB(3) JXS_FB(4) JXS_FB(5)
+                   : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]) : [m] "v"(m), [k] "n"(K));
+#undef JXS_FB
+  }
+  template <int K, int N>
+  __device__ __forceinline__ void fmac_row_bcast(double* x, double m) const {
+#pragma unroll
+    for (int i = 0; i < N; ++i) x[i] = x[i] + m * row_bcast(x[i], K);
+  }
   __device__ __forceinline__ V from_next(V x) const { return dpp<0x130>(x); }  // wave_shl:1, lane i <- i+1
   __device__ __forceinline__ V from_prev(V x) const { return dpp<0x138>(x); }  // wave_shr:1, lane i <- i-1
   template <int OFF>
@@ -387,6 +416,46 @@ struct DeviceLanes {
     asm volatile("s_nop 1\n\t" JXS_DPP7("quad_perm:[1,0,3,2]") JXS_DPP7("quad_perm:[2,3,0,1]") JXS_DPP7("row_half_mirror")
                  : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]));
 #undef JXS_DPP7
+  }
+  // two independent 8-lane reductions, stage by stage (d = S.U and S.pA of a tree level)
+  __device__ __forceinline__ void allreduce8x2(float* x) const {
+#define JXS_DPP2(CTRL)                                                              \
+  "v_add_f32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+  "v_add_f32_dpp %1, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+    // (two values: each stage reads what its predecessor wrote one instruction earlier -- one wait state more)
+    asm volatile("s_nop 1\n\t" JXS_DPP2("quad_perm:[1,0,3,2]") "s_nop 0\n\t" JXS_DPP2("quad_perm:[2,3,0,1]") "s_nop 0\n\t" JXS_DPP2("row_half_mirror")
+                 : "+v"(x[0]), "+v"(x[1]));
+#undef JXS_DPP2
+  }
+  __device__ __forceinline__ void allreduce8x2(double* x) const {
+    x[0] = allreduce8(x[0]), x[1] = allreduce8(x[1]);
+  }
+  // Rank-one update of a 6x6 matrix whose rows sit in the lanes 0..5 of an 8-lane slot:  m[j] += s * u_j, j < 6, with
+  // u_j = the value `u` of lane j of the slot -- the all-gather of u is never materialised.  fp32: the lanes of the
+  // slot's low quad reach u_0..u_3 by a quad broadcast of u and u_4, u_5 by a quad broadcast of the half-mirrored u
+  // (lane i <-> 7 - i), the high quad the other way round; every broadcast is the DPP operand of a v_fmac restricted
+  // to its quads by the bank mask: 13 instructions, where six 8-lane reductions of the scaled rows took 21 + 3.
+  __device__ __forceinline__ void rank1_rows(float* m, float u, float s) const {
+    float mir;
+#define JXS_R1(i, SRC, QP, BANK) "v_fmac_f32_dpp %" #i ", %[" SRC "], %[s] quad_perm:[" QP "] row_mask:0xf bank_mask:" BANK "\n\t"
+    asm volatile("s_nop 1\n\t"
+                 "v_mov_b32_dpp %[mir], %[u] row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 JXS_R1(0, "u", "0,0,0,0", "0x5") JXS_R1(1, "u", "1,1,1,1", "0x5") JXS_R1(2, "u", "2,2,2,2", "0x5")
+                 JXS_R1(3, "u", "3,3,3,3", "0x5") JXS_R1(4, "u", "0,0,0,0", "0xa") JXS_R1(5, "u", "1,1,1,1", "0xa")
+                 JXS_R1(0, "mir", "3,3,3,3", "0xa") JXS_R1(1, "mir", "2,2,2,2", "0xa") JXS_R1(2, "mir", "1,1,1,1", "0xa")
+                 JXS_R1(3, "mir", "0,0,0,0", "0xa") JXS_R1(4, "mir", "3,3,3,3", "0x5") JXS_R1(5, "mir", "2,2,2,2", "0x5")
+                 : "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3]), "+v"(m[4]), "+v"(m[5]), [mir] "=&v"(mir)
+                 : [u] "v"(u), [s] "v"(s));
+#undef JXS_R1
+  }
+  __device__ __forceinline__ void rank1_rows(double* m, double u, double s) const {
+    const int slot0 = (lane_ & ~7);
+    double g[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) g[j] = shfl(u, slot0 + j);
+    fence();
+#pragma unroll
+    for (int j = 0; j < 6; ++j) m[j] = m[j] + s * g[j];
   }
   // six reductions (the inertia wave of a two-wave workgroup: U = MA S without the bias entry)
   __device__ __forceinline__ void allreduce8x6(float* x) const {

@@ -238,6 +238,10 @@ struct HostLanes {
     for (int i = 0; i < G; ++i) r.v[i] = x.v[((i & ~15) + (k & 15)) & (G - 1)];
     return r;
   }
+  template <int K, int N>
+  void fmac_row_bcast(V* x, const V& m) const {  // x[i] += m * (x[i] of lane K of the 16-lane row)
+    for (int i = 0; i < N; ++i) x[i] = x[i] + m * row_bcast(x[i], K);
+  }
   V allreduce8(const V& x) const {
     V r;
     for (int i = 0; i < G; ++i) {
@@ -246,6 +250,16 @@ struct HostLanes {
       r.v[i] = acc;
     }
     return r;
+  }
+  void allreduce8x2(V* x) const {
+    for (int k = 0; k < 2; ++k) x[k] = allreduce8(x[k]);
+  }
+  void rank1_rows(V* m, const V& u, const V& s) const {  // m[j] += s * (u of lane j of the 8-lane slot)
+    for (int j = 0; j < 6; ++j) {
+      V g;
+      for (int i = 0; i < G; ++i) g.v[i] = u.v[((i & ~7) + j) & (G - 1)];
+      m[j] = m[j] + s * g;
+    }
   }
   void allreduce8x7(V* x) const {
     for (int k = 0; k < 7; ++k) x[k] = allreduce8(x[k]);
