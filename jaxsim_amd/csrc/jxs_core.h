@@ -35,6 +35,11 @@ struct Core {
   using VI = typename L::VI;
   using VM = typename L::VM;
   static constexpr int G = L::G;
+#ifdef JXS_NO_LANE_ROWS  // developer knob: A/B the table-independent loads of the joint / deformation rows (run(), stage A)
+  static constexpr bool kLaneRows = false;
+#else
+  static constexpr bool kLaneRows = true;
+#endif
 #ifdef JXS_NO_ROW_BASE_SOLVE  // developer knob: A/B the base solve of the row-distributed sweeps (aba_rows)
   static constexpr bool kNoRowBaseSolve = true;
 #else
@@ -143,17 +148,19 @@ struct Core {
     // pointers, row counts: SGPRs that arrive with the wave) is issued first and unconditionally, so that
     // these loads are in flight while the scalar loads of the rest of the argument block (KParams, the
     // other pointers) are still on their own round trip; branches on those values come afterwards.
-    const VI jtype = ln.lconsti(A.lti, LI_JTYPE);
-    const VI parent = ln.lconsti(A.lti, LI_PARENT);
-    const VI level = ln.lconsti(A.lti, LI_LEVEL);
-    const VI lnk = ln.lconsti(A.lti, LI_LINK);   // reference link index of this lane
-    const VI jrow = ln.lconsti(A.lti, LI_JROW);  // joint arrays are 0-based: ii = i - 1 (rbda/aba.py:133)
-    VI jump[kMaxRounds], child[kMaxChildren];
-#pragma unroll
-    for (int k = 0; k < kMaxRounds; ++k) jump[k] = ln.lconsti(A.lti, LI_JUMP + k);  // -1 beyond the last round
-#pragma unroll
-    for (int k = 0; k < kMaxChildren; ++k) child[k] = ln.lconsti(A.lti, LI_CHILD + k);
-    // state (row D): the joint rows need the lane's joint index, one dependent round trip behind the tables
+    // [round 3] ORDER OF ISSUE = ORDER OF FIRST USE.  Loads return in the order they were issued and the CU's memory
+    // pipeline takes 23 (128-bit) to 39 (32-bit) ticks per instruction (tools/ubench/cu_share.hip), so the thirty loads
+    // of this prologue arrive over ~700 ticks behind the first: what forward kinematics needs -- joint positions,
+    // base rows, index words, axis and lambda_H_pre -- goes first, the contact tables and inertias stream in behind it.
+    // The joint rows are loaded BY LANE INDEX (lane l >= 1: row l - 1; an address that needs no table) and move to the
+    // lane that owns the joint by one shuffle when the index word has arrived -- none when the joints are numbered in
+    // lane order (P.jrow_seq) -- instead of being issued only then (a second round trip: 400 cycles).
+    const VI jl = vsel(lane < 1, lane * 0, vsel(lane <= P.n, lane - 1, lane * 0 + (P.n - 1)));
+    V s = V(T(0)), sd = V(T(0));
+    if (kLaneRows) {
+      s = ln.gload(A.state_in, jl + P.row_s, P.n_rows);
+      sd = ln.gload(A.state_in, jl + P.row_sd, P.n_rows);
+    }
     V pB[3], q[4], vW[3], om[3];
     // The 13 environment-uniform rows (base position, quaternion, base velocity): one load instruction per row
     // costs the CU's vector-memory pipeline 32 ticks each (tools/ubench/cu_share.hip; the prologue is bound by
@@ -174,6 +181,16 @@ struct Core {
 #pragma unroll
     for (int k = 0; k < 4; ++k) q[k] = ln.gload_u(A.state_in, P.row_quat + k, P.n_rows);
     }
+    const VI jtype = ln.lconsti(A.lti, LI_JTYPE);
+    const VI parent = ln.lconsti(A.lti, LI_PARENT);
+    const VI level = ln.lconsti(A.lti, LI_LEVEL);
+    const VI lnk = ln.lconsti(A.lti, LI_LINK);   // reference link index of this lane
+    const VI jrow = ln.lconsti(A.lti, LI_JROW);  // joint arrays are 0-based: ii = i - 1 (rbda/aba.py:133)
+    VI jump[kMaxRounds], child[kMaxChildren];
+#pragma unroll
+    for (int k = 0; k < kMaxRounds; ++k) jump[k] = ln.lconsti(A.lti, LI_JUMP + k);  // -1 beyond the last round
+#pragma unroll
+    for (int k = 0; k < kMaxChildren; ++k) child[k] = ln.lconsti(A.lti, LI_CHILD + k);
     V ax[3], Rpre[9], ppre[3], cL[3], IL[6];
 #pragma unroll
     for (int k = 0; k < 3; ++k) ax[k] = ln.lconstf(A.ltf, LF_AXIS + k);
@@ -182,33 +199,46 @@ struct Core {
 #pragma unroll
     for (int k = 0; k < 3; ++k) ppre[k] = ln.lconstf(A.ltf, LF_PPRE + k);
     const V mass = ln.lconstf(A.ltf, LF_MASS);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) cL[k] = ln.lconstf(A.ltf, LF_COM + k);
-#pragma unroll
-    for (int k = 0; k < 6; ++k) IL[k] = ln.lconstf(A.ltf, LF_ICOM + k);
-    V smin, smax, klim, dlim, kc, kv;
-    if (kStep) {
-      smin = ln.lconstf(A.ltf, LF_SMIN), smax = ln.lconstf(A.ltf, LF_SMAX);
-      klim = ln.lconstf(A.ltf, LF_KLIM), dlim = ln.lconstf(A.ltf, LF_DLIM);
-      kc = ln.lconstf(A.ltf, LF_KC), kv = ln.lconstf(A.ltf, LF_KV);
-    }
     V Rsuc[9], psuc[3];  // identity for most models (P.any_suc says whether they are used): three wide loads
 #pragma unroll
     for (int k = 0; k < 9; ++k) Rsuc[k] = ln.lconstf(A.ltf, LF_RSUC + k);
 #pragma unroll
     for (int k = 0; k < 3; ++k) psuc[k] = ln.lconstf(A.ltf, LF_PSUC + k);
+    if (kLaneRows) ln.fence();  // ---- everything above is in flight before anything below is issued ----
     // collidable-point tables of chunk 0 (further chunks are loaded inside the contact loop); the tables
     // hold at least one (empty) slot per lane, so the load is legal whatever the contact model
     PointSlot ps0;
     if (kStep) load_slot_tables(lane, 0, ps0);
+    // deformation rows of the points: by lane index too (lane l: point row l) when all collidable points fit one chunk
+    const bool m_by_lane = kStep && !kRigid && kLaneRows && P.n_chunks == 1 && P.n_points <= G;
+    V m_raw[3] = {V(T(0)), V(T(0)), V(T(0))};
+    if (m_by_lane) {
+      const VI pl = vsel(lane < P.n_points, lane, lane * 0) * 3;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) m_raw[k] = ln.gload(A.state_in, pl + (P.row_m + k), P.n_rows);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) cL[k] = ln.lconstf(A.ltf, LF_COM + k);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) IL[k] = ln.lconstf(A.ltf, LF_ICOM + k);
+    V smin, smax, klim, dlim, kfc, kfv;
+    if (kStep) {
+      smin = ln.lconstf(A.ltf, LF_SMIN), smax = ln.lconstf(A.ltf, LF_SMAX);
+      klim = ln.lconstf(A.ltf, LF_KLIM), dlim = ln.lconstf(A.ltf, LF_DLIM);
+      kfc = ln.lconstf(A.ltf, LF_KC), kfv = ln.lconstf(A.ltf, LF_KV);
+    }
     // tables of the row-distributed ABA passes: always present in the model block, loaded whatever the layout
     // the model ends up using (the flag that decides lives in the parameter block, one scalar load away)
     RowTabs rt;
     if ((kStep || MODE == MODE_FD) && !kRigid) load_row_tabs(rt);
     const VI jrow_c = vsel(jrow >= 0, jrow, lane * 0);
-    V s = ln.gload(A.state_in, jrow_c + P.row_s, P.n_rows);
-    V sd = ln.gload(A.state_in, jrow_c + P.row_sd, P.n_rows);
+    const VI jsrc = jrow_c + 1;  // the lane that loaded this lane's joint row
+    if (!kLaneRows) {  // the joint rows need the lane's joint index, one dependent round trip behind the tables
+      s = ln.gload(A.state_in, jrow_c + P.row_s, P.n_rows);
+      sd = ln.gload(A.state_in, jrow_c + P.row_sd, P.n_rows);
+    }
     ln.fence();
+    if (kLaneRows && !P.jrow_seq) s = ln.shfl(s, jsrc), sd = ln.shfl(sd, jsrc);
     if (stage_base) {
       ln.lds_write(lane + kArea, base_stage, lane < 16);
       ln.lds_sync();
@@ -230,12 +260,18 @@ struct Core {
 #pragma unroll
       for (int k = 0; k < 3; ++k) vW[k] = V(T(0)), om[k] = V(T(0));
     }
-    V tau_in = (A.tau != nullptr) ? ln.gload(A.tau, jrow_c, P.n) : V(T(0));
-    V f6in[6];
-    if (A.link_f != nullptr) {
-      const VI lrow = vsel(lnk >= 0, lnk, lane * 0) * 6;
-#pragma unroll
-      for (int k = 0; k < 6; ++k) f6in[k] = ln.gload(A.link_f, lrow + k, P.nL * 6);
+    // The optional inputs.  [round 3] No load sits in a branch up here: a load issued on one side of a branch leaves
+    // its destination register "pending" at the join, and the wait-count bookkeeping of the compiler then makes the
+    // first instruction that reuses the register wait for EVERY load of the prologue -- forward kinematics started
+    // when the last table had arrived instead of the ninth load.  The joint torques are loaded unconditionally (from
+    // the joint-position rows when there are none: a row that exists; the value is dropped), last in the queue, and
+    // first used by the actuation model right before ABA; the link wrenches are loaded where they are used.
+    const bool has_tau = A.tau != nullptr;
+    V tau_in;
+    if (kLaneRows) {
+      tau_in = ln.gload(has_tau ? A.tau : A.state_in, jl + (has_tau ? 0 : P.row_s), has_tau ? P.n : P.n_rows);
+    } else {
+      tau_in = has_tau ? ln.gload(A.tau, jrow_c, P.n) : V(T(0));
     }
     const bool with_rows = P.row_mode && (kStep || MODE == MODE_FD) && !kRigid;
     const bool with_contacts = (kStep && !kRigid) && P.n_chunks > 0;  // soft contacts (state m)
@@ -246,36 +282,27 @@ struct Core {
     const VM is_root = level == 0;
     s = vsel(is_joint, s, V(T(0)));
     sd = vsel(is_joint, sd, V(T(0)));
-    tau_in = vsel(is_joint, tau_in, V(T(0)));
-    // Batch 2: the tangential deformation rows depend on the slot table just loaded.
-    if (with_contacts) load_slot_state(ps0);
+    // Batch 2: the tangential deformation rows.  Loaded by lane index: they move to the lanes of their slots where they
+    // are first used (the contact phase; RungeKutta4 keeps a copy of the initial state and needs them here).  Else
+    // their addresses depend on the slot table just loaded.
+    auto place_m = [&]() {
+      const VI psrc = vsel(ps0.body >= 0, ps0.prow, lane * 0);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) ps0.m[k] = P.prow_seq ? m_raw[k] : ln.shfl(m_raw[k], psrc);
+    };
+    if (with_contacts) {
+      if (!m_by_lane) load_slot_state(ps0);
+      else if (kRK4) place_m();
+    }
     ln.stamp(A, 1);  // tables + state arrived
 
     // Fused rollout: `n_steps` consecutive steps with the state carried in registers -- tables,
     // inputs and state are read once, the state is written once (jxs_rollout).  One step otherwise.
     const int n_steps = (MODE == MODE_ROLLOUT) ? A.n_steps : 1;  // compile-time 1 for a plain step
     for (int it = 0; it < n_steps; ++it) {
-    V tau = tau_in;
-    // ---- B: joint torques (api/actuation_model.py:7-126) --------------------------------
-    if (kStep) {
-      const V lower = vmin(s - smin, V(T(0)));  // clip(max=0)
-      const V upper = vmax(s - smax, V(T(0)));  // clip(min=0)
-      V tau_pl = -(klim * (lower + upper));
-      // `jnp.positive` is unary plus: tau_pl -= tau_pl * d * sd   (actuation_model.py:64-66)
-      tau_pl = tau_pl - tau_pl * (dlim * sd);
-      V tau_fr = V(T(0));
-      if (P.enable_friction) {
-        const V sgn = vsel(sd > V(T(0)), V(T(1)), vsel(sd < V(T(0)), V(T(-1)), V(T(0))));
-        tau_fr = -(kc * sgn + kv * sd);
-      }
-      const V tot = tau + tau_fr + tau_pl;
-      const V av = vabs(sd);
-      const V lim = vsel(av <= V(P.w_th), V(P.tau_max),
-                         vsel(av <= V(P.w_max), P.tau_max * (V(T(1)) - (av - P.w_th) * P.inv_w_range), V(T(0))));
-      tau = vmax(vmin(tot, lim), -lim);  // clip(tot, -lim, lim)
-    }
+    V tau = V(T(0));  // (set at stage 0, right before ABA: see "B: joint torques" below)
 
-    // Runge-Kutta 4 (api/integrators.py:91-167): the joint torques above are computed once from the
+    // Runge-Kutta 4 (api/integrators.py:91-167): the joint torques (B, below) are computed once from the
     // initial state (api/model.py:2658), the stage loop below evaluates system_dynamics
     // (api/ode.py:174-225) at x0, x0 + dt/2 k1, x0 + dt/2 k2, x0 + dt k3.  One stage for Euler.
     // RigidContacts: stage 0 is the step with QP contact forces, stage 1 re-evaluates the kinematics
@@ -427,8 +454,13 @@ struct Core {
     } else if (A.link_f != nullptr) {
       const VM is_link = level >= 0;
       V f6[6];
+      {
+        const VI lrow = vsel(lnk >= 0, lnk, lane * 0) * 6;
 #pragma unroll
-      for (int k = 0; k < 6; ++k) f6[k] = vsel(is_link, f6in[k], V(T(0)));
+        for (int k = 0; k < 6; ++k) f6[k] = ln.gload(A.link_f, lrow + k, P.nL * 6);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) f6[k] = vsel(is_link, f6[k], V(T(0)));
+      }
       V arm[3], t[3];
       if (A.force_repr == REPR_INERTIAL) {
         // [f; mu_W - p_B x f]
@@ -478,6 +510,7 @@ struct Core {
     }
 
     // ---- J,K,L,I: soft contacts ----------------------------------------------------------
+    if (with_contacts && m_by_lane && !kRK4 && it == 0 && stage == 0) place_m();
     if (with_contacts && with_rows && P.n_chunks == 1) {
       // The kinematics of the parent links reach the point lanes through the LDS scratch of the
       // row-distributed layout (18 writes + 18 reads, one round trip) instead of 18 ds_bpermute:
@@ -526,6 +559,35 @@ struct Core {
     } else
     if (with_contacts) contacts(lane, ps0, R, r, vl, va, ra, pB, doff, vBc, om, fl, fa);  // sets ps0.md
     ln.stamp(A, 5);  // contacts
+
+    // ---- B: joint torques (api/actuation_model.py:7-126): once per step, from the state the step starts from (stage 0
+    //      of RungeKutta4, api/model.py:2658).  Placed here, not at the top: the torque input is the LAST load of the
+    //      prologue, and nothing before ABA needs it.
+    if (stage == 0) {
+      V tq = tau_in;
+      if (kLaneRows) {
+        if (!P.jrow_seq) tq = ln.shfl(tq, jsrc);
+        tq = has_tau ? tq : V(T(0));
+      }
+      tau = vsel(is_joint, tq, V(T(0)));
+      if (kStep) {
+        const V lower = vmin(s - smin, V(T(0)));  // clip(max=0)
+        const V upper = vmax(s - smax, V(T(0)));  // clip(min=0)
+        V tau_pl = -(klim * (lower + upper));
+        // `jnp.positive` is unary plus: tau_pl -= tau_pl * d * sd   (actuation_model.py:64-66)
+        tau_pl = tau_pl - tau_pl * (dlim * sd);
+        V tau_fr = V(T(0));
+        if (P.enable_friction) {
+          const V sgn = vsel(sd > V(T(0)), V(T(1)), vsel(sd < V(T(0)), V(T(-1)), V(T(0))));
+          tau_fr = -(kfc * sgn + kfv * sd);
+        }
+        const V tot = tau + tau_fr + tau_pl;
+        const V av = vabs(sd);
+        const V lim = vsel(av <= V(P.w_th), V(P.tau_max),
+                           vsel(av <= V(P.w_max), P.tau_max * (V(T(1)) - (av - P.w_th) * P.inv_w_range), V(T(0))));
+        tau = vmax(vmin(tot, lim), -lim);  // clip(tot, -lim, lim)
+      }
+    }
 
     // ---- link inertia in C and bias force --------------------------------------------------
     // M = [[m I, m S(c)^T],[m S(c), I_c + m S(c) S(c)^T]]  (math/inertia.py:14-41) with the CoM

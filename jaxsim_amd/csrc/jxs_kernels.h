@@ -55,6 +55,9 @@ __global__ __launch_bounds__(64, VARIANT == KV_OCC2 ? 2 : 1) void jxs_kernel(con
   jxs::KParams<T> P = *reinterpret_cast<const jxs::KParams<T>*>(pre_mblk);
   jxs::KArgs<T> A{};
   A.state_in = pre_state_in, A.state_out = pre_state_out, A.tau = pre_tau, A.link_f = pre_link_f;
+#ifdef JXS_ASSUME_NO_INPUTS  // analysis aid (tools/spec_isa.py): the instruction stream without the optional inputs
+  A.tau = nullptr, A.link_f = nullptr;
+#endif
   A.N = pre_N, A.force_repr = pre_force_repr, A.n_steps = pre_n_steps;
   A.ltf = reinterpret_cast<const T*>(pre_mblk + jxs::mblk_off_ltf<T>());
   A.lti = reinterpret_cast<const int*>(pre_mblk + jxs::mblk_off_lti<T>(G));
@@ -100,6 +103,9 @@ __global__ __launch_bounds__(256, 1) void jxs_kernel_duo(const T* pre_state_in, 
   jxs::KParams<T> P = *reinterpret_cast<const jxs::KParams<T>*>(pre_mblk);
   jxs::KArgs<T> A{};
   A.state_in = pre_state_in, A.state_out = pre_state_out, A.tau = pre_tau, A.link_f = pre_link_f;
+#ifdef JXS_ASSUME_NO_INPUTS  // analysis aid (tools/spec_isa.py): the instruction stream without the optional inputs
+  A.tau = nullptr, A.link_f = nullptr;
+#endif
   A.N = pre_N, A.force_repr = pre_force_repr, A.n_steps = pre_n_steps;
   A.ltf = reinterpret_cast<const T*>(pre_mblk + jxs::mblk_off_ltf<T>());
   A.lti = reinterpret_cast<const int*>(pre_mblk + jxs::mblk_off_lti<T>(G));

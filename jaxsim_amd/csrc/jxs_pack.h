@@ -66,7 +66,7 @@ std::string kernel_spec_string(const Packed<T>& pk, int mode) {
   }
   add("flat", P.flat), add("enable_friction", P.enable_friction), add("pq_half", P.pq_half), add("anchored", P.anchored);
   add("rigid", P.rigid), add("n_cp", P.n_cp), add("rg_merge", P.rg_merge), add("rr_refine", P.rr_refine), add("rk4fast", P.rk4fast);
-  add("jump_pad", P.jump_pad);
+  add("jump_pad", P.jump_pad), add("jrow_seq", P.jrow_seq), add("prow_seq", P.prow_seq);
   s.pop_back();
   return s;
 }
@@ -416,6 +416,15 @@ std::string pack_model(const jxs_model_desc& d, Packed<T>& out) {
       s = e + 1;
     }
   }
+  // [round 3] State rows loaded by lane index (jxs_core.h run(), stage A): the joint rows always; the deformation rows
+  // when all collidable points fit one chunk of G lanes.
+  P.jrow_seq = 1, P.prow_seq = (n_chunks <= 1 && d.n_points <= G) ? 1 : 0;
+  for (int lane = 0; lane < G; ++lane) {
+    const int jr = out.lti[(size_t)lane * kLtiStride + LI_JROW];
+    if (jr >= 0 && jr != lane - 1) P.jrow_seq = 0;
+  }
+  for (int s2 = 0; s2 < n_en && s2 < G; ++s2)
+    if (out.pti[(size_t)s2 * kPtStride + PI_ROW] != s2) P.prow_seq = 0;
   // [round 3] Pointer jumping without selects: when the group has a padding lane, every source "beyond the base"
   // (and every source of the padding lanes themselves) points at the first padding lane.  Padding lanes carry the
   // identity transform and zero velocity / acceleration contributions (defaults above: no joint, identity pre- and

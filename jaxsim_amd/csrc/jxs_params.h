@@ -255,6 +255,10 @@ struct KParams {
   int rr_refine;                 // refinement steps against the operator applied through the tree
   int jump_pad;                  // 1: pointer-jumping sources beyond the base point at a padding lane that holds the identity
                                  // transform and zero vectors (no selects in the rounds); 0: they are -1 (no padding lane: nL == G)
+  // [round 3] The joint rows (and, with one point chunk of <= G collidable points, the deformation rows) of the state are
+  // LOADED by lane index -- lane l >= 1 joint row l - 1, lane l point row l -- and permuted to the owning lanes when the
+  // index tables have arrived (jxs_core.h, stage A).  1: that permutation is the identity, no shuffle.
+  int jrow_seq, prow_seq;
   int rk4fast;                   // RungeKutta4Fast: contact forces and position derivatives of the initial state (api/integrators.py:170-276)
   int anchored;                  // 1: the ABA of step / forward dynamics refers every first-child chain to its leaf link (fp32 conditioning)
 };
