@@ -1054,9 +1054,13 @@ struct Core {
         // new base state (it was integrated from values that are uniform over the environment), so lane k < 13 picks
         // value k and stores row k (rows 0..6 and 7+n..12+n) -- instead of thirteen exec-masked stores of the root lane
         const V b13[13] = {pB[0], pB[1], pB[2], q[0], q[1], q[2], q[3], vW[0], vW[1], vW[2], om[0], om[1], om[2]};
-        V val = b13[0];
-#pragma unroll
-        for (int k = 1; k < 13; ++k) val = vsel(lane == k, b13[k], val);
+        // (a tree over the bits of the lane index: four masks and a depth of four, where a chain of twelve
+        // compare-and-select pairs cost a wait state each -- a compare writes the mask its select reads)
+        const VM b0 = (lane & 1) != 0, b1 = (lane & 2) != 0, b2 = (lane & 4) != 0, b3 = (lane & 8) != 0;
+        const V t01 = vsel(b0, b13[1], b13[0]), t23 = vsel(b0, b13[3], b13[2]), t45 = vsel(b0, b13[5], b13[4]);
+        const V t67 = vsel(b0, b13[7], b13[6]), t89 = vsel(b0, b13[9], b13[8]), tab = vsel(b0, b13[11], b13[10]);
+        const V q0 = vsel(b1, t23, t01), q1 = vsel(b1, t67, t45), q2 = vsel(b1, tab, t89);
+        const V val = vsel(b3, vsel(b2, b13[12], q2), vsel(b2, q1, q0));
         const VI brow = vsel(lane < 7, lane, vsel(lane < 13, lane + P.n, lane * 0));
         ln.gstore(A.state_out, brow, val, lane < 13, P.n_rows);
       } else {
@@ -1472,14 +1476,11 @@ struct Core {
               }
               const V c1 = vsel(is_ang, pick3(d3, j1), zero);    //  d_{j+1}: multiplies LIN_{j+2}
               const V c2 = vsel(is_ang, -pick3(d3, j2), zero);   // -d_{j+2}: multiplies LIN_{j+1}
-              V g1[7], g2[7];
+              V x7[7] = {Ma[0], Ma[1], Ma[2], Ma[3], Ma[4], Ma[5], pa};
+              ln.ang_from_lin7(x7, c1, c2, xsrc1, xsrc2);  // x += c1 * x@(linear row j + 2) + c2 * x@(linear row j + 1)
 #pragma unroll
-              for (int j = 0; j < 6; ++j) g1[j] = ln.shfl(Ma[j], xsrc1), g2[j] = ln.shfl(Ma[j], xsrc2);
-              g1[6] = ln.shfl(pa, xsrc1), g2[6] = ln.shfl(pa, xsrc2);
-              ln.fence();
-#pragma unroll
-              for (int j = 0; j < 6; ++j) Ma[j] = Ma[j] + c1 * g2[j] + c2 * g1[j];
-              pa = pa + c1 * g2[6] + c2 * g1[6];
+              for (int j = 0; j < 6; ++j) Ma[j] = x7[j];
+              pa = x7[6];
             }
             // what a first child hands to its parent in the same lanes: x 1, else x 0 (values are finite: packed multiplies
             // instead of seven selects)
@@ -1514,6 +1515,8 @@ struct Core {
 
     ln.stamp(A, 7);  // pass 2 (row-distributed)
     // ---- base acceleration (rbda/aba.py:240-243) --------------------------------------------
+    V a0_own = zero;           // entry `row` of the base acceleration in the six row lanes of slot 0, zero elsewhere
+    bool a0_in_lanes = false;
     if (floating && G >= 16 && !kNoRowBaseSolve) {
       // [round 3] Gauss-Jordan across the six row lanes of slot 0, which hold the rows of MA_0 and of pA_0 already:
       // per pivot one reciprocal, one multiplier and 6 - k fused "own -= f * (row k)" whose row-k operand is a DPP
@@ -1525,8 +1528,11 @@ struct Core {
       for (int j = 0; j < 6; ++j) x[j] = MA0[j];
       x[6] = -p0;
       gauss_jordan_rows<0>(row, x);
-      const V piv = vsel(row == 0, x[0], vsel(row == 1, x[1], vsel(row == 2, x[2], vsel(row == 3, x[3], vsel(row == 4, x[4], x[5])))));
-      ln.lds_write(lane + XB, x[6] * vrcp_acc(piv), lane < 6);
+      // (own pivot: the entries that settle last are selected last)
+      const V piv = vsel(row == 5, x[5], vsel(row == 4, x[4], vsel(row == 3, x[3], vsel(row == 2, x[2], vsel(row == 1, x[1], x[0])))));
+      a0_own = vsel(lane < 6, x[6] * vrcp_acc(piv), zero);  // pass 3 starts from here, without the LDS round trip below
+      a0_in_lanes = true;
+      ln.lds_write(lane + XB, a0_own, lane < 6);
       V rw[8];
       ln.template lds_readv<8>(lane * 0 + XB, rw);
 #pragma unroll
@@ -1556,12 +1562,13 @@ struct Core {
 
     ln.stamp(A, 8);  // base solve
     // ---- pass 3, base to leaves (rbda/aba.py:251-267) -----------------------------------------
-    V acar = vsel(row == 0, a0[0], vsel(row == 1, a0[1], vsel(row == 2, a0[2],
-             vsel(row == 3, a0[3], vsel(row == 4, a0[4], vsel(row == 5, a0[5], zero))))));
+    // (only slot 0 starts from the base: every other slot begins with a link that pulls its parent's acceleration)
+    V acar = a0_in_lanes ? a0_own
+                         : vsel(row == 0, a0[0], vsel(row == 1, a0[1], vsel(row == 2, a0[2],
+                           vsel(row == 3, a0[3], vsel(row == 4, a0[4], vsel(row == 5, a0[5], zero))))));
 #pragma unroll
     for (int Lv = 1; Lv < kRowLevels; ++Lv) {
       if (Lv <= max_depth) {
-        const VM has = rt.rec[Lv] != lds_zero_rec(G);
         V apar = acar;
         if ((ppull_levels >> Lv) & 1u) {
           const VM pulled = rt.ppull[Lv] >= 0;
@@ -1573,18 +1580,20 @@ struct Core {
             const V al1 = ln.shfl(acar, pslot + 3 + j1), al2 = ln.shfl(acar, pslot + 3 + j2);
             ln.fence();
             const V* d3 = dkeep[Lv];  // cross levels and parent-pull levels are the same levels
-            const V sh = al1 * pick3(d3, j2) - al2 * pick3(d3, j1);
-            apar = vsel(pulled, q + vsel(is_lin, sh, zero), acar);
+            // (the lane masks go into the coefficients, beside the chain: shuffle -> multiply -> fused multiply-add -> add)
+            const VM shm = pulled && is_lin;
+            const V k2 = vsel(shm, pick3(d3, j2), zero), k1 = vsel(shm, pick3(d3, j1), zero);
+            apar = vsel(pulled, q, acar) + (al1 * k2 - al2 * k1);
           } else {
             ln.fence();
             apar = vsel(pulled, q, acar);
           }
         }
-        V ai = apar + cr[Lv];
+        const V ai = apar + cr[Lv];
         const V tot = ln.allreduce8(Ur[Lv] * ai);
         const V sd = (uu[Lv] - tot) * invd[Lv];
-        ai = ai + Sr[Lv] * sd;
-        acar = vsel(has, ai, acar);
+        // (no select: lanes without a link at this level carry c_r = S_r = 0 and 1 / d = 0, and their apar is acar)
+        acar = ai + Sr[Lv] * sd;
         // every row lane of the slot holds the same sd: all of them store it to the link's record (same address, same
         // value; lanes without a link store into the unread word of the all-zero record) -- no exec-mask bookkeeping
         ln.lds_write(rt.rec[Lv] + RL_SDD, sd);

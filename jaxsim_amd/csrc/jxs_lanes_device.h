@@ -337,25 +337,29 @@ struct DeviceLanes {
   }
   // x[i] += m * (x[i] of lane K of this lane's 16-lane row), i < N: the elimination step of a Gauss-Jordan sweep whose
   // rows live in the lanes of a row.  fp32: N v_fmac_f32_dpp with the row broadcast folded into the source operand
-  // (the compiler keeps v_mov_dpp + v_fma apart); the leading s_nop covers the VALU-write -> DPP-read hazard.
+  // (the compiler keeps v_mov_dpp + v_fma apart).  PRECONDITION (the assembler cannot see it): x[] was not written by
+  // the two instructions in front of the call (VALU write -> DPP read needs two wait states; an s_nop 1 costs a lone
+  // wave 9 ticks, tools/ubench/issue_rate.hip) -- in the Gauss-Jordan sweep the broadcast of the pivot, its reciprocal
+  // and the multiplier stand between two steps.
   template <int K, int N>
   __device__ __forceinline__ void fmac_row_bcast(float* x, float m) const {
+    if (K == 0) asm volatile("s_nop 1");  // (first step: the rows may just have been copied into place)
     static_assert(N >= 1 && N <= 6 && K >= 0 && K < 16, "fmac_row_bcast: one to six values, lane 0..15 of the row");
 #define JXS_FB(i) "v_fmac_f32_dpp %" #i ", %" #i ", %[m] row_newbcast:%[k] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
     if constexpr (N == 1)
-      asm volatile("s_nop 1\n\t" JXS_FB(0) : "+v"(x[0]) : [m] "v"(m), [k] "n"(K));
+      asm volatile(JXS_FB(0) : "+v"(x[0]) : [m] "v"(m), [k] "n"(K));
     else if constexpr (N == 2)
-      asm volatile("s_nop 1\n\t" JXS_FB(0) JXS_FB(1) : "+v"(x[0]), "+v"(x[1]) : [m] "v"(m), [k] "n"(K));
+      asm volatile(JXS_FB(0) JXS_FB(1) : "+v"(x[0]), "+v"(x[1]) : [m] "v"(m), [k] "n"(K));
     else if constexpr (N == 3)
-      asm volatile("s_nop 1\n\t" JXS_FB(0) JXS_FB(1) JXS_FB(2) : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]) : [m] "v"(m), [k] "n"(K));
+      asm volatile(JXS_FB(0) JXS_FB(1) JXS_FB(2) : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]) : [m] "v"(m), [k] "n"(K));
     else if constexpr (N == 4)
-      asm volatile("s_nop 1\n\t" JXS_FB(0) JXS_FB(1) JXS_FB(2) JXS_FB(3)
+      asm volatile(JXS_FB(0) JXS_FB(1) JXS_FB(2) JXS_FB(3)
                    : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]) : [m] "v"(m), [k] "n"(K));
     else if constexpr (N == 5)
-      asm volatile("s_nop 1\n\t" JXS_FB(0) JXS_FB(1) JXS_FB(2) JXS_FB(3) JXS_FB(4)
+      asm volatile(JXS_FB(0) JXS_FB(1) JXS_FB(2) JXS_FB(3) JXS_FB(4)
                    : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]) : [m] "v"(m), [k] "n"(K));
     else
-      asm volatile("s_nop 1\n\t" JXS_FB(0) JXS_FB(1) JXS_FB(2) JXS_FB(3) JXS_FB(4) JXS_FB(5)
+      asm volatile(JXS_FB(0) JXS_FB(1) JXS_FB(2) JXS_FB(3) JXS_FB(4) JXS_FB(5)
                    : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]) : [m] "v"(m), [k] "n"(K));
 #undef JXS_FB
   }
@@ -392,10 +396,22 @@ struct DeviceLanes {
   }
 
   // sum over the 8 lanes of a slot (row-distributed ABA), result in all 8: three DPP adds
-  __device__ __forceinline__ V allreduce8(V x) const {
+  __device__ __forceinline__ double allreduce8(double x) const {
     x = x + dpp<0xB1>(x);   // quad_perm:[1,0,3,2]
     x = x + dpp<0x4E>(x);   // quad_perm:[2,3,0,1]
     x = x + dpp<0x141>(x);  // row_half_mirror
+    return x;
+  }
+  // fp32: three v_add_f32_dpp written out -- the compiler turns the first stage into v_mov_dpp + v_fmac (recomputing the
+  // product that feeds it), one dependent instruction more on the base-to-leaves chain of pass 3
+  __device__ __forceinline__ float allreduce8(float x) const {
+    asm volatile("s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                 "s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                 "s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1"
+                 : "+v"(x));
     return x;
   }
   // seven independent 8-lane reductions advanced stage by stage: consecutive DPP instructions never read a
@@ -430,6 +446,54 @@ struct DeviceLanes {
   __device__ __forceinline__ void allreduce8x2(double* x) const {
     x[0] = allreduce8(x[0]), x[1] = allreduce8(x[1]);
   }
+  // three independent 8-lane reductions (d = S.U, S.pA and U.c of a tree level): a value is read three instructions
+  // after it was written, no wait states between the stages
+  __device__ __forceinline__ void allreduce8x3(float* x) const {
+#define JXS_DPP3(CTRL)                                                              \
+  "v_add_f32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+  "v_add_f32_dpp %1, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+  "v_add_f32_dpp %2, %2, %2 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+    asm volatile("s_nop 1\n\t" JXS_DPP3("quad_perm:[1,0,3,2]") JXS_DPP3("quad_perm:[2,3,0,1]") JXS_DPP3("row_half_mirror")
+                 : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]));
+#undef JXS_DPP3
+  }
+  __device__ __forceinline__ void allreduce8x3(double* x) const {
+    x[0] = allreduce8(x[0]), x[1] = allreduce8(x[1]), x[2] = allreduce8(x[2]);
+  }
+  // Seven values per lane, lane = 8 * slot + row:  x[j] += c1 * x[j]@(linear row (jj + 2) % 3) + c2 * x[j]@(linear row
+  // (jj + 1) % 3) of the same slot, on the angular row lanes 3 + jj (c1 = c2 = 0 on every other lane; the linear rows
+  // are sources only and keep their values) -- the re-reference of a link's rows to another anchor (aba_rows).  fp32:
+  // row 3 finds its two sources in its own quad (quad_perm), rows 4 and 5 in a copy shifted by four lanes (row_shr:4);
+  // every source is the DPP operand of a bank-masked v_fmac: 35 vector instructions where fourteen ds_bpermute (19 ticks
+  // of issue each for a lone wave) and fourteen multiply-adds stood.  The stages run value by value, so that no DPP
+  // reads a register written by the two instructions in front of it.  (`s1`, `s2`: the source lanes, for the generic form)
+  __device__ __forceinline__ void ang_from_lin7(float* x, float c1, float c2, int, int) const {
+    float X0, X1, X2, X3, X4, X5, X6;
+#define JXS_A7(OP) OP(0, 7) OP(1, 8) OP(2, 9) OP(3, 10) OP(4, 11) OP(5, 12) OP(6, 13)
+#define JXS_A7_SHR(i, X) "v_mov_b32_dpp %" #X ", %" #i " row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+#define JXS_A7_A1(i, X) "v_fmac_f32_dpp %" #i ", %" #i ", %[c1] quad_perm:[0,1,2,2] row_mask:0xf bank_mask:0x5\n\t"
+#define JXS_A7_A2(i, X) "v_fmac_f32_dpp %" #i ", %" #i ", %[c2] quad_perm:[0,1,2,1] row_mask:0xf bank_mask:0x5\n\t"
+#define JXS_A7_B1(i, X) "v_fmac_f32_dpp %" #i ", %" #X ", %[c1] quad_perm:[0,1,2,3] row_mask:0xf bank_mask:0xa\n\t"
+#define JXS_A7_B2(i, X) "v_fmac_f32_dpp %" #i ", %" #X ", %[c2] quad_perm:[2,0,2,3] row_mask:0xf bank_mask:0xa\n\t"
+    asm volatile("s_nop 1\n\t" JXS_A7(JXS_A7_SHR) JXS_A7(JXS_A7_A1) JXS_A7(JXS_A7_A2) JXS_A7(JXS_A7_B1) JXS_A7(JXS_A7_B2)
+                 : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "=&v"(X0), "=&v"(X1), "=&v"(X2),
+                   "=&v"(X3), "=&v"(X4), "=&v"(X5), "=&v"(X6)
+                 : [c1] "v"(c1), [c2] "v"(c2));
+#undef JXS_A7
+#undef JXS_A7_SHR
+#undef JXS_A7_A1
+#undef JXS_A7_A2
+#undef JXS_A7_B1
+#undef JXS_A7_B2
+  }
+  __device__ __forceinline__ void ang_from_lin7(double* x, double c1, double c2, int s1, int s2) const {
+    double g1[7], g2[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) g1[j] = shfl(x[j], s1), g2[j] = shfl(x[j], s2);
+    fence();
+#pragma unroll
+    for (int j = 0; j < 7; ++j) x[j] = x[j] + c1 * g2[j] + c2 * g1[j];
+  }
   // Rank-one update of a 6x6 matrix whose rows sit in the lanes 0..5 of an 8-lane slot:  m[j] += s * u_j, j < 6, with
   // u_j = the value `u` of lane j of the slot -- the all-gather of u is never materialised.  fp32: the lanes of the
   // slot's low quad reach u_0..u_3 by a quad broadcast of u and u_4, u_5 by a quad broadcast of the half-mirrored u
@@ -438,8 +502,8 @@ struct DeviceLanes {
   __device__ __forceinline__ void rank1_rows(float* m, float u, float s) const {
     float mir;
 #define JXS_R1(i, SRC, QP, BANK) "v_fmac_f32_dpp %" #i ", %[" SRC "], %[s] quad_perm:[" QP "] row_mask:0xf bank_mask:" BANK "\n\t"
-    asm volatile("s_nop 1\n\t"
-                 "v_mov_b32_dpp %[mir], %[u] row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+    // (no leading s_nop: `u` is older than the reductions and the reciprocal that produce `s`)
+    asm volatile("v_mov_b32_dpp %[mir], %[u] row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
                  JXS_R1(0, "u", "0,0,0,0", "0x5") JXS_R1(1, "u", "1,1,1,1", "0x5") JXS_R1(2, "u", "2,2,2,2", "0x5")
                  JXS_R1(3, "u", "3,3,3,3", "0x5") JXS_R1(4, "u", "0,0,0,0", "0xa") JXS_R1(5, "u", "1,1,1,1", "0xa")
                  JXS_R1(0, "mir", "3,3,3,3", "0xa") JXS_R1(1, "mir", "2,2,2,2", "0xa") JXS_R1(2, "mir", "1,1,1,1", "0xa")

@@ -85,7 +85,7 @@ def _flags() -> list[str]:
 
 
 def path_of(text: str) -> pathlib.Path:
-    key = hashlib.sha256((text + "|" + source_sha() + "|" + " ".join(_flags())).encode()).hexdigest()[:20]
+    key = hashlib.sha256((text + "|" + source_sha() + "|" + " ".join(_flags()) + os.environ.get("JAXSIM_AMD_SPEC_CSRC", "")).encode()).hexdigest()[:20]
     return CACHE / f"libjxs_spec_{key}.so"
 
 
@@ -106,7 +106,10 @@ def compile(model, dtype, mode: int = MODE_STEP, *, force: bool = False) -> path
     tmp = out.with_suffix(f".tmp{os.getpid()}.so")
     cmd = [_HIPCC, *_flags(), f"-DJXS_SPEC_T={fields['T']}", f"-DJXS_SPEC_G={fields['G']}", f"-DJXS_SPEC_MODE={fields['MODE']}",
            f"-DJXS_SPEC_ASSIGN={assign}", f'-DJXS_SPEC_STRING="{text}"', "jxs_spec.hip", "-o", str(tmp)]  # fmt: skip
-    r = subprocess.run(cmd, cwd=_CSRC, capture_output=True, text=True)
+    # developer aid (tools/gpu/*.sh): compile the kernel sources of another directory -- a copy of an earlier csrc/ with the
+    # same parameter block -- against this library, for A/B timings on one box
+    src = os.environ.get("JAXSIM_AMD_SPEC_CSRC") or _CSRC
+    r = subprocess.run(cmd, cwd=src, capture_output=True, text=True)
     if r.returncode != 0:
         tmp.unlink(missing_ok=True)
         raise RuntimeError(f"hipcc failed for the specialised kernel ({text}):\n{r.stderr[-4000:]}")

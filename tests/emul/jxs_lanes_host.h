@@ -251,8 +251,17 @@ struct HostLanes {
     }
     return r;
   }
+  void allreduce8x3(V* x) const {
+    for (int k = 0; k < 3; ++k) x[k] = allreduce8(x[k]);
+  }
   void allreduce8x2(V* x) const {
     for (int k = 0; k < 2; ++k) x[k] = allreduce8(x[k]);
+  }
+  // x[j] += c1 * x[j]@s2 + c2 * x[j]@s1, j < 7 (s1, s2: source lanes; see the device backend)
+  void ang_from_lin7(V* x, const V& c1, const V& c2, const VI& s1, const VI& s2) const {
+    V g1[7], g2[7];
+    for (int j = 0; j < 7; ++j) g1[j] = shfl(x[j], s1), g2[j] = shfl(x[j], s2);
+    for (int j = 0; j < 7; ++j) x[j] = x[j] + c1 * g2[j] + c2 * g1[j];
   }
   void rank1_rows(V* m, const V& u, const V& s) const {  // m[j] += s * (u of lane j of the 8-lane slot)
     for (int j = 0; j < 6; ++j) {
