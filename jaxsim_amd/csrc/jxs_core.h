@@ -1496,6 +1496,16 @@ struct Core {
               for (int k = 0; k < kRowExtra; ++k) {
                 if (k >= npull) break;
                 const VI src = rt.pull[Lv][k];  // (nothing to pull: an idle row lane, whose values are zero)
+                if (L::kHasRowShift && ((P.row_pull_dpp >> (Lv * kRowExtra + k)) & 1u)) {
+                  // the child sits in the next slot of the same 16-lane row: a DPP row shift (jxs_lanes_device.h)
+                  V acc7[7] = {accM[0], accM[1], accM[2], accM[3], accM[4], accM[5], accp};
+                  const V x7[7] = {Ma[0], Ma[1], Ma[2], Ma[3], Ma[4], Ma[5], pa};
+                  ln.fmac7_from_next_slot(acc7, x7, vsel(src != 6, V(T(1)), zero));
+#pragma unroll
+                  for (int j = 0; j < 6; ++j) accM[j] = acc7[j];
+                  accp = acc7[6];
+                  continue;
+                }
                 V g[7];
 #pragma unroll
                 for (int j = 0; j < 6; ++j) g[j] = ln.shfl(Ma[j], src);

@@ -232,7 +232,10 @@ struct DeviceLanes {
   __device__ __forceinline__ VM all_true() const { return true; }
   // Scheduling fence: everything issued before it (a batch of shuffles) stays before, every
   // consumer after -- the batch is pipelined through the LDS crossbar and waited for once.
-  __device__ __forceinline__ void fence() const { __builtin_amdgcn_sched_barrier(0); }
+#ifndef JXS_FENCE_MASK  // developer knob: which instruction classes the scheduler may move across fence() (0: none)
+#define JXS_FENCE_MASK 0
+#endif
+  __device__ __forceinline__ void fence() const { __builtin_amdgcn_sched_barrier(JXS_FENCE_MASK); }
   // Phase stamps for the developer profiling build; compiled out otherwise.
   template <class KA>
   __device__ __forceinline__ void stamp(const KA& A, int i) const {
@@ -494,6 +497,18 @@ struct DeviceLanes {
 #pragma unroll
     for (int j = 0; j < 7; ++j) x[j] = x[j] + c1 * g2[j] + c2 * g1[j];
   }
+  // acc[j] += m * x[j]@(lane + 8), j < 7, within the lane's 16-lane row (lanes 8..15 of a row add nothing): a parent slot
+  // pulls the rows of a child that sits in the slot next to it (aba_rows) -- seven v_fmac with a row_shl:8 DPP operand
+  // instead of seven ds_bpermute, a wait and seven additions
+  static constexpr bool kHasRowShift = sizeof(T) == 4;
+  __device__ __forceinline__ void fmac7_from_next_slot(float* acc, const float* x, float m) const {
+#define JXS_P8(i, j) "v_fmac_f32_dpp %" #i ", %" #j ", %[m] row_shl:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+    asm volatile("s_nop 1\n\t" JXS_P8(0, 7) JXS_P8(1, 8) JXS_P8(2, 9) JXS_P8(3, 10) JXS_P8(4, 11) JXS_P8(5, 12) JXS_P8(6, 13)
+                 : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6])
+                 : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), [m] "v"(m));
+#undef JXS_P8
+  }
+  __device__ __forceinline__ void fmac7_from_next_slot(double*, const double*, double) const {}  // (never called: kHasRowShift)
   // Rank-one update of a 6x6 matrix whose rows sit in the lanes 0..5 of an 8-lane slot:  m[j] += s * u_j, j < 6, with
   // u_j = the value `u` of lane j of the slot -- the all-gather of u is never materialised.  fp32: the lanes of the
   // slot's low quad reach u_0..u_3 by a quad broadcast of u and u_4, u_5 by a quad broadcast of the half-mirrored u

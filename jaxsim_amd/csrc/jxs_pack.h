@@ -58,7 +58,7 @@ std::string kernel_spec_string(const Packed<T>& pk, int mode) {
   add("seg_steps", P.seg_steps), add("n_rounds", P.n_rounds), add("max_depth", P.max_depth), add("floating", P.floating);
   add("any_suc", P.any_suc), add("seg_dpp_ok", P.seg_dpp_ok), add("row_mode", P.row_mode);
   add("row_cross_levels", P.row_cross_levels, true), add("row_ppull_levels", P.row_ppull_levels, true);
-  add("row_pull_counts", P.row_pull_counts, true), add("nonadj_levels", P.nonadj_levels, true);
+  add("row_pull_counts", P.row_pull_counts, true), add("row_pull_dpp", P.row_pull_dpp, true), add("nonadj_levels", P.nonadj_levels, true);
   for (int k = 0; k < (int)(sizeof(P.maxch_nib) / sizeof(P.maxch_nib[0])); ++k) {
     char nm[32];
     std::snprintf(nm, sizeof nm, "maxch_nib[%d]", k);
@@ -442,6 +442,7 @@ std::string pack_model(const jxs_model_desc& d, Packed<T>& out) {
   P.row_cross_levels = 0;
   P.row_ppull_levels = 0;
   P.row_pull_counts = 0;
+  P.row_pull_dpp = 0;
   out.rti.assign((size_t)kRtiStride * G, -1);
   {
     const int n_slots_row = G / 8;
@@ -506,6 +507,18 @@ std::string pack_model(const jxs_model_desc& d, Packed<T>& out) {
           if (RI(RT_REC + L, lane) < 0) RI(RT_REC + L, lane) = lds_zero_rec(G);
       // [round 3] "no extra child to pull" = pull from lane 6: an idle row lane (rows 6 and 7 of a slot read the zero
       // record at every level), whose row of Ma and whose pa are zero -- the pulled values are added without a select
+      // [round 3] which pulls a DPP row shift can do: every real source eight lanes up in the puller's own 16-lane row
+      if (std::getenv("JXS_DISABLE_PULL_DPP") == nullptr)  // developer knob: A/B
+        for (int f = 0; f < kRowLevels * kRowExtra; ++f) {
+          bool any = false, all = true;
+          for (int lane = 0; lane < G; ++lane) {
+            const int src = RI(RT_PULL + f, lane);
+            if (src < 0) continue;
+            any = true;
+            if (src != lane + 8 || (lane & 15) >= 8) all = false;
+          }
+          if (any && all) P.row_pull_dpp |= 1u << f;
+        }
       for (int lane = 0; lane < G; ++lane)
         for (int f = RT_PULL; f < RT_PULL + kRowLevels * kRowExtra; ++f)
           if (RI(f, lane) < 0) RI(f, lane) = 6;

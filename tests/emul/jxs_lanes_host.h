@@ -150,6 +150,8 @@ struct HostLanes {
   // (the MFMA tiles of the contact solvers' Cholesky exist on the device only: the emulation runs the vector path,
   // which performs the same fused multiply-adds in the same order)
   static constexpr bool kHasMfma = false;
+  static constexpr bool kHasRowShift = false;  // (the emulation pulls through shfl: same values)
+  void fmac7_from_next_slot(V*, const V*, const V&) const {}
   template <int NTMAX>
   struct ChTiles {
     ChTiles(const HostLanes&, int, int) {}
