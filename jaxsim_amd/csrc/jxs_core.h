@@ -392,7 +392,7 @@ struct Core {
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         Sa[k] = vsel(is_rev, Ra_[k], V(T(0)));
-        Sl[k] = vsel(is_rev, rxa[k], vsel(is_pri, Ra_[k], V(T(0))));
+        Sl[k] = vsel(is_rev, rxa[k], P.any_pri ? vsel(is_pri, Ra_[k], V(T(0))) : V(T(0)));
       }
     }
 
@@ -1086,9 +1086,10 @@ struct Core {
   // base rotation: q <- q / |q| and its DCM (data.base_orientation, api/data.py:267-286)
   JXS_HD void base_dcm(V* q, V* R0) const {
     {
+      // q / (|q| + eps where |q| = 0)  (data.base_orientation): 1 / |q| as ONE refined reciprocal square root -- this is the
+      // head of the step's critical path (square root, guard, reciprocal: twelve dependent instructions before)
       const V nsq = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
-      const V nrm = vsqrt(nsq);
-      const V inv = vrcp(nrm + vsel(nrm == V(T(0)), V(P.eps), V(T(0))));
+      const V inv = vsel(nsq > V(T(0)), vrsqrt(vsel(nsq > V(T(0)), nsq, V(T(1)))), V(T(1) / P.eps));
 #pragma unroll
       for (int k = 0; k < 4; ++k) q[k] = q[k] * inv;
     }
@@ -1126,7 +1127,7 @@ struct Core {
     Rj[8] = cs + c1 * ax[2] * ax[2];
     V pj[3];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) pj[k] = vsel(is_pri, s * ax[k], V(T(0)));
+    for (int k = 0; k < 3; ++k) pj[k] = P.any_pri ? vsel(is_pri, s * ax[k], V(T(0))) : V(T(0));
     V Rl[9], pl[3];
     if (P.any_suc) {
       V tmp[9], t3[3];
@@ -1138,7 +1139,12 @@ struct Core {
       mat3vec(Rpre, t3, pl);
     } else {
       mat3mul(Rpre, Rj, Rl);
-      mat3vec(Rpre, pj, pl);
+      if (P.any_pri) {
+        mat3vec(Rpre, pj, pl);
+      } else {  // (no prismatic joint in the model: the translation is lambda_H_pre's)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) pl[k] = V(T(0));
+      }
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) pl[k] = pl[k] + ppre[k];
@@ -1446,12 +1452,14 @@ struct Core {
           ln.allreduce8x2(red);
           const V d = red[0];
           const V u = cur.tau - red[1];
-          const V inv = vsel(has, vrcp_acc(vsel(has, d, V(T(1)))), zero);
-          const V Ud = U_r * inv;
-          V Ma[6], pa = pr + Ud * u;
+          // -1 / d, zero in the lanes without a link (their d = 0: whatever the reciprocal returns there is dropped by the
+          // select, not multiplied away).  The sign lives in the select: no negation on the chain to the rank-one update.
+          const V ninv = vsel(has, -vrcp_acc(d), zero);
+          const V nUd = U_r * ninv;
+          V Ma[6], pa = pr - nUd * u;
 #pragma unroll
           for (int j = 0; j < 6; ++j) Ma[j] = MArow[j];
-          ln.rank1_rows(Ma, U_r, -Ud);
+          ln.rank1_rows(Ma, U_r, nUd);
           {
             V t;
             if (L::dot6_packed(Ma, cur.c, &t)) {
@@ -1461,7 +1469,7 @@ struct Core {
               for (int j = 0; j < 6; ++j) pa = pa + Ma[j] * cur.c[j];
             }
           }
-          Ur[Lv] = U_r, Sr[Lv] = S_r, cr[Lv] = c_r, invd[Lv] = inv, uu[Lv] = u;
+          Ur[Lv] = U_r, Sr[Lv] = S_r, cr[Lv] = c_r, invd[Lv] = ninv, uu[Lv] = u;  // (invd: -1 / d)
           // propagate: first children stay in their lanes, extra children are pulled by the
           // parent's lanes.  A fixed base receives nothing (rbda/aba.py:217-222).
           if (Lv >= 2 || floating) {
@@ -1601,7 +1609,7 @@ struct Core {
         }
         const V ai = apar + cr[Lv];
         const V tot = ln.allreduce8(Ur[Lv] * ai);
-        const V sd = (uu[Lv] - tot) * invd[Lv];
+        const V sd = (tot - uu[Lv]) * invd[Lv];  // (invd = -1 / d)
         // (no select: lanes without a link at this level carry c_r = S_r = 0 and 1 / d = 0, and their apar is acar)
         acar = ai + Sr[Lv] * sd;
         // every row lane of the slot holds the same sd: all of them store it to the link's record (same address, same
@@ -1705,7 +1713,7 @@ struct Core {
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         Sa[k] = vsel(is_rev, Ra_[k], V(T(0)));
-        Sl[k] = vsel(is_rev, rxa[k], vsel(is_pri, Ra_[k], V(T(0))));
+        Sl[k] = vsel(is_rev, rxa[k], P.any_pri ? vsel(is_pri, Ra_[k], V(T(0))) : V(T(0)));
       }
     }
     V cw[3], Ic[6];
@@ -2084,6 +2092,12 @@ struct Core {
 
   template <int OFF>
   JXS_HD void seg_step_dpp(const VI& tail, V* w6) const {
+    if (G >= 16) {
+      // the partner's value times 1 or 0 -- a 16-lane row holds points of ONE environment here, so a non-finite wrench
+      // can only reach lanes of the environment it belongs to
+      ln.template fmac6_row_from_next<OFF>(w6, vsel(tail >= OFF, V(T(1)), V(T(0))));
+      return;
+    }
     const VM take = tail >= OFF;
     V g6[6];
 #pragma unroll

@@ -375,6 +375,23 @@ struct DeviceLanes {
   __device__ __forceinline__ V from_prev(V x) const { return dpp<0x138>(x); }  // wave_shr:1, lane i <- i-1
   template <int OFF>
   __device__ __forceinline__ V row_from_next(V x) const { return dpp<0x100 + OFF>(x); }  // row_shl:OFF
+  // w[k] += m * w[k]@(lane + OFF) within the 16-lane row (nothing beyond the row), k < 6: one step of the segmented
+  // suffix sum of the point wrenches (link_wrench_sums) -- six v_fmac with a row_shl DPP operand where a v_mov_dpp, a
+  // select and an addition per value stood.  `m`: 1.0 where the lane takes its partner's value, else 0.0.
+  template <int OFF>
+  __device__ __forceinline__ void fmac6_row_from_next(float* w, float m) const {
+    static_assert(OFF >= 1 && OFF <= 15, "row shift");
+#define JXS_S6(i) "v_fmac_f32_dpp %" #i ", %" #i ", %[m] row_shl:%[off] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+    asm volatile("s_nop 1\n\t" JXS_S6(0) JXS_S6(1) JXS_S6(2) JXS_S6(3) JXS_S6(4) JXS_S6(5)
+                 : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5])
+                 : [m] "v"(m), [off] "n"(OFF));
+#undef JXS_S6
+  }
+  template <int OFF>
+  __device__ __forceinline__ void fmac6_row_from_next(double* w, double m) const {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) w[k] = w[k] + m * row_from_next<OFF>(w[k]);
+  }
   // acc[k] += x[k](lane+1) * m for 9 values: nine v_fmac_f32_dpp in one asm block.  hipcc does not
   // fuse mov_dpp + fma itself; inside an asm block it does not see the "VALU write -> DPP read"
   // hazard either, hence the leading s_nop 1 (2 wait states) -- operands are not rewritten inside.

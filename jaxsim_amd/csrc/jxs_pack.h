@@ -56,7 +56,7 @@ std::string kernel_spec_string(const Packed<T>& pk, int mode) {
   };
   add("nL", P.nL), add("n", P.n), add("n_points", P.n_points), add("n_slots", P.n_slots), add("n_chunks", P.n_chunks);
   add("seg_steps", P.seg_steps), add("n_rounds", P.n_rounds), add("max_depth", P.max_depth), add("floating", P.floating);
-  add("any_suc", P.any_suc), add("seg_dpp_ok", P.seg_dpp_ok), add("row_mode", P.row_mode);
+  add("any_suc", P.any_suc), add("any_pri", P.any_pri), add("seg_dpp_ok", P.seg_dpp_ok), add("row_mode", P.row_mode);
   add("row_cross_levels", P.row_cross_levels, true), add("row_ppull_levels", P.row_ppull_levels, true);
   add("row_pull_counts", P.row_pull_counts, true), add("row_pull_dpp", P.row_pull_dpp, true), add("nonadj_levels", P.nonadj_levels, true);
   for (int k = 0; k < (int)(sizeof(P.maxch_nib) / sizeof(P.maxch_nib[0])); ++k) {
@@ -357,6 +357,9 @@ std::string pack_model(const jxs_model_desc& d, Packed<T>& out) {
     F(LF_DLIM, lane) = (T)d.position_limit_damper[i];
   }
   P.any_suc = any_suc;
+  P.any_pri = 0;
+  for (int i = 1; i < nL; ++i)
+    if (d.joint_type[i] == 2) P.any_pri = 1;
   // anchored ABA (jxs_core.h): on for the soft-contact / forward-dynamics kernels of every model with joints
   P.anchored = (std::getenv("JXS_DISABLE_ANCHORS") == nullptr && nL > 1) ? 1 : 0;  // developer knob: A/B
 

@@ -317,6 +317,10 @@ struct HostLanes {
     for (int k = 0; k < 9; ++k) a[k] = a[k] + m * from_next(x[k]);
   }
   template <int OFF>
+  void fmac6_row_from_next(V* w, const V& m) const {  // w[k] += m * w[k]@(lane + OFF) within the 16-lane row
+    for (int k = 0; k < 6; ++k) w[k] = w[k] + m * row_from_next<OFF>(w[k]);
+  }
+  template <int OFF>
   V row_from_next(const V& x) const {
     V r;
     for (int i = 0; i < G; ++i) r.v[i] = ((i % 16) + OFF < 16 && i + OFF < G) ? x.v[i + OFF] : T(0);
