@@ -391,8 +391,13 @@ struct Core {
       cross(r, Ra_, rxa);
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        Sa[k] = vsel(is_rev, Ra_[k], V(T(0)));
-        Sl[k] = vsel(is_rev, rxa[k], P.any_pri ? vsel(is_pri, Ra_[k], V(T(0))) : V(T(0)));
+        if (P.any_pri) {
+          Sa[k] = vsel(is_rev, Ra_[k], V(T(0)));
+          Sl[k] = vsel(is_rev, rxa[k], vsel(is_pri, Ra_[k], V(T(0))));
+        } else {  // every joint is revolute, and the lanes without a joint carry a zero axis in the table: nothing to mask
+          Sa[k] = Ra_[k];
+          Sl[k] = rxa[k];
+        }
       }
     }
 
@@ -423,7 +428,12 @@ struct Core {
     V doff[3];
     {
       V bo[3] = {V(P.base_off[0]), V(P.base_off[1]), V(P.base_off[2])};
-      mat3vec(R0, bo, doff);
+      if (P.has_base_off) {
+        mat3vec(R0, bo, doff);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) doff[k] = V(T(0));
+      }
     }
 
     if (MODE == MODE_KIN) {
@@ -1111,7 +1121,7 @@ struct Core {
     // Rodrigues from the half angle: sin s = 2 sh ch, 1 - cos s = 2 sh^2 (the reference also
     // forms 1 - cos as 2 sin^2(theta/2)), cos s = 1 - 2 sh^2.
     V sh, chh;
-    vsincos(vsel(is_rev, s, V(T(0))) * T(0.5), sh, chh);
+    vsincos((P.any_pri ? vsel(is_rev, s, V(T(0))) : s) * T(0.5), sh, chh);  // (s is zero in the lanes without a joint)
     const V sn = T(2) * sh * chh;
     const V c1 = T(2) * sh * sh;
     const V cs = V(T(1)) - c1;
@@ -1712,8 +1722,13 @@ struct Core {
       cross(r, Ra_, rxa);
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        Sa[k] = vsel(is_rev, Ra_[k], V(T(0)));
-        Sl[k] = vsel(is_rev, rxa[k], P.any_pri ? vsel(is_pri, Ra_[k], V(T(0))) : V(T(0)));
+        if (P.any_pri) {
+          Sa[k] = vsel(is_rev, Ra_[k], V(T(0)));
+          Sl[k] = vsel(is_rev, rxa[k], vsel(is_pri, Ra_[k], V(T(0))));
+        } else {  // every joint is revolute, and the lanes without a joint carry a zero axis in the table: nothing to mask
+          Sa[k] = Ra_[k];
+          Sl[k] = rxa[k];
+        }
       }
     }
     V cw[3], Ic[6];
@@ -2178,9 +2193,9 @@ struct Core {
     mat3vec(Rb, Lp, rc0);
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      rc0[k] = rc0[k] + rb[k];     // relative to the ABA base origin
-      rc[k] = rc0[k] + doff[k];    // relative to the base position, cached (FK) placement
-      pw[k] = rc[k] + pB[k];       // world position
+      rc0[k] = rc0[k] + rb[k];                               // relative to the ABA base origin
+      rc[k] = P.has_base_off ? rc0[k] + doff[k] : rc0[k];    // relative to the base position, cached (FK) placement
+      pw[k] = rc[k] + pB[k];                                 // world position
     }
     // pdot_C = W_v_L,lin + W_w_L x W_p_C of the cached link kinematics
     // (collidable_points.py:50-53), written about the C origin.
@@ -2192,7 +2207,7 @@ struct Core {
       cross(om, rc, t);
 #pragma unroll
       for (int k = 0; k < 3; ++k) pd[k] = pd[k] + vBc[k] + t[k];
-    } else {
+    } else if (P.has_base_off) {
       cross(om, doff, t);  // zero for URDF models (suc_H_i[0] = I when floating)
 #pragma unroll
       for (int k = 0; k < 3; ++k) pd[k] = pd[k] + t[k];
@@ -2228,16 +2243,25 @@ struct Core {
     const V fn = vmax(zero, Kdp * delta + Ddq * ddelta);
     // tangential / normal split of the point velocity and of the deformation
     V vt[3], mn[3], mt[3];
+    if (P.flat) {
+      // n = +z: the products with the components 0, 0, 1 of the normal written out (IEEE arithmetic keeps x * 0 and
+      // x - x * 1 as instructions): the same values, signed zeros aside
+      vt[0] = pd[0], vt[1] = pd[1], vt[2] = zero;
+      mn[0] = zero, mn[1] = zero, mn[2] = m[2];
+      mt[0] = m[0], mt[1] = m[1], mt[2] = zero;
+    } else {
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      vt[k] = pd[k] - pdn * nh[k];
-      mn[k] = mdn * nh[k];
-      mt[k] = m[k] - mn[k];
+      for (int k = 0; k < 3; ++k) {
+        vt[k] = pd[k] - pdn * nh[k];
+        mn[k] = mdn * nh[k];
+        mt[k] = m[k] - mn[k];
+      }
     }
     V ft[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) ft[k] = -(Kdp * mt[k] + Ddq * vt[k]);
-    const V ft2 = ft[0] * ft[0] + ft[1] * ft[1] + ft[2] * ft[2];
+    if (P.flat) ft[2] = zero;
+    const V ft2 = P.flat ? ft[0] * ft[0] + ft[1] * ft[1] : ft[0] * ft[0] + ft[1] * ft[1] + ft[2] * ft[2];
     const V mufn = P.mu * fn;
     const VM no_contact = !in_contact;  // delta <= 0
     const VM sticking = no_contact || (ft2 <= mufn * mufn);
@@ -2253,14 +2277,25 @@ struct Core {
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       const V md_nc = -(P.K_over_D * m[k]);
-      const V md_st = vt[k] - P.K_over_D * mn[k];
-      const V md_sl = -(ft[k] + Kdp * mt[k]) * inv_Ddq;
-      md[k] = vsel(no_contact, md_nc, vsel(sticking, md_st, md_sl));
+      if (P.flat && k < 2) {  // (m_n = 0 in the plane)
+        const V md_sl = -(ft[k] + Kdp * mt[k]) * inv_Ddq;
+        md[k] = vsel(no_contact, md_nc, vsel(sticking, vt[k], md_sl));
+      } else if (P.flat) {    // (along the normal: v_t = m_t = f_t = 0)
+        md[k] = vsel(no_contact || sticking, md_nc, zero);
+      } else {
+        const V md_st = vt[k] - P.K_over_D * mn[k];
+        const V md_sl = -(ft[k] + Kdp * mt[k]) * inv_Ddq;
+        md[k] = vsel(no_contact, md_nc, vsel(sticking, md_st, md_sl));
+      }
     }
     // wrench [f; (r_C - rab) x f]  (W_f = [f; p x f], soft.py:377-388, moved to the reference point)
-    w6[0] = vsel(valid, fn * nh[0] + ft[0], zero);
-    w6[1] = vsel(valid, fn * nh[1] + ft[1], zero);
-    w6[2] = vsel(valid, fn * nh[2] + ft[2], zero);
+    if (P.flat) {
+      w6[0] = vsel(valid, ft[0], zero), w6[1] = vsel(valid, ft[1], zero), w6[2] = vsel(valid, fn, zero);
+    } else {
+      w6[0] = vsel(valid, fn * nh[0] + ft[0], zero);
+      w6[1] = vsel(valid, fn * nh[1] + ft[1], zero);
+      w6[2] = vsel(valid, fn * nh[2] + ft[2], zero);
+    }
     // moment about the anchor of the parent link's chain (rab = 0: about the origin of C)
     V lever[3] = {rc[0] - rab[0], rc[1] - rab[1], rc[2] - rab[2]};
     cross(lever, w6, w6 + 3);

@@ -56,7 +56,7 @@ std::string kernel_spec_string(const Packed<T>& pk, int mode) {
   };
   add("nL", P.nL), add("n", P.n), add("n_points", P.n_points), add("n_slots", P.n_slots), add("n_chunks", P.n_chunks);
   add("seg_steps", P.seg_steps), add("n_rounds", P.n_rounds), add("max_depth", P.max_depth), add("floating", P.floating);
-  add("any_suc", P.any_suc), add("any_pri", P.any_pri), add("seg_dpp_ok", P.seg_dpp_ok), add("row_mode", P.row_mode);
+  add("any_suc", P.any_suc), add("any_pri", P.any_pri), add("has_base_off", P.has_base_off), add("seg_dpp_ok", P.seg_dpp_ok), add("row_mode", P.row_mode);
   add("row_cross_levels", P.row_cross_levels, true), add("row_ppull_levels", P.row_ppull_levels, true);
   add("row_pull_counts", P.row_pull_counts, true), add("row_pull_dpp", P.row_pull_dpp, true), add("nonadj_levels", P.nonadj_levels, true);
   for (int k = 0; k < (int)(sizeof(P.maxch_nib) / sizeof(P.maxch_nib[0])); ++k) {
@@ -269,6 +269,7 @@ std::string pack_model(const jxs_model_desc& d, Packed<T>& out) {
   P.inv_w_range = (T)(1.0 / (d.omega_max - d.omega_th));
   P.enable_friction = d.enable_friction ? 1 : 0;
   for (int k = 0; k < 3; ++k) P.base_off[k] = (T)d.suc_H_i[4 * k + 3];
+  P.has_base_off = (P.base_off[0] != T(0) || P.base_off[1] != T(0) || P.base_off[2] != T(0)) ? 1 : 0;
   P.eps = std::numeric_limits<T>::epsilon();
   P.quat_K = (T)0.1;
 

@@ -212,6 +212,7 @@ struct KParams {
   unsigned int row_cross_levels;     // bit L: some parent pulls an extra child of level L across slots
   unsigned int row_ppull_levels;     // bit L: some link of level L has its parent in another slot
   unsigned int row_pull_counts;      // 4 bits per level L: max number of extra children (level L) any parent pulls
+  int has_base_off;                  // 0: base_off = 0 (every floating-base URDF model): the terms of the base-link offset are left out
   int any_pri;                       // 1: the model has a prismatic joint (else their translation and motion-subspace terms are left out)
   unsigned int row_pull_dpp;         // bit L * kRowExtra + k: every k-th extra child of level L sits in the slot next to its parent's, eight
                                      // lanes up in the same 16-lane row -- a DPP row shift reaches it (no ds_bpermute)  [round 3]
