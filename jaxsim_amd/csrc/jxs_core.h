@@ -1099,7 +1099,7 @@ struct Core {
       // q / (|q| + eps where |q| = 0)  (data.base_orientation): 1 / |q| as ONE refined reciprocal square root -- this is the
       // head of the step's critical path (square root, guard, reciprocal: twelve dependent instructions before)
       const V nsq = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
-      const V inv = vsel(nsq > V(T(0)), vrsqrt(vsel(nsq > V(T(0)), nsq, V(T(1)))), V(T(1) / P.eps));
+      const V inv = vsel(nsq > V(T(0)), vrsqrt(vsel(nsq > V(T(0)), nsq, V(T(1)))), V(T(1)));  // (|q| = 0: q / eps = 0 = q)
 #pragma unroll
       for (int k = 0; k < 4; ++k) q[k] = q[k] * inv;
     }
@@ -1149,15 +1149,10 @@ struct Core {
       mat3vec(Rpre, t3, pl);
     } else {
       mat3mul(Rpre, Rj, Rl);
-      if (P.any_pri) {
-        mat3vec(Rpre, pj, pl);
-      } else {  // (no prismatic joint in the model: the translation is lambda_H_pre's)
-#pragma unroll
-        for (int k = 0; k < 3; ++k) pl[k] = V(T(0));
-      }
+      if (P.any_pri) mat3vec(Rpre, pj, pl);
     }
 #pragma unroll
-    for (int k = 0; k < 3; ++k) pl[k] = pl[k] + ppre[k];
+    for (int k = 0; k < 3; ++k) pl[k] = (P.any_pri || P.any_suc) ? pl[k] + ppre[k] : ppre[k];  // (no prismatic joint: lambda_H_pre's translation)
     // The base lane starts from (R0, 0): frame C has its origin at the base position.
 #pragma unroll
     for (int k = 0; k < 9; ++k) R[k] = vsel(is_root, R0[k], Rl[k]);
