@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Assembly + instruction mix of a model-specialised kernel (developer aid; needs hipcc, not a GPU).
-    python tools/spec_isa.py icub23 float32 [mode] [extra hipcc flags...]   -> /tmp/spec_<model>_<dtype>_<mode>.s"""
+    python tools/spec_isa.py icub23|anymal12|quadruped_rigid|humanoid_relaxed float32 [mode] [extra hipcc flags...]   -> /tmp/spec_<model>_<dtype>_<mode>.s"""
 import collections
 import pathlib
 import re
@@ -17,7 +17,7 @@ from jaxsim_amd import specialize as sp  # noqa: E402
 name, dtype = sys.argv[1], sys.argv[2]
 mode = int(sys.argv[3]) if len(sys.argv) > 3 else None
 extra = sys.argv[4:]
-model = bench.build_model(name)
+model = {"quadruped_rigid": bench.build_quadruped_rigid, "humanoid_relaxed": bench.build_humanoid_relaxed}.get(name, lambda: bench.build_model(name))()
 mode = sp.mode_of(model) if mode is None else mode
 text = sp.spec(model, np.dtype(dtype), mode)
 head, assign = text.rsplit(";", 1)
