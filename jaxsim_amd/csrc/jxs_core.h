@@ -783,6 +783,24 @@ struct Core {
           if (k < nch) {
             // 1.0 where this lane is a parent of the current level with a k-th child, else 0.0
             const V okf = vsel(is_par && (child[k] >= 0), V(T(1)), V(T(0)));
+            const int sh = (L::kHasRowShl && A.spec_consts && !anch) ? P.child_shift(k) : 0;
+            if (sh > 0) {
+              // [round 3] every such child sits `sh` lanes up in its parent's 16-lane row: gathered by a DPP row shift
+              // folded into the accumulation (27 instructions instead of 27 ds_bpermute, a wait and 27 multiply-adds)
+              V acc9[9], src9[9];
+              ln.template fmac_row_shl<9>(MA, Ma, okf, sh);
+              ln.template fmac_row_shl<9>(MA + 9, Ma + 9, okf, sh);
+#pragma unroll
+              for (int e = 0; e < 3; ++e) acc9[e] = MA[18 + e], src9[e] = Ma[18 + e];
+#pragma unroll
+              for (int e = 0; e < 6; ++e) acc9[3 + e] = pA[e], src9[3 + e] = pa[e];
+              ln.template fmac_row_shl<9>(acc9, src9, okf, sh);
+#pragma unroll
+              for (int e = 0; e < 3; ++e) MA[18 + e] = acc9[e];
+#pragma unroll
+              for (int e = 0; e < 6; ++e) pA[e] = acc9[3 + e];
+              continue;
+            }
             // issue all 27 shuffles back to back, wait once, then consume (Ma/pa are finite in
             // every lane, see inv_d above, so masking by multiplication is safe)
             V gM[21], gp[6], gd[3];

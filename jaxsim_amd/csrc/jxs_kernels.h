@@ -83,6 +83,11 @@ __global__ __launch_bounds__(64, VARIANT == KV_OCC2 ? 2 : 1) void jxs_kernel(con
 #endif
   // (launch_one allocates the LDS area of the row layout for exactly these modes when P.row_mode is set; only where
   // that flag is a compile-time constant, so that the first loads of the generic kernel need no scalar load)
+#ifdef JXS_SPEC_ASSIGN
+  A.spec_consts = 1;
+#else
+  A.spec_consts = 0;
+#endif
   A.has_lds = (kFlagsKnown && P.row_mode && (MODE == jxs::MODE_STEP || MODE == jxs::MODE_ROLLOUT || MODE == jxs::MODE_FD || MODE == jxs::MODE_STEP_RK4)) ? 1 : 0;
   extern __shared__ __align__(16) unsigned char jxs_smem[];
   const jxs::DeviceLanes<T, G> ln(A.N, reinterpret_cast<T*>(jxs_smem),

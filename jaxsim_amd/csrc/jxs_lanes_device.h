@@ -392,6 +392,51 @@ struct DeviceLanes {
 #pragma unroll
     for (int k = 0; k < 6; ++k) w[k] = w[k] + m * row_from_next<OFF>(w[k]);
   }
+  // acc[i] += m * x[i]@(lane + OFF) inside the lane's 16-lane row (nothing beyond the row), i < N <= 9: a parent of the
+  // link-per-lane sweeps gathers a child that sits OFF lanes up (KParams::child_shift) -- v_fmac with a row_shl DPP
+  // operand instead of ds_bpermute + select + add per value
+  static constexpr bool kHasRowShl = sizeof(T) == 4;
+  template <int OFF, int N>
+  __device__ __forceinline__ void fmac_row_shl_c(float* a, const float* x, float m) const {
+    static_assert(N == 3 || N == 6 || N == 9, "three, six or nine values");
+#define JXS_RS(i, j) "v_fmac_f32_dpp %" #i ", %" #j ", %[m] row_shl:%[off] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+    if constexpr (N == 3)
+      asm volatile("s_nop 1\n\t" JXS_RS(0, 3) JXS_RS(1, 4) JXS_RS(2, 5)
+                   : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]) : "v"(x[0]), "v"(x[1]), "v"(x[2]), [m] "v"(m), [off] "n"(OFF));
+    else if constexpr (N == 6)
+      asm volatile("s_nop 1\n\t" JXS_RS(0, 6) JXS_RS(1, 7) JXS_RS(2, 8) JXS_RS(3, 9) JXS_RS(4, 10) JXS_RS(5, 11)
+                   : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5])
+                   : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), [m] "v"(m), [off] "n"(OFF));
+    else
+      asm volatile("s_nop 1\n\t" JXS_RS(0, 9) JXS_RS(1, 10) JXS_RS(2, 11) JXS_RS(3, 12) JXS_RS(4, 13) JXS_RS(5, 14) JXS_RS(6, 15)
+                   JXS_RS(7, 16) JXS_RS(8, 17)
+                   : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8])
+                   : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]), "v"(x[8]), [m] "v"(m),
+                     [off] "n"(OFF));
+#undef JXS_RS
+  }
+  template <int N>
+  __device__ __forceinline__ void fmac_row_shl(float* a, const float* x, float m, int off) const {
+    switch (off) {  // (wave-uniform; a constant in the model-specialised kernels)
+      case 1: fmac_row_shl_c<1, N>(a, x, m); break;
+      case 2: fmac_row_shl_c<2, N>(a, x, m); break;
+      case 3: fmac_row_shl_c<3, N>(a, x, m); break;
+      case 4: fmac_row_shl_c<4, N>(a, x, m); break;
+      case 5: fmac_row_shl_c<5, N>(a, x, m); break;
+      case 6: fmac_row_shl_c<6, N>(a, x, m); break;
+      case 7: fmac_row_shl_c<7, N>(a, x, m); break;
+      case 8: fmac_row_shl_c<8, N>(a, x, m); break;
+      case 9: fmac_row_shl_c<9, N>(a, x, m); break;
+      case 10: fmac_row_shl_c<10, N>(a, x, m); break;
+      case 11: fmac_row_shl_c<11, N>(a, x, m); break;
+      case 12: fmac_row_shl_c<12, N>(a, x, m); break;
+      case 13: fmac_row_shl_c<13, N>(a, x, m); break;
+      case 14: fmac_row_shl_c<14, N>(a, x, m); break;
+      default: fmac_row_shl_c<15, N>(a, x, m); break;
+    }
+  }
+  template <int N>
+  __device__ __forceinline__ void fmac_row_shl(double*, const double*, double, int) const {}  // (never called: kHasRowShl)
   // acc[k] += x[k](lane+1) * m for 9 values: nine v_fmac_f32_dpp in one asm block.  hipcc does not
   // fuse mov_dpp + fma itself; inside an asm block it does not see the "VALU write -> DPP read"
   // hazard either, hence the leading s_nop 1 (2 wait states) -- operands are not rewritten inside.

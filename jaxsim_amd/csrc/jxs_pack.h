@@ -58,7 +58,7 @@ std::string kernel_spec_string(const Packed<T>& pk, int mode) {
   add("seg_steps", P.seg_steps), add("n_rounds", P.n_rounds), add("max_depth", P.max_depth), add("floating", P.floating);
   add("any_suc", P.any_suc), add("any_pri", P.any_pri), add("has_base_off", P.has_base_off), add("seg_dpp_ok", P.seg_dpp_ok), add("row_mode", P.row_mode);
   add("row_cross_levels", P.row_cross_levels, true), add("row_ppull_levels", P.row_ppull_levels, true);
-  add("row_pull_counts", P.row_pull_counts, true), add("row_pull_dpp", P.row_pull_dpp, true), add("nonadj_levels", P.nonadj_levels, true);
+  add("row_pull_counts", P.row_pull_counts, true), add("row_pull_dpp", P.row_pull_dpp, true), add("child_off", P.child_off, true), add("nonadj_levels", P.nonadj_levels, true);
   for (int k = 0; k < (int)(sizeof(P.maxch_nib) / sizeof(P.maxch_nib[0])); ++k) {
     char nm[32];
     std::snprintf(nm, sizeof nm, "maxch_nib[%d]", k);
@@ -221,6 +221,19 @@ std::string pack_model(const jxs_model_desc& d, Packed<T>& out) {
   }
   std::vector<int> subtree(nL, 1);
   for (int i = nL - 1; i >= 1; --i) subtree[d.parent[i]] += subtree[i];  // BFS indices: children after parents
+  P.child_off = 0;
+  if (std::getenv("JXS_DISABLE_CHILD_DPP") == nullptr)  // developer knob: A/B
+    for (int k = 1; k <= 5; ++k) {
+      int off = -1;
+      for (int i = 0; i < nL; ++i) {
+        if ((int)children[i].size() <= k) continue;
+        const int pl = lane_of[i], o = lane_of[children[i][k]] - pl;
+        if (o < 1 || o > 15 || (pl & 15) + o > 15) off = 0;
+        else if (off == -1) off = o;
+        else if (off != o) off = 0;
+      }
+      if (off > 0) P.child_off |= (unsigned)off << ((k - 1) * 4);
+    }
   P.nonadj_levels = 0;
   for (int i = 1; i < nL; ++i)
     if (lane_of[d.parent[i]] != lane_of[i] - 1) P.nonadj_levels |= 1ull << level[i];

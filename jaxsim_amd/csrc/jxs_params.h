@@ -214,6 +214,12 @@ struct KParams {
   unsigned int row_pull_counts;      // 4 bits per level L: max number of extra children (level L) any parent pulls
   int has_base_off;                  // 0: base_off = 0 (every floating-base URDF model): the terms of the base-link offset are left out
   int any_pri;                       // 1: the model has a prismatic joint (else their translation and motion-subspace terms are left out)
+  // [round 3] link-per-lane sweeps: nibble k - 1, k = 1..5: EVERY link with a k-th child (a non-first child) finds it the
+  // same number of lanes up, inside its own 16-lane row -- the child is gathered by a DPP row shift folded into the
+  // accumulation instead of a ds_bpermute per value; 0: shuffle.  Used by the model-specialised kernels only (the shift
+  // is an instruction modifier: a run-time value would be a fifteen-way branch around every gather).
+  unsigned int child_off;
+  JXS_HD int child_shift(int k) const { return (k >= 1 && k <= 5) ? (int)((child_off >> ((k - 1) * 4)) & 15u) : 0; }
   unsigned int row_pull_dpp;         // bit L * kRowExtra + k: every k-th extra child of level L sits in the slot next to its parent's, eight
                                      // lanes up in the same 16-lane row -- a DPP row shift reaches it (no ds_bpermute)  [round 3]
   JXS_HD int maxch(int L) const {
@@ -290,6 +296,7 @@ struct KArgs {
   long long* dbg;      // developer builds (-DJXS_PHASE_TIMING): [blocks][kDbgSlots] cycle stamps, else null
   int* faults;         // [2] environments whose QP contact-force solve / impact solve was discarded (non-finite), or null
   int flags;           // developer switches of a launch: bit 0 = no MFMA in the contact solvers' Cholesky (A/B against the vector path)
+  int spec_consts;     // 1: the integer model flags of KParams are compile-time constants in this kernel (jxs_spec.hip)
   int has_lds;         // the launch has the per-environment LDS area of the row layout (known when the wave starts: a
                        // compile-time constant in the specialised / common-feature kernels): the thirteen
                        // environment-uniform rows of the state are fetched by ONE load instruction and spread through it

@@ -150,6 +150,9 @@ struct HostLanes {
   // (the MFMA tiles of the contact solvers' Cholesky exist on the device only: the emulation runs the vector path,
   // which performs the same fused multiply-adds in the same order)
   static constexpr bool kHasMfma = false;
+  static constexpr bool kHasRowShl = false;  // (the emulation gathers children through shfl: same values)
+  template <int N>
+  void fmac_row_shl(V*, const V*, const V&, int) const {}
   static constexpr bool kHasRowShift = false;  // (the emulation pulls through shfl: same values)
   void fmac7_from_next_slot(V*, const V*, const V&) const {}
   template <int NTMAX>
