@@ -1450,11 +1450,14 @@ struct Core {
       if (Lv <= max_depth && (Lv >= 1 || floating)) {
         const VM has = rt.rec[Lv] != lds_zero_rec(G);
         V MArow[6];  // (lanes without a link, and the idle lanes 6, 7 of a slot, read the all-zero record)
-        if (!L::add6_packed(cur.Mrow, accM, MArow)) {
+        if (Lv == max_depth) {  // (the deepest level: nothing has been handed up yet -- IEEE arithmetic keeps x + 0)
+#pragma unroll
+          for (int j = 0; j < 6; ++j) MArow[j] = cur.Mrow[j];
+        } else if (!L::add6_packed(cur.Mrow, accM, MArow)) {
 #pragma unroll
           for (int j = 0; j < 6; ++j) MArow[j] = cur.Mrow[j] + accM[j];
         }
-        const V pr = cur.pr + accp;
+        const V pr = (Lv == max_depth) ? cur.pr : cur.pr + accp;
         const V S_r = cur.S_r;
         const V c_r = cur.c_r;
         if (Lv == 0) {
