@@ -44,6 +44,36 @@ def test_mode_follows_the_contact_model_and_integrator(models):
     assert specialize.spec(rigid, np.float32, specialize.MODE_STEP_RIGID).count("P.rg_merge=1") == 1
 
 
+def _flags(model, dtype=np.float32):
+    text = specialize.spec(model, dtype, specialize.mode_of(model))
+    return {k[2:]: int(v.rstrip("ul"), 0) for k, v in (kv.split("=") for kv in text.rsplit(";", 1)[1].split(","))}
+
+
+def test_description_carries_what_the_round_3_kernels_branch_on(models):
+    """Packer-derived constants of the round-3 step kernels (jxs_pack.h): DPP-reachable children, lane-ordered rows,
+    and the features whose terms a model-specialised kernel leaves out."""
+    icub, anymal, cartpole, pendulum = (_flags(models(n)) for n in ("icub", "anymal", "cartpole", "pendulum"))
+    # no prismatic joint in the humanoid / quadruped, one in the cartpole
+    assert (icub["any_pri"], anymal["any_pri"], cartpole["any_pri"]) == (0, 0, 1)
+    # floating-base URDF models carry no base-link offset; the fixed-base pendulum of the zoo does
+    assert (icub["has_base_off"], anymal["has_base_off"], pendulum["has_base_off"]) == (0, 0, 1)
+    # the quadruped's base finds its second, third and fourth leg 4, 7 and 10 lanes up (DFS lane order, three links per leg)
+    assert anymal["child_off"] == 0xA74
+    # the humanoid: the root's third child sits 13 lanes up in its own 16-lane row; its second children differ between
+    # the root and the chest, so k = 1 stays a shuffle
+    assert icub["child_off"] == 0xD0
+    # row layout of the humanoid: two of the three extra children sit in the slot next to their parent's
+    assert bin(icub["row_pull_dpp"]).count("1") == 2 and icub["row_mode"] == 1
+    # points of the humanoid are numbered in slot order, its joints are not in lane order; a chain is
+    assert (icub["prow_seq"], icub["jrow_seq"], cartpole["jrow_seq"]) == (1, 0, 1)
+    # the knobs switch the features off (A/B on a GPU box: tools/gpu/r03_env_ab.sh)
+    for knob, key in (("JXS_DISABLE_CHILD_DPP", "child_off"), ("JXS_DISABLE_PULL_DPP", "row_pull_dpp")):
+        os.environ[knob] = "1"
+        try:
+            assert _flags(models("anymal" if key == "child_off" else "icub"))[key] == 0
+        finally:
+            del os.environ[knob]
+
 @pytest.mark.skipif(HIPCC is None, reason="hipcc not installed")
 def test_build_produces_the_two_entry_points(models, tmp_path, monkeypatch):
     monkeypatch.setattr(specialize, "CACHE", tmp_path)
