@@ -69,6 +69,24 @@ struct Core {
     o[1] = a[2] * b[0] - a[0] * b[2];
     o[2] = a[0] * b[1] - a[1] * b[0];
   }
+  // acc[k] += x[k]@(lane + 1) where `ok`, k < N (6 or 9): a parent of the link-per-lane sweeps takes the share of its FIRST
+  // child, which sits in the next lane (depth-first lane order).  Fused form: a DPP lane shift as the operand of a
+  // multiply-add with the mask as a 0 / 1 factor (values are finite by construction) -- with the last lane of the group
+  // switched off, because ITS next lane is the base link of the next environment and 0 x NaN of a diverged neighbour
+  // would walk down the padding lanes into this one (tests: test_a_non_finite_environment_does_not_touch_its_neighbours).
+  // That lane must be a padding lane for this (nobody needs its value); a model that fills its group takes the selects.
+  template <int N>
+  JXS_HD void add_from_next(const VI& lane, V* acc, const V* x, const VM& ok) const {
+    static_assert(N == 6 || N == 9, "six or nine values");
+    if (P.nL < G) {
+      const V okf = vsel(ok, V(T(1)), V(T(0)));
+      if (N == 9) ln.fmac9_from_next(acc, x, okf, lane < G - 1);
+      else ln.fmac6_from_next(acc, x, okf, lane < G - 1);
+    } else {
+#pragma unroll
+      for (int k = 0; k < N; ++k) acc[k] = acc[k] + vsel(ok, ln.from_next(x[k]), V(T(0)));
+    }
+  }
   static JXS_HD void mat3vec(const V* R, const V* x, V* o) {  // o = R x, R row-major
     o[0] = R[0] * x[0] + R[1] * x[1] + R[2] * x[2];
     o[1] = R[3] * x[0] + R[4] * x[1] + R[5] * x[2];
@@ -757,11 +775,11 @@ struct Core {
         const unsigned long long mcw = Lv < 16 ? mc0 : Lv < 32 ? mc1 : Lv < 48 ? mc2 : mc3;
         const int nch = (int)((mcw >> ((Lv & 15) * 4)) & 15ull);
         if (nch >= 1) {
-          const V okf = vsel(is_par && (child[0] >= 0), V(T(1)), V(T(0)));
-          // 27 values = 3 blocks of 9 fused "acc += value(lane+1) * okf"
+          const VM ok0 = is_par && (child[0] >= 0);
+          // 27 values = 3 blocks of 9 fused "acc += value(lane+1) * ok"
           V acc9[9], src9[9];
-          ln.fmac9_from_next(MA, Ma, okf);
-          ln.fmac9_from_next(MA + 9, Ma + 9, okf);
+          add_from_next<9>(lane, MA, Ma, ok0);
+          add_from_next<9>(lane, MA + 9, Ma + 9, ok0);
   #pragma unroll
           for (int e = 0; e < 3; ++e) {
             acc9[e] = MA[18 + e];
@@ -772,7 +790,7 @@ struct Core {
             acc9[3 + e] = pA[e];
             src9[3 + e] = pa[e];
           }
-          ln.fmac9_from_next(acc9, src9, okf);
+          add_from_next<9>(lane, acc9, src9, ok0);
   #pragma unroll
           for (int e = 0; e < 3; ++e) MA[18 + e] = acc9[e];
   #pragma unroll
@@ -2516,10 +2534,10 @@ struct Core {
       const VM is_par = level == (Lv - 1);
       const int nch = P.maxch(Lv);
       if (nch >= 1) {
-        const V okf = vsel(is_par && (child[0] >= 0), V(T(1)), V(T(0)));
+        const VM ok0 = is_par && (child[0] >= 0);
         V t9[9];
-        ln.fmac9_from_next(Ic, Ic, okf);
-        ln.fmac9_from_next(Ic + 9, Ic + 9, okf);
+        add_from_next<9>(lane, Ic, Ic, ok0);
+        add_from_next<9>(lane, Ic + 9, Ic + 9, ok0);
 #pragma unroll
         for (int e = 0; e < 3; ++e) t9[e] = Ic[18 + e];
 #pragma unroll
@@ -2527,7 +2545,7 @@ struct Core {
         V a9[9];
 #pragma unroll
         for (int e = 0; e < 9; ++e) a9[e] = t9[e];
-        ln.fmac9_from_next(a9, t9, okf);
+        add_from_next<9>(lane, a9, t9, ok0);
 #pragma unroll
         for (int e = 0; e < 3; ++e) Ic[18 + e] = a9[e];
       }

@@ -440,8 +440,11 @@ struct DeviceLanes {
   // acc[k] += x[k](lane+1) * m for 9 values: nine v_fmac_f32_dpp in one asm block.  hipcc does not
   // fuse mov_dpp + fma itself; inside an asm block it does not see the "VALU write -> DPP read"
   // hazard either, hence the leading s_nop 1 (2 wait states) -- operands are not rewritten inside.
-  __device__ __forceinline__ void fmac9_from_next(float* a, const float* x, float m) const {
-    asm volatile(
+  // `active`: the lanes that take part -- a lane that does not is not written, and reads as 0 from its neighbour
+  // (bound_ctrl).  The callers switch the LAST lane of every environment off: its lane + 1 is the base link of the
+  // NEXT environment, and 0 x (a non-finite value of a diverged neighbour) is not 0.
+  __device__ __forceinline__ void fmac9_from_next(float* a, const float* x, float m, bool active) const {
+    if (active) asm volatile(
         "s_nop 1\n\t"
         "v_fmac_f32_dpp %0, %9, %18 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
         "v_fmac_f32_dpp %1, %10, %18 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
@@ -455,9 +458,30 @@ struct DeviceLanes {
         : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8])
         : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]), "v"(x[8]), "v"(m));
   }
-  __device__ __forceinline__ void fmac9_from_next(double* a, const double* x, double m) const {
+  // six values (a spatial force): the sweeps of the rigid contact models hand the first child's share to its parent
+  __device__ __forceinline__ void fmac6_from_next(float* a, const float* x, float m, bool active) const {
+    if (active) asm volatile(
+        "s_nop 1\n\t"
+        "v_fmac_f32_dpp %0, %6, %12 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_dpp %1, %7, %12 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_dpp %2, %8, %12 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_dpp %3, %9, %12 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_dpp %4, %10, %12 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_dpp %5, %11, %12 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+        : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5])
+        : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(m));
+  }
+  __device__ __forceinline__ void fmac6_from_next(double* a, const double* x, double m, bool active) const {
+    if (active) {
 #pragma unroll
-    for (int k = 0; k < 9; ++k) a[k] = a[k] + m * from_next(x[k]);
+      for (int k = 0; k < 6; ++k) a[k] = a[k] + m * from_next(x[k]);
+    }
+  }
+  __device__ __forceinline__ void fmac9_from_next(double* a, const double* x, double m, bool active) const {
+    if (active) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) a[k] = a[k] + m * from_next(x[k]);
+    }
   }
 
   // sum over the 8 lanes of a slot (row-distributed ABA), result in all 8: three DPP adds

@@ -316,9 +316,21 @@ struct HostLanes {
   void lds_readv(const VI& addr, V* v) const {
     for (int k = 0; k < N; ++k) v[k] = lds_read(addr + k);
   }
-  void fmac9_from_next(V* a, const V* x, const V& m) const {
-    for (int k = 0; k < 9; ++k) a[k] = a[k] + m * from_next(x[k]);
+  // (`active`: lanes that take part; an inactive lane keeps its value and reads as zero from its neighbour, like a DPP
+  // operand of an exec-masked lane with bound_ctrl)
+  template <int N>
+  void fmacN_from_next(V* a, const V* x, const V& m, const VM& active) const {
+    for (int k = 0; k < N; ++k) {
+      V xm = x[k];
+      for (int i = 0; i < G; ++i)
+        if (!active.v[i]) xm.v[i] = T(0);
+      const V t = a[k] + m * from_next(xm);
+      for (int i = 0; i < G; ++i)
+        if (active.v[i]) a[k].v[i] = t.v[i];
+    }
   }
+  void fmac6_from_next(V* a, const V* x, const V& m, const VM& active) const { fmacN_from_next<6>(a, x, m, active); }
+  void fmac9_from_next(V* a, const V* x, const V& m, const VM& active) const { fmacN_from_next<9>(a, x, m, active); }
   template <int OFF>
   void fmac6_row_from_next(V* w, const V& m) const {  // w[k] += m * w[k]@(lane + OFF) within the 16-lane row
     for (int k = 0; k < 6; ++k) w[k] = w[k] + m * row_from_next<OFF>(w[k]);

@@ -1391,3 +1391,38 @@ def test_discarded_rigid_solves_are_counted_gpu(models):
             js.model.step(model, bad)
     finally:
         os.environ.pop("JAXSIM_ENABLE_EXCEPTIONS")
+
+
+ISOLATION_CASES = ["cartpole", "chain5", "chain9f", "anymal", "icub", "icub16", "anymal_rigid4", "anymal_relaxed4", "icub_relaxed16"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ISOLATION_CASES)
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_a_non_finite_environment_does_not_touch_its_neighbours(models, case, dtype):
+    """Environments are independent problems: a diverged one -- NaN in its state -- must leave
+    every other environment of the batch bit for bit what it is without it.  The kernels mask lanes by multiplying with
+    0 / 1 where the values are finite by construction and shift values between lanes with DPP; neither may carry a NaN
+    across the boundary of an environment (rows of 16 lanes, wave shifts)."""
+    if case == "anymal_rigid4":
+        name, model = "anymal", helpers.rigid_model(models("anymal"), helpers.ANYMAL_FEET_4, K=1e4, D=2e2)
+    elif case == "anymal_relaxed4":
+        name, model = "anymal", helpers.relaxed_model(models("anymal"), helpers.ANYMAL_FEET_4)
+    elif case == "icub_relaxed16":
+        name, model = "icub", helpers.relaxed_model(models("icub"), list(range(16)))
+    else:
+        name, model = case, models(case)
+    N = 24
+    d = models.random_data(name, N, seed=11, dtype=dtype)
+    blk = helpers.odata_to_block(model, d)
+    clean = js.model.step(model, js.data.JaxSimModelData.from_state_block(model, blk.copy())).state_block()
+    assert np.isfinite(clean).all()
+    n = model.dofs()
+    for bad_env in (0, 5, N - 1):
+        dirty = blk.copy()
+        dirty[13 + n + (n - 1), bad_env] = np.nan  # the last joint velocity of one environment
+        dirty[0, bad_env] = np.inf               # and its base position
+        out = js.model.step(model, js.data.JaxSimModelData.from_state_block(model, dirty)).state_block()
+        others = [e for e in range(N) if e != bad_env]
+        assert not np.isfinite(out[:, bad_env]).all()
+        assert np.array_equal(out[:, others], clean[:, others]), (case, bad_env, np.argwhere(out[:, others] != clean[:, others])[:4])
