@@ -247,3 +247,36 @@ def test_specialised_object_is_mapped_while_and_after_a_model_runs(models, monke
     model.__dict__.pop("_device", None)
     gc.collect()
     assert want in mapped()
+
+
+@pytest.mark.gpu
+def test_specialised_rk4_rigid_kernel_is_deterministic_gpu(models, monkeypatch):
+    """RungeKutta4 + RigidContacts on the quadruped AS A MODEL-SPECIALISED KERNEL (the default experience with hipcc;
+    the rest of the suite pins the ahead-of-time kernels for most models): finite, the same bits on every call, and
+    the library's own kernel within fp32 rounding.  This kernel exposed a hardware hazard of round 3's DPP child
+    gathers -- a DPP operand right behind the scalar instruction that re-enables lanes still saw them switched off
+    (jxs_lanes_device.h exec_settle): results were non-finite in some environments on some calls."""
+    import jaxsim_amd as ja
+
+    model = helpers.with_params(helpers.rigid_model(models("anymal"), helpers.ANYMAL_FEET_4, K=1e4, D=2e2), integrator=ja.IntegratorType.RungeKutta4)
+    d = models.random_data("anymal", 21, seed=5, dtype=np.float32)
+    blk = helpers.odata_to_block(model, d)
+
+    def step():
+        return js.model.step(model, js.data.JaxSimModelData.from_state_block(model, blk.copy())).state_block()
+
+    monkeypatch.setenv("JAXSIM_AMD_SPECIALIZE", "0")
+    model.__dict__.pop("_device", None)
+    generic = step()
+    monkeypatch.setenv("JAXSIM_AMD_SPECIALIZE", "1" if HIPCC else "cached")  # (pre-built by __graft_entry__.build())
+    model.__dict__.pop("_device", None)
+    try:
+        if specialize.modes(runtime.device_model(model, np.float32)) != [specialize.MODE_STEP_RK4_RIGID]:
+            pytest.skip("no specialised RungeKutta4 + RigidContacts kernel in the cache and no hipcc")
+        first = step()
+        assert np.isfinite(first).all()
+        for _ in range(8):
+            np.testing.assert_array_equal(step(), first)
+        assert helpers.rel_err(first, generic) < 5e-4
+    finally:
+        model.__dict__.pop("_device", None)
