@@ -507,11 +507,50 @@ def dry_run_bootstrap(args, rank, world, result_out):
         raise SystemExit(f"rank {rank}: bootstrap dry run failed: {los} {his} {ids}")
 
 
+def spawn_ranks(n_ranks):
+    """`python bench.py --gpus N` without a launcher: start one process per GPU of this node with the variables
+    torch.distributed.run would export (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT; the bootstrap of
+    jaxsim_amd/distributed.py is file-based and torch-free, its job key uses MASTER_PORT and the pid of this parent),
+    forward rank 0's result line, and return the first non-zero exit code of any rank (0 if all succeeded).  A rank
+    that dies takes the others down with it instead of leaving them in a rendezvous."""
+    import socket
+    import subprocess
+    import time
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))  # fmt: skip
+        # rank 0 inherits stdout (its JSON line is the result); the other ranks' stdout goes to stderr
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env, stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    live = set(range(n_ranks))
+    while live:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print(f"bench.py: rank {r} exited with {code}; stopping the other ranks", file=sys.stderr)
+                for q in live:
+                    procs[q].terminate()
+        time.sleep(0.05)
+    return rc
+
+
 def main():
     args = parse_args()
     if os.environ.get("JAXSIM_AMD_LIB"):
         # the developer knob of jaxsim_amd/_lib.py would let any library stand in for the product
         raise SystemExit("bench.py measures the in-tree library only: unset JAXSIM_AMD_LIB")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # one command: `python bench.py --gpus N` is its own launcher (one child process per GPU, same arguments)
+        raise SystemExit(spawn_ranks(args.gpus))
     # Model-specialised step kernels (jaxsim_amd/specialize.py): what `jax.jit` is to the reference -- the same
     # kernel source compiled with the model's integer flags as constants.  Built once per model (seconds, hipcc;
     # __graft_entry__.build() pre-builds the configurations of this file), outside every timed region.
@@ -528,7 +567,7 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and world == 1:
-        raise SystemExit("multi-GPU runs are launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE=1")
     if args.steps < 1:
         raise SystemExit("--steps must be >= 1")
 

@@ -98,6 +98,35 @@ def test_bench_bootstrap_dry_run(world):
     assert out["shards"][0] == [0, 1024] and out["shards"][-1] == [1024 * (world - 1), 1024 * world]
 
 
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_is_its_own_launcher(world):
+    """[round 4] `python bench.py --gpus N` as ONE command, without torch.distributed.run: bench.py starts one rank per
+    GPU itself (bench.py::spawn_ranks), rank 0's JSON line is the only thing on stdout, exit code 0."""
+    import json
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR", "JAXSIM_AMD_LIB")}
+    res = subprocess.run([sys.executable, str(HERE.parent / "bench.py"), "--gpus", str(world), "--steps", "20", "--warmup", "5", "--dry-run-bootstrap"],
+                         capture_output=True, text=True, timeout=300, env=dict(env, OMP_NUM_THREADS="1"))  # fmt: skip
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    lines = res.stdout.splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), res.stdout
+    out = json.loads(lines[0])
+    assert out["ok"] and out["n_gpus"] == world and out["global_batch"] == 1024 * world and out["same_id_on_all_ranks"]
+    assert out["shards"][-1] == [1024 * (world - 1), 1024 * world]
+
+
+def test_bench_launcher_propagates_a_failing_rank():
+    """A rank that cannot run (here: no second HIP device -- on a CPU box none at all) makes the one-command launch
+    exit non-zero without a result line, and no rank is left waiting in the rendezvous."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR", "JAXSIM_AMD_LIB")}
+    res = subprocess.run([sys.executable, str(HERE.parent / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                          "--saturated-envs", "0", "--no-other-contact-models"],
+                         capture_output=True, text=True, timeout=300, env=dict(env, OMP_NUM_THREADS="1", ROCR_VISIBLE_DEVICES="0"))  # fmt: skip
+    assert res.returncode != 0
+    assert not [ln for ln in res.stdout.splitlines() if ln.startswith("{")], res.stdout
+    assert "stopping the other ranks" in res.stderr or "exited with" in res.stderr
+
+
 def test_all_gather_state_refuses_unequal_shards(monkeypatch):
     class FakeComm:
         world_size = 2
