@@ -227,6 +227,12 @@ int jxs_validate_state(jxs_model* model, const void* state, int N, int* counts3,
  * solves, counts2[1] = impact solves, in environments, since the last reset.  Synchronous.          */
 int jxs_solver_fault_counts(jxs_model* model, int* counts2, int reset, void* stream);
 
+/* Developer knobs of the launcher (JXS_DUO, JXS_DUO_MAX_BLOCKS, JXS_NO_MFMA, JXS_DISABLE_COMMON_VARIANT: A/B switches
+ * between kernel variants that compute the same thing) are read from the environment once per process, at the first
+ * launch.  This call reads them again -- for test programs that switch variants between launches.  No reference
+ * counterpart (XLA flags are read once too).                                                          */
+int jxs_debug_reload_env(void);
+
 /* Gravity compensation torques: the joint part of free_floating_gravity_forces
  * (src/jaxsim/api/model.py:1897-1931: RNEA at zero velocity, zero acceleration, no external forces),
  * written as [n][N] -- the layout jxs_step reads `tau` in, so a controller loop

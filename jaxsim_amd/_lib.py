@@ -222,6 +222,7 @@ def _declare(lib):
         "jxs_refresh_kinematics": [vp, vp, vp, vp, C.c_int, vp],
         "jxs_mass_matrix": [vp, vp, vp, C.c_int, vp],
         "jxs_solver_fault_counts": [vp, C.POINTER(C.c_int), C.c_int, vp],
+        "jxs_debug_reload_env": [],
         "jxs_jacobian_full": [vp, vp, vp, vp, C.c_int, vp],
         "jxs_mass_matrix_inverse": [vp, vp, vp, C.c_int, vp],
         "jxs_comm_unique_id": [C.c_char * 128],

@@ -47,4 +47,9 @@ fi
 for t in float double; do for m in 0 1 2 3 4 5 6 7 8 9 10 11; do [ -f "$OBJ/inst_${t}_${m}.o" ] || { echo "missing object inst_${t}_${m}.o" >&2; exit 1; }; done; done
 [ -f "$OBJ/api.o" ] || { echo "missing object api.o" >&2; exit 1; }
 "$HIPCC" --offload-arch=gfx950 -shared -fPIC "$OBJ"/api.o "$OBJ"/inst_*.o -o "$OUT" -ldl
+# [round 4] wait-state lint of the device code (jaxsim_amd/isa_lint.py): the hazards hipcc cannot pad inside asm blocks
+# (VALU write -> DPP read, VALU EXEC write -> DPP).  A hit FAILS the build.  JXS_SKIP_LINT=1: developer builds only.
+if [ "${JXS_SKIP_LINT:-0}" != 1 ]; then
+  (cd ../.. && "${PYTHON:-python3}" -m jaxsim_amd.isa_lint "jaxsim_amd/csrc/$OUT") || { echo "build.sh: ISA lint failed for $OUT" >&2; rm -f "$OUT"; exit 1; }
+fi
 echo "built $(pwd)/$OUT"

@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <string>
 
 #include "../../include/jaxsim_amd.h"
@@ -28,6 +29,29 @@ template <typename T, int MODE>
 hipError_t launch_g(int G, const jxs::KParams<T>& P, const unsigned char* mblk, const jxs::KArgs<T>& A, hipStream_t s);
 }
 using jxs_launch::launch_g;
+
+namespace {
+// Developer knobs of the launcher (JXS_NO_MFMA, JXS_DUO, JXS_DUO_MAX_BLOCKS, JXS_DISABLE_COMMON_VARIANT): read from the
+// environment ONCE per process -- getenv on every launch of a ~6 us kernel was host time on the hot path and a data race
+// with a Python thread that changes os.environ (glibc getenv against setenv).  jxs_debug_reload_env() re-reads them: the
+// tests switch variants between launches of one process.  Launches captured in a hipGraph keep what they captured.
+std::atomic<int> g_knobs{-1}, g_duo_max_blocks{0};
+void load_knobs() {
+  auto on = [](const char* name) { const char* v = std::getenv(name); return v != nullptr && std::atoi(v) != 0; };
+  int k = 0;
+  if (on("JXS_NO_MFMA")) k |= jxs::KNOB_NO_MFMA;
+  if (on("JXS_DUO")) k |= jxs::KNOB_DUO;
+  if (std::getenv("JXS_DISABLE_COMMON_VARIANT") != nullptr) k |= jxs::KNOB_NO_COMMON_VARIANT;
+  const char* b = std::getenv("JXS_DUO_MAX_BLOCKS");
+  g_duo_max_blocks.store(b == nullptr ? 0 : std::atoi(b));
+  g_knobs.store(k);
+}
+void debug_knobs(int& knobs, int& duo_max_blocks) {
+  static std::once_flag once;
+  std::call_once(once, load_knobs);
+  knobs = g_knobs.load(std::memory_order_relaxed), duo_max_blocks = g_duo_max_blocks.load(std::memory_order_relaxed);
+}
+}  // namespace
 
 namespace {
 
@@ -97,6 +121,7 @@ struct ModelT {
     jxs::KArgs<T> a{};
     a.N = N;
     a.faults = faults;
+    debug_knobs(a.knobs, a.duo_max_blocks);
     return a;
   }
 };
@@ -623,6 +648,12 @@ int jxs_gravity_torques(jxs_model* model, const void* state, void* out_tau, int 
   // no velocity rows, no prefix sums, no rotated inertias (jxs_core.h gravity_torques)
   return run_any(model, jxs::MODE_GRAV, state, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, N, 1, stream,
                  out_tau);
+}
+int jxs_debug_reload_env(void) {
+  int k, b;
+  debug_knobs(k, b);  // (the first read happens exactly once)
+  load_knobs();
+  return JXS_OK;
 }
 int jxs_solver_fault_counts(jxs_model* model, int* counts2, int reset, void* stream) {
   if (model == nullptr || counts2 == nullptr) return fail(JXS_EINVAL, "null argument");

@@ -1594,7 +1594,7 @@ struct Core {
       const V piv = vsel(row == 5, x[5], vsel(row == 4, x[4], vsel(row == 3, x[3], vsel(row == 2, x[2], vsel(row == 1, x[1], x[0])))));
       a0_own = vsel(lane < 6, x[6] * vrcp_acc(piv), zero);  // pass 3 starts from here, without the LDS round trip below
       a0_in_lanes = true;
-      ln.lds_write(lane + XB, a0_own, lane < 6);  // (exec-masked: the helper lets EXEC settle before the DPP reductions of pass 3)
+      ln.lds_write(lane + XB, a0_own, lane < 6);
       V rw[8];
       ln.template lds_readv<8>(lane * 0 + XB, rw);
 #pragma unroll

@@ -150,9 +150,10 @@ hipError_t launch_one(const jxs::KParams<T>& P, const unsigned char* mblk, const
   const bool rows = P.row_mode && (MODE == jxs::MODE_STEP || MODE == jxs::MODE_ROLLOUT || MODE == jxs::MODE_FD ||
                                    MODE == jxs::MODE_STEP_RK4);
   size_t lds_bytes = rows ? sizeof(T) * (size_t)envs_per_wave * jxs::lds_words_per_env(G) : 0;
-  const char* const no_mfma = std::getenv("JXS_NO_MFMA");  // developer A/B: the vector path of the contact solvers' Cholesky
+  // (developer knobs arrive in A.knobs: the library reads the environment once, jxs_api.hip debug_knobs -- no getenv on the
+  // launch path, no race with a Python thread that edits os.environ)
   const KTail<T> tail{A.in_a, A.out_a, A.out_H, A.out_V, A.out_tau, A.id_zero_vel, A.dbg, A.faults,
-                      A.flags | ((no_mfma != nullptr && std::atoi(no_mfma) != 0) ? 1 : 0)};
+                      A.flags | ((A.knobs & jxs::KNOB_NO_MFMA) ? 1 : 0)};  // KNOB_NO_MFMA: A/B of the vector path of the contact solvers' Cholesky
   if (MODE == jxs::MODE_STEP_RIGID || MODE == jxs::MODE_STEP_RK4_RIGID) {
     lds_bytes = sizeof(T) * (size_t)envs_per_wave * jxs::rigid_lds_words_per_env(P.n_cp, P.rigid);
     if (lds_bytes > 64 * 1024) {  // beyond the default dynamic-LDS window (gfx950 has 160 KiB per CU)
@@ -174,20 +175,19 @@ hipError_t launch_one(const jxs::KParams<T>& P, const unsigned char* mblk, const
   // inertia recursion stays the critical path and the waves of a CU share its LDS and vector-memory pipelines.
   // JXS_DUO_MAX_BLOCKS bounds the grids it is used for.
   if constexpr (MODE == jxs::MODE_STEP && G >= 8) {
-    // (read per launch, not cached: the tests switch it between launches; a replayed hipGraph keeps what it captured)
-    const char* const duo_e = std::getenv("JXS_DUO");
-    const char* const duo_b = std::getenv("JXS_DUO_MAX_BLOCKS");
-    const int duo_env = duo_e == nullptr ? -1 : std::atoi(duo_e);
-    const int duo_max_blocks = duo_b == nullptr ? (1 << 30) : std::atoi(duo_b);
+    const int duo_env = (A.knobs & jxs::KNOB_DUO) ? 1 : 0;
+    const int duo_max_blocks = A.duo_max_blocks > 0 ? A.duo_max_blocks : (1 << 30);
     const bool fits = P.row_mode == 1 && P.rigid == 0 && P.n_chunks <= 1 && duo_lds_bytes<T>(G) <= (size_t)160 * 1024;
     if (fits && duo_env > 0 && blocks <= duo_max_blocks) {
       const size_t bytes = duo_lds_bytes<T>(G);
-      static bool attr_set = false;
-      if (!attr_set) {
+      static bool attr_set[64] = {};  // per device: a function attribute belongs to the device's copy of the kernel
+      int dev = 0;
+      (void)hipGetDevice(&dev);
+      if (dev < 0 || dev >= 64 || !attr_set[dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&jxs_kernel_duo<T, G, MODE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
       }
       hipLaunchKernelGGL((jxs_kernel_duo<T, G, MODE>), dim3((blocks + 1) / 2), dim3(256), bytes, s, A.state_in, A.state_out, mblk, A.tau,
                          A.link_f, A.N, P.n_rows, P.n, A.force_repr, A.n_steps, tail);
@@ -196,7 +196,7 @@ hipError_t launch_one(const jxs::KParams<T>& P, const unsigned char* mblk, const
   }
 #ifndef JXS_SPEC_ASSIGN  // (a model-specialised build has these constants anyway)
   constexpr bool kHasCommon = (MODE == jxs::MODE_STEP || MODE == jxs::MODE_ROLLOUT) && G >= 8;
-  const bool common_off = std::getenv("JXS_DISABLE_COMMON_VARIANT") != nullptr;  // developer knob, read per launch: A/B against KV_GENERIC
+  const bool common_off = (A.knobs & jxs::KNOB_NO_COMMON_VARIANT) != 0;  // developer knob: A/B against KV_GENERIC
   if (kHasCommon && !common_off && P.floating == 1 && P.any_suc == 0 && P.seg_dpp_ok == 1 && P.row_mode == 1 && P.flat == 1 && P.pq_half == 1 &&
       P.anchored == 1 && P.rigid == 0 && P.rk4fast == 0 && P.n_chunks == 1) {
     hipLaunchKernelGGL((jxs_kernel<T, G, MODE, kHasCommon ? KV_COMMON : KV_GENERIC>), dim3(blocks), dim3(64), lds_bytes, s, A.state_in,

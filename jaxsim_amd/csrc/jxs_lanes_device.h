@@ -232,14 +232,17 @@ struct DeviceLanes {
   __device__ __forceinline__ VM all_true() const { return true; }
   // Scheduling fence: everything issued before it (a batch of shuffles) stays before, every
   // consumer after -- the batch is pipelined through the LDS crossbar and waited for once.
-  // A DPP operand reads OTHER lanes, and which of them count as switched off (and read as zero under bound_ctrl) follows
-  // the EXEC mask -- for a few cycles after a scalar instruction changed it, the OLD mask: a DPP instruction right behind
-  // the `s_or_b64 exec` that ends an exec-masked region took zeros from lanes that region had switched off
-  // (RungeKutta4 + RigidContacts kernel of the quadruped: non-deterministic NaNs, gone with five wait states; the
-  // compiler's hazard table only knows the VALU-writes-EXEC case and cannot see inside an asm block anyway).  So: the
-  // DPP blocks that sit in or right behind such a region start with `s_nop 4`, and code that follows an exec-masked
-  // write with DPP arithmetic calls this first.  [round 3]
-  static __device__ __forceinline__ void exec_settle() { asm volatile("s_nop 4"); }
+  // [round 4] An exec-masked LDS write `if (mask) lds_[a] = v` is a message to OTHER lanes, which the compiler cannot
+  // know: it reasons per thread, merges neighbouring `if (mask)` regions, sinks the loads and arithmetic that feed the
+  // store into them and orders everything around them freely.  The RungeKutta4 + RigidContacts kernel of the quadruped
+  // (model-specialised, merged Delassus sweeps of jxs_rigid.inc) returned different bits from call to call that way.
+  // Round 3 cured it with `s_nop 4` behind every masked write and blamed the hardware (a stale EXEC for DPP operands
+  // behind a scalar write of EXEC).  tools/ubench/exec_dpp.hip measured that hazard away (profiles/
+  // r04_exec_dpp_ubench.txt: 0 wrong lanes in 1e9 at 0..6 wait states; only the two documented VALU cases exist), and
+  // an EMPTY volatile asm in the same place gives the same bits as the wait states did (profiles/
+  // r04_masked_lds_write_bisect.md): what cured it was the compiler barrier.  So a masked write ends with one -- no
+  // instruction, no wait state.
+  static __device__ __forceinline__ void lds_publish() { asm volatile("" ::: "memory"); }
 #ifndef JXS_FENCE_MASK  // developer knob: which instruction classes the scheduler may move across fence() (0: none)
 #define JXS_FENCE_MASK 0
 #endif
@@ -409,14 +412,14 @@ struct DeviceLanes {
     static_assert(N == 3 || N == 6 || N == 9, "three, six or nine values");
 #define JXS_RS(i, j) "v_fmac_f32_dpp %" #i ", %" #j ", %[m] row_shl:%[off] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
     if constexpr (N == 3)
-      asm volatile("s_nop 4\n\t" JXS_RS(0, 3) JXS_RS(1, 4) JXS_RS(2, 5)
+      asm volatile("s_nop 1\n\t" JXS_RS(0, 3) JXS_RS(1, 4) JXS_RS(2, 5)
                    : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]) : "v"(x[0]), "v"(x[1]), "v"(x[2]), [m] "v"(m), [off] "n"(OFF));
     else if constexpr (N == 6)
-      asm volatile("s_nop 4\n\t" JXS_RS(0, 6) JXS_RS(1, 7) JXS_RS(2, 8) JXS_RS(3, 9) JXS_RS(4, 10) JXS_RS(5, 11)
+      asm volatile("s_nop 1\n\t" JXS_RS(0, 6) JXS_RS(1, 7) JXS_RS(2, 8) JXS_RS(3, 9) JXS_RS(4, 10) JXS_RS(5, 11)
                    : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5])
                    : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), [m] "v"(m), [off] "n"(OFF));
     else
-      asm volatile("s_nop 4\n\t" JXS_RS(0, 9) JXS_RS(1, 10) JXS_RS(2, 11) JXS_RS(3, 12) JXS_RS(4, 13) JXS_RS(5, 14) JXS_RS(6, 15)
+      asm volatile("s_nop 1\n\t" JXS_RS(0, 9) JXS_RS(1, 10) JXS_RS(2, 11) JXS_RS(3, 12) JXS_RS(4, 13) JXS_RS(5, 14) JXS_RS(6, 15)
                    JXS_RS(7, 16) JXS_RS(8, 17)
                    : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8])
                    : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]), "v"(x[8]), [m] "v"(m),
@@ -448,13 +451,12 @@ struct DeviceLanes {
   // acc[k] += x[k](lane+1) * m for 9 values: nine v_fmac_f32_dpp in one asm block.  hipcc does not
   // fuse mov_dpp + fma itself; inside an asm block it does not see the "VALU write -> DPP read"
   // hazard either, hence the leading s_nop 1 (2 wait states) -- operands are not rewritten inside.
-  // (the block starts with s_nop 4: it sits right behind the scalar instruction that switched lanes off -- exec_settle)
   // `active`: the lanes that take part -- a lane that does not is not written, and reads as 0 from its neighbour
   // (bound_ctrl).  The callers switch the LAST lane of every environment off: its lane + 1 is the base link of the
   // NEXT environment, and 0 x (a non-finite value of a diverged neighbour) is not 0.
   __device__ __forceinline__ void fmac9_from_next(float* a, const float* x, float m, bool active) const {
     if (active) asm volatile(
-        "s_nop 4\n\t"
+        "s_nop 1\n\t"
         "v_fmac_f32_dpp %0, %9, %18 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
         "v_fmac_f32_dpp %1, %10, %18 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
         "v_fmac_f32_dpp %2, %11, %18 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
@@ -470,7 +472,7 @@ struct DeviceLanes {
   // six values (a spatial force): the sweeps of the rigid contact models hand the first child's share to its parent
   __device__ __forceinline__ void fmac6_from_next(float* a, const float* x, float m, bool active) const {
     if (active) asm volatile(
-        "s_nop 4\n\t"
+        "s_nop 1\n\t"
         "v_fmac_f32_dpp %0, %6, %12 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
         "v_fmac_f32_dpp %1, %7, %12 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
         "v_fmac_f32_dpp %2, %8, %12 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
@@ -726,7 +728,7 @@ struct DeviceLanes {
   __device__ __forceinline__ void lds_write(int addr, T v) const { lds_[addr] = v; }
   __device__ __forceinline__ void lds_write(int addr, T v, bool mask) const {
     if (mask) lds_[addr] = v;
-    exec_settle();  // (an exec-masked region ends here; DPP arithmetic may follow closely)
+    lds_publish();
   }
   __device__ __forceinline__ V lds_read(int addr) const { return lds_[addr]; }
   // N consecutive words with 128-bit LDS instructions; `addr` is a multiple of 16 bytes (4 floats / 2 doubles).
@@ -755,7 +757,7 @@ struct DeviceLanes {
   template <int N>
   __device__ __forceinline__ void lds_writev_if(int addr, const T* v, bool mask) const {
     if (mask) lds_writev<N>(addr, v);
-    exec_settle();
+    lds_publish();
   }
   template <int N>
   __device__ __forceinline__ void lds_readv(int addr, T* v) const {

@@ -274,6 +274,7 @@ struct KParams {
 };
 
 // Device/host pointers handed to the core for one launch.
+enum Knob : int { KNOB_NO_MFMA = 1, KNOB_DUO = 2, KNOB_NO_COMMON_VARIANT = 4 };
 template <typename T>
 struct KArgs {
   const T* ltf;        // [G][kLtfStride]
@@ -297,6 +298,9 @@ struct KArgs {
   int* faults;         // [2] environments whose QP contact-force solve / impact solve was discarded (non-finite), or null
   int flags;           // developer switches of a launch: bit 0 = no MFMA in the contact solvers' Cholesky (A/B against the vector path)
   int spec_consts;     // 1: the integer model flags of KParams are compile-time constants in this kernel (jxs_spec.hip)
+  int knobs;           // host only: developer knobs of the launcher (KNOB_*), read from the environment ONCE by the
+                       // library (jxs_api.hip debug_knobs; jxs_debug_reload_env re-reads them for the tests)
+  int duo_max_blocks;  // host only: largest grid the two-wave variant is used for (JXS_DUO_MAX_BLOCKS)
   int has_lds;         // the launch has the per-environment LDS area of the row layout (known when the wave starts: a
                        // compile-time constant in the specialised / common-feature kernels): the thirteen
                        // environment-uniform rows of the state are fetched by ONE load instruction and spread through it

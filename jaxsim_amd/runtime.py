@@ -269,16 +269,19 @@ class DeviceModel:
 
 def device_model(model, dtype) -> DeviceModel:
     """Device tables of ``model`` for ``dtype``; rebuilt when a model constant changed."""
-    sig = _lib.model_signature(model, dtype)
+    from . import specialize  # model-specialised step kernel: a cached object, or built now if asked for
+
+    # (the kernel policy is part of the key: a process that changes JAXSIM_AMD_SPECIALIZE gets the kernels it asked for)
+    sig = (_lib.model_signature(model, dtype), specialize.policy())
     cache = model.__dict__.setdefault("_device", {})
     hit = cache.get(np.dtype(dtype).str)
     if hit is not None and hit[0] == sig:
         return hit[1]
     dm = DeviceModel(model, dtype)
-    from . import specialize  # model-specialised step kernel: a cached object, or built now if asked for
-
     how = specialize.policy()
-    if how != "off":
+    if how == "require":
+        specialize.attach(dm, model, require=True)  # (raises: the suite's specialised pass must not fall back silently)
+    elif how != "off":
         try:
             specialize.attach(dm, model, build=(how == "build"))
         except (RuntimeError, OSError) as exc:  # no hipcc / failed build: the generic kernel of the library runs

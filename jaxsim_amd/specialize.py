@@ -41,15 +41,26 @@ _FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fv
           "-mllvm", "-amdgpu-kernarg-preload-count=16", "-Wno-cuda-compat", "-Wno-pass-failed", "-Djxs_launch=jxs_launch_spec"]  # fmt: skip
 
 
-@functools.lru_cache(maxsize=1)
-def source_sha() -> str:
-    """Hash of the kernel sources a specialised object is compiled from (once per process)."""
+def _src_dir() -> pathlib.Path:
+    """The directory the kernel sources are compiled from: csrc/, or the developer override (tools/gpu/*.sh A/B runs)."""
+    return pathlib.Path(os.environ.get("JAXSIM_AMD_SPEC_CSRC") or _CSRC)
+
+
+@functools.lru_cache(maxsize=4)
+def _source_sha_of(directory: str) -> str:
     h = hashlib.sha256()
-    for name in sorted(os.listdir(_CSRC)):
+    d = pathlib.Path(directory)
+    for name in sorted(os.listdir(d)):
         if name.endswith((".h", ".inc")) or name == "jxs_spec.hip":
-            h.update(name.encode() + b"\0" + (_CSRC / name).read_bytes())
+            h.update(name.encode() + b"\0" + (d / name).read_bytes())
     h.update((pathlib.Path(__file__).resolve().parent.parent / "include" / "jaxsim_amd.h").read_bytes())
     return h.hexdigest()[:16]
+
+
+def source_sha() -> str:
+    """Hash of the kernel sources a specialised object is compiled from -- of the directory that is actually
+    compiled (once per process and directory)."""
+    return _source_sha_of(str(_src_dir()))
 
 
 MODE_ROLLOUT, MODE_STEP_RK4, MODE_STEP_RK4_RIGID = 4, 5, 7
@@ -85,34 +96,72 @@ def _flags() -> list[str]:
 
 
 def path_of(text: str) -> pathlib.Path:
-    key = hashlib.sha256((text + "|" + source_sha() + "|" + " ".join(_flags()) + os.environ.get("JAXSIM_AMD_SPEC_CSRC", "")).encode()).hexdigest()[:20]
+    key = hashlib.sha256((text + "|" + source_sha() + "|" + " ".join(_flags())).encode()).hexdigest()[:20]
     return CACHE / f"libjxs_spec_{key}.so"
 
 
+def _record(text: str) -> None:
+    """``JAXSIM_AMD_SPEC_RECORD=<file>``: append the description of every kernel a process asks for (hit or miss).
+    tests/spec_manifest.txt is such a record of the GPU suite; ``__graft_entry__.build()`` pre-builds it."""
+    path = os.environ.get("JAXSIM_AMD_SPEC_RECORD")
+    if path:
+        with open(path, "a") as f:
+            f.write(text + "\n")
+
+
 def cached(model, dtype, mode: int = MODE_STEP) -> pathlib.Path | None:
-    p = path_of(spec(model, dtype, mode))
+    text = spec(model, dtype, mode)
+    _record(text)
+    p = path_of(text)
     return p if p.exists() else None
 
 
 def compile(model, dtype, mode: int = MODE_STEP, *, force: bool = False) -> pathlib.Path:  # noqa: A001
     """Build (or find) the specialised kernel object; needs hipcc, not a GPU."""
-    text = spec(model, dtype, mode)
+    return compile_text(spec(model, dtype, mode), force=force)
+
+
+def compile_text(text: str, *, force: bool = False) -> pathlib.Path:
+    """``compile`` from the description alone (``spec``): everything the build needs is in the text."""
     out = path_of(text)
     if out.exists() and not force:
         return out
     head, assign = text.rsplit(";", 1)
     fields = dict(kv.split("=") for kv in head.split(";"))
     CACHE.mkdir(exist_ok=True)
+    # one builder per object: the ranks of a multi-process run (and the threads of attach()) that miss the same object
+    # queue on its lock file; whoever gets it second finds the object built and returns it
+    import fcntl
+
+    with open(out.with_suffix(".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if out.exists() and not force:
+                return out
+            return _compile_locked(text, fields, assign, out)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _compile_locked(text: str, fields: dict, assign: str, out: pathlib.Path) -> pathlib.Path:
     tmp = out.with_suffix(f".tmp{os.getpid()}.so")
     cmd = [_HIPCC, *_flags(), f"-DJXS_SPEC_T={fields['T']}", f"-DJXS_SPEC_G={fields['G']}", f"-DJXS_SPEC_MODE={fields['MODE']}",
            f"-DJXS_SPEC_ASSIGN={assign}", f'-DJXS_SPEC_STRING="{text}"', "jxs_spec.hip", "-o", str(tmp)]  # fmt: skip
-    # developer aid (tools/gpu/*.sh): compile the kernel sources of another directory -- a copy of an earlier csrc/ with the
-    # same parameter block -- against this library, for A/B timings on one box
-    src = os.environ.get("JAXSIM_AMD_SPEC_CSRC") or _CSRC
-    r = subprocess.run(cmd, cwd=src, capture_output=True, text=True)
+    # (JAXSIM_AMD_SPEC_CSRC, developer aid of tools/gpu/*.sh: the kernel sources of another directory -- a copy of an earlier
+    # csrc/ with the same parameter block -- compiled against this library, for A/B runs on one box)
+    r = subprocess.run(cmd, cwd=_src_dir(), capture_output=True, text=True)
     if r.returncode != 0:
         tmp.unlink(missing_ok=True)
         raise RuntimeError(f"hipcc failed for the specialised kernel ({text}):\n{r.stderr[-4000:]}")
+    # [round 4] wait-state lint of the object (isa_lint.py): a hazard inside a hand-written DPP block fails the build
+    # here, before any launch could run it (the library's own kernels are linted by csrc/build.sh)
+    try:
+        from . import isa_lint
+
+        isa_lint.check(str(tmp))
+    except RuntimeError:
+        tmp.unlink(missing_ok=True)
+        raise
     os.replace(tmp, out)  # atomic: concurrent ranks may build the same object
     return out
 
@@ -121,7 +170,7 @@ def compile(model, dtype, mode: int = MODE_STEP, *, force: bool = False) -> path
 QUERY_MODES = (1, 2, 3, 8, 9, 10, 11)
 
 
-def attach(dm, model, mode: int | None = None, *, build: bool = False) -> bool:
+def attach(dm, model, mode: int | None = None, *, build: bool = False, require: bool = False) -> bool:
     """Attach the specialised kernels of the model (all modes of ``modes_of``, or one ``mode``) to the device
     model ``dm``.  Without ``build`` only objects found in the cache are used; with it the missing ones are
     compiled now, concurrently (one hipcc process per mode).  True if any was attached."""
@@ -129,15 +178,33 @@ def attach(dm, model, mode: int | None = None, *, build: bool = False) -> bool:
     todo = modes_of(model) if mode is None else ([mode] if isinstance(mode, int) else list(mode))
     paths: dict[int, pathlib.Path | None] = {m: cached(model, dm.dtype, m) for m in todo}
     missing = [m for m in todo if paths[m] is None]
+    if require and missing and not build:
+        raise _lib.JaxsimAmdError("JAXSIM_AMD_SPECIALIZE=require: no pre-built model-specialised kernel for " +
+                                  "; ".join(spec(model, dm.dtype, m) for m in missing))
     if build and missing:
-        if len(missing) == 1:
-            paths[missing[0]] = compile(model, dm.dtype, missing[0])
-        else:
-            from concurrent.futures import ThreadPoolExecutor
+        # one hipcc process per missing mode; a mode whose build fails falls back to the library's own kernel ALONE
+        # (the objects that did build are attached), and the failure is reported once all are done
+        from concurrent.futures import ThreadPoolExecutor
 
-            with ThreadPoolExecutor(len(missing)) as ex:
-                for m, p in zip(missing, ex.map(lambda mm: compile(model, dm.dtype, mm), missing)):
-                    paths[m] = p
+        def one(mm):
+            try:
+                return compile(model, dm.dtype, mm), None
+            except (RuntimeError, OSError) as exc:
+                return None, exc
+
+        with ThreadPoolExecutor(len(missing)) as ex:
+            results = list(ex.map(one, missing))
+        failed = []
+        for m, (p, exc) in zip(missing, results):
+            paths[m] = p
+            if exc is not None:
+                failed.append((m, exc))
+        if failed and len(failed) == len(missing) and all(paths[m] is None for m in todo):
+            raise failed[0][1]
+        for m, exc in failed:
+            import warnings
+
+            warnings.warn(f"jaxsim_amd: no model-specialised kernel for mode {m} ({exc}); using the generic one", RuntimeWarning, stacklevel=2)
     done = False
     for m in todo:
         p = paths[m]
@@ -162,6 +229,8 @@ def ensure_mode(dm, model, mode: int) -> bool:
     how = policy()
     if how == "off":
         return False
+    if how == "require":
+        return attach(dm, model, mode, require=True)
     try:
         return attach(dm, model, mode, build=(how == "build"))
     except (RuntimeError, OSError) as exc:
@@ -196,6 +265,8 @@ def policy() -> str:
         return "build"
     if v == "cached":
         return "cached"
+    if v == "require":  # the test-suite's specialised pass: like 'cached', but a missing object is an error, not a fallback
+        return "require"
     return "build" if hipcc_available() else "cached"
 
 

@@ -11,11 +11,29 @@ for p in (str(ROOT), str(ROOT / "tests")):
 
 
 # The product's default is to compile a model-specialised kernel on first use when hipcc is present
-# (jaxsim_amd/specialize.py::policy -- the jax.jit experience).  The suite pins 'cached': the zoo models whose objects
-# __graft_entry__.build() pre-built run specialised, every other model runs the library's own kernels, no test waits
-# ~20 s per new model for a compiler, and a kernel never changes between two calls a test compares bitwise.
-# tests/test_specialize.py covers build-on-first-use explicitly.
+# (jaxsim_amd/specialize.py::policy -- the jax.jit experience).  [round 4] Every `gpu` test runs TWICE (fixture
+# `kernel_policy` below): once through the library's own ahead-of-time kernels (JAXSIM_AMD_SPECIALIZE=0) and once through
+# the model-specialised kernel of its model (JAXSIM_AMD_SPECIALIZE=require: the object must have been pre-built -- a
+# missing one is an error, never a silent fallback).  __graft_entry__.build() pre-builds every kernel description listed
+# in tests/spec_manifest.txt, which is a record of this suite (JAXSIM_AMD_TEST_RECORD=1 JAXSIM_AMD_SPEC_RECORD=<file>
+# python -m pytest tests -m gpu, on the GPU box; tools/gpu/r04_record_manifest.sh).  No test waits for a compiler, and a
+# kernel never changes between two calls a test compares bitwise.  Outside the fixture (CPU tests) 'cached' is pinned.
 os.environ.setdefault("JAXSIM_AMD_SPECIALIZE", "cached")
+KERNEL_POLICIES = {"library": "0", "specialised": "cached" if os.environ.get("JAXSIM_AMD_TEST_RECORD") else "require"}
+
+
+def pytest_generate_tests(metafunc):
+    # tests/test_specialize.py chooses the policy itself, test by test
+    if metafunc.definition.get_closest_marker("gpu") and metafunc.module.__name__ != "test_specialize":
+        metafunc.parametrize("kernel_policy", list(KERNEL_POLICIES), indirect=True)
+
+
+@pytest.fixture(autouse=True)
+def kernel_policy(request, monkeypatch):
+    which = getattr(request, "param", None)
+    if which is not None:
+        monkeypatch.setenv("JAXSIM_AMD_SPECIALIZE", KERNEL_POLICIES[which])
+    return which
 
 
 def pytest_configure(config):
@@ -47,6 +65,33 @@ def pytest_collection_modifyitems(config, items):
     for it in items:
         if "gpu" in it.keywords:
             it.add_marker(skip)
+
+
+@pytest.fixture()
+def knobs():
+    """Developer knobs of the launcher (JXS_DUO, JXS_NO_MFMA, JXS_DISABLE_COMMON_VARIANT ...): the library reads the
+    environment once per process (csrc/jxs_api.hip debug_knobs), so a test that switches kernel variants between
+    launches sets them through this fixture, which tells the library to read them again -- now and when the test ends."""
+    from jaxsim_amd import _lib
+
+    saved = {}
+
+    def set_knob(name, value):
+        saved.setdefault(name, os.environ.get(name))
+        if value is None:
+            os.environ.pop(name, None)
+        else:
+            os.environ[name] = str(value)
+        _lib.check(_lib.load().jxs_debug_reload_env(), "jxs_debug_reload_env")
+
+    yield set_knob
+    for name, value in saved.items():
+        if value is None:
+            os.environ.pop(name, None)
+        else:
+            os.environ[name] = value
+    if saved:
+        _lib.check(_lib.load().jxs_debug_reload_env(), "jxs_debug_reload_env")
 
 
 @pytest.fixture(scope="session")

@@ -150,7 +150,7 @@ struct HostLanes {
   // (the MFMA tiles of the contact solvers' Cholesky exist on the device only: the emulation runs the vector path,
   // which performs the same fused multiply-adds in the same order)
   static constexpr bool kHasMfma = false;
-  static void exec_settle() {}
+  static void lds_publish() {}
   static constexpr bool kHasRowShl = false;  // (the emulation gathers children through shfl: same values)
   template <int N>
   void fmac_row_shl(V*, const V*, const V&, int) const {}

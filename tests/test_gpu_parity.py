@@ -178,7 +178,7 @@ def test_data_build_and_properties(models):
 @pytest.mark.parametrize("name", ["icub", "anymal", "cartpole", "double_pendulum"])
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("kernels", ["common_variant", "run_time_flags"])
-def test_step_matches_oracle_through_the_librarys_own_kernels(models, name, dtype, kernels, monkeypatch):
+def test_step_matches_oracle_through_the_librarys_own_kernels(models, name, dtype, kernels, monkeypatch, knobs):
     """[ADVICE r2] The zoo models above have pre-built model-specialised kernels, so every other step test runs those.
     Here the same step goes through what a model WITHOUT a specialised object gets: the ahead-of-time common-feature
     variant (`KV_COMMON`, floating-base soft-contact models in the row layout) and the kernel that reads every flag at
@@ -188,7 +188,7 @@ def test_step_matches_oracle_through_the_librarys_own_kernels(models, name, dtyp
     model = models(name)
     monkeypatch.setenv("JAXSIM_AMD_SPECIALIZE", "0")
     if kernels == "run_time_flags":
-        monkeypatch.setenv("JXS_DISABLE_COMMON_VARIANT", "1")
+        knobs("JXS_DISABLE_COMMON_VARIANT", 1)
     model.__dict__.pop("_device", None)
     try:
         N = 70
@@ -325,19 +325,19 @@ def test_plane_terrain_gpu(models, dtype):
     assert helpers.rel_err(out.state_block(), helpers.odata_to_block(model, ref)) < helpers.tol_of(dtype)
 
 
-def test_fused_rollout_equals_repeated_steps_gpu(models, monkeypatch):
+def test_fused_rollout_equals_repeated_steps_gpu(models, knobs):
     model = models("icub")
     d = models.random_data("icub", 64, seed=14, dtype=np.float32)
     g = to_gpu(model, d)
     fused = js.model.rollout(model, g, 9).state_block()
     # bitwise against the single-wave step kernel (the fused rollout is its loop)
-    monkeypatch.setenv("JXS_DUO", "0")
+    knobs("JXS_DUO", 0)
     g1 = g
     for _ in range(9):
         g1 = js.model.step(model, g1)
     np.testing.assert_array_equal(fused, g1.state_block())
     # the opt-in two-wave variant forms the bias force from the handed-over rows of Ma in another order: rounding only
-    monkeypatch.setenv("JXS_DUO", "1")
+    knobs("JXS_DUO", 1)
     for _ in range(9):
         g = js.model.step(model, g)
     assert helpers.rel_err(fused, g.state_block()) < 2e-3  # nine steps of a contact-rich fp32 trajectory
@@ -353,7 +353,7 @@ def test_fused_rollout_equals_repeated_steps_gpu(models, monkeypatch):
 
 @pytest.mark.parametrize("name", ["anymal", "icub", "icub16"])
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
-def test_two_wave_step_matches_oracle_and_single_wave_gpu(models, name, dtype, monkeypatch):
+def test_two_wave_step_matches_oracle_and_single_wave_gpu(models, name, dtype, knobs):
     """The opt-in two-wave workgroup variant of the step kernel (JXS_DUO=1; jxs_core.h run_inertia + run<MODE_STEP,
     ROLE_MAIN>): against the oracle within the stated tolerance, against the single-wave kernel to rounding, for a
     ragged batch (an odd number of tiles: the second pair of the last workgroup is empty)."""
@@ -362,9 +362,9 @@ def test_two_wave_step_matches_oracle_and_single_wave_gpu(models, name, dtype, m
     d = models.random_data(name, N, seed=4, dtype=dtype)
     tau, f = helpers.random_inputs(model, N, 5, dtype)
     ref = oracle.step(model, helpers.upcast(d), link_forces=f.astype(np.float64), joint_force_references=tau.astype(np.float64))
-    monkeypatch.setenv("JXS_DUO", "0")
+    knobs("JXS_DUO", 0)
     solo = js.model.step(model, to_gpu(model, d), link_forces=f, joint_force_references=tau).state_block()
-    monkeypatch.setenv("JXS_DUO", "1")
+    knobs("JXS_DUO", 1)
     duo = js.model.step(model, to_gpu(model, d), link_forces=f, joint_force_references=tau).state_block()
     assert helpers.rel_err(duo, helpers.odata_to_block(model, ref)) < helpers.tol_of(dtype, name)
     # (fp32: other contraction choices in two instruction streams; measured 4e-5 on the humanoid's contact-rich states)
@@ -565,7 +565,7 @@ def test_rk4fast_step_matches_oracle_gpu(models, reduced_qp, kind, key):
 
 
 @pytest.mark.parametrize("kind,key", [("rigid", "anymal16"), ("relaxed", "icub16")])
-def test_mfma_cholesky_equals_the_vector_path_bitwise_gpu(models, kind, key, monkeypatch):
+def test_mfma_cholesky_equals_the_vector_path_bitwise_gpu(models, kind, key, monkeypatch, knobs):
     """[round 3] The blocked Cholesky of the contact solvers with its trailing updates on the matrix cores
     (v_mfma_f32_16x16x4_f32 accumulator tiles, jxs_lanes_device.h ChTiles) -- an opt-in build (-DJXS_MFMA_CHOLESKY,
     measured slower end to end, profiles/r03_mfma_cholesky_experiment.md), here as a model-specialised kernel built
@@ -594,7 +594,7 @@ def test_mfma_cholesky_equals_the_vector_path_bitwise_gpu(models, kind, key, mon
     try:
         assert specialize.modes(runtime.device_model(model, np.float32)) == [specialize.MODE_STEP_RIGID]
         tiles = [run(d) for d in datas]
-        monkeypatch.setenv("JXS_NO_MFMA", "1")
+        knobs("JXS_NO_MFMA", 1)
         vector = [run(d) for d in datas]
     finally:
         model.__dict__.pop("_device", None)

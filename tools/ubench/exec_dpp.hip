@@ -37,9 +37,14 @@ struct Res {
   unsigned first_lane, first_got, first_want, pad;
 };
 
+// one atomic per WAVE (contended per-lane atomics on one address made the first version of this program crawl)
 __device__ __forceinline__ void report(Res* r, unsigned nbad, unsigned lane, unsigned got, unsigned want, bool isbad) {
-  if (nbad) atomicAdd(&r->bad, (unsigned long long)nbad);
-  if (isbad && atomicCAS(&r->pad, 0u, 1u) == 0u) r->first_lane = lane, r->first_got = got, r->first_want = want;
+  unsigned tot = nbad;
+  for (int off = 32; off; off >>= 1) tot += __shfl_xor(tot, off);
+  const unsigned long long bad_lanes = __ballot(isbad);
+  if (tot && lane == 0) atomicAdd(&r->bad, (unsigned long long)tot);
+  if (bad_lanes && lane == (unsigned)__ffsll((long long)bad_lanes) - 1u && atomicCAS(&r->pad, 0u, 1u) == 0u)
+    r->first_lane = lane, r->first_got = got, r->first_want = want;
 }
 
 // Every test: `want` is computed on the host-visible rule "source lane switched off or beyond the wave -> 0 (bound_ctrl),
@@ -119,14 +124,15 @@ __device__ __forceinline__ void report(Res* r, unsigned nbad, unsigned lane, uns
   /* T6: exec-masked LDS write, region ends (s_or_b64 exec), -> k -> DPP */                                              \
   __global__ void t6_##k(Res* res, int iters) {                                                                         \
     __shared__ unsigned lds[256];                                                                                       \
+    lds[threadIdx.x & 255] = 0;                                                                                         \
     PROLOGUE                                                                                                            \
     const unsigned addr = (threadIdx.x & 255) * 4u;                                                                     \
     asm volatile("s_mov_b64 %[save], exec\n\ts_mov_b64 exec, %[m]\n\t" SETTLE "ds_write_b32 %[addr], %[v]\n\t"          \
                  "s_or_b64 exec, exec, %[save]\n\t" NOPS_##k DPP_SHL SETTLE "s_waitcnt lgkmcnt(0)\n\t"                  \
                  : [out] "+v"(out), [save] "=&s"(save), FOPS : [v] "v"(v), [m] "s"(M), [addr] "v"(addr) : "memory");   \
-    if (lds[0] == 0x12345u) res->pad = 9;                                                                               \
     const unsigned want = lane == 63 ? 0u : v + 1u;                                                                     \
     EPILOGUE                                                                                                            \
+    if (lds[(threadIdx.x + 1) & 255] == 0x12345u) res->pad = 9;                                                                                                           \
   }                                                                                                                     \
   /* T7: the DPP source is written by a VALU inside the masked region; s_or_b64 exec (1 state) -> k -> DPP.           \
      Even lanes hold the new value, odd lanes the old one; needs 2 states in total if the scalar counts as one. */      \
@@ -138,6 +144,28 @@ __device__ __forceinline__ void report(Res* r, unsigned nbad, unsigned lane, uns
                  "v_mov_b32_dpp %[out], %[x] wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" SETTLE             \
                  : [out] "+v"(out), [save] "=&s"(save), [x] "+v"(x), FOPS : [v] "v"(v), [m] "s"(M));                  \
     const unsigned want = lane == 63 ? 0u : ((lane & 1) ? v + 1u : (0x22220000u | (lane + 1)));                         \
+    EPILOGUE                                                                                                            \
+  }                                                                                                                     \
+  /* T10 (control c): VALU writes the NON-shuffled operand (src1) of a DPP instruction -> k -> DPP.  LLVM pads 2. */      \
+  __global__ void t10_##k(Res* res, int iters) {                                                                        \
+    PROLOGUE                                                                                                            \
+    unsigned x = 0x33330000u | lane;                                                                                    \
+    asm volatile(FILL "v_mov_b32 %[x], %[v]\n\t" NOPS_##k "v_add_u32_dpp %[out], %[v], %[x] wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" SETTLE \
+                 : [out] "+v"(out), [x] "+v"(x), FOPS : [v] "v"(v));                                                   \
+    save = 0;                                                                                                           \
+    const unsigned want = lane == 63 ? v : v + 1u + v;                                                                  \
+    EPILOGUE                                                                                                            \
+  }                                                                                                                     \
+  /* T11 (control d): VALU writes the ACCUMULATOR of v_fmac_f32_dpp (a plain operand too) -> k -> DPP */                \
+  __global__ void t11_##k(Res* res, int iters) {                                                                        \
+    PROLOGUE                                                                                                            \
+    float acc = 0.5f;                                                                                                   \
+    const float vf = (float)(lane + 1), one = 1.0f, base = (float)((it & 255) + 3);                                      \
+    asm volatile(FILL "v_mov_b32 %[acc], %[base]\n\t" NOPS_##k "v_fmac_f32_dpp %[acc], %[vf], %[one] wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" SETTLE \
+                 : [acc] "+v"(acc), FOPS : [vf] "v"(vf), [one] "v"(one), [base] "v"(base));                            \
+    save = 0;                                                                                                           \
+    out = __float_as_uint(acc);                                                                                         \
+    const unsigned want = __float_as_uint(base + (lane == 63 ? 0.0f : (float)(lane + 2)));                              \
     EPILOGUE                                                                                                            \
   }                                                                                                                     \
   /* T8: T1 with row_shl:1 (16-lane rows) */                                                                            \
@@ -169,16 +197,19 @@ KERNELS(6)
 
 typedef void (*Kern)(Res*, int);
 #define ROW(t) {t##_0, t##_1, t##_2, t##_3, t##_4, t##_5, t##_6}
-static Kern table[9][7] = {ROW(t1), ROW(t2), ROW(t3), ROW(t4), ROW(t5), ROW(t6), ROW(t7), ROW(t8), ROW(t9)};
-static const char* names[9] = {
+static Kern table[11][7] = {ROW(t1), ROW(t2), ROW(t3), ROW(t4), ROW(t5), ROW(t6), ROW(t7), ROW(t8), ROW(t9), ROW(t10), ROW(t11)};
+static const char* names[11] = {
     "T1 s_mov_b64 exec (lanes off)          -> DPP wave_shl", "T2 s_or_b64 exec (lanes on)            -> DPP wave_shl",
     "T3 s_or_b64 ; s_and_saveexec_b64       -> DPP wave_shl", "T4 CONTROL v_cmpx writes EXEC (doc: 5) -> DPP wave_shl",
     "T5 CONTROL v_mov writes source (doc: 2)-> DPP wave_shl", "T6 masked ds_write ; s_or_b64 exec     -> DPP wave_shl",
     "T7 masked v_mov of source ; s_or exec  -> DPP wave_shl", "T8 s_and_b64 exec (lanes off)          -> DPP row_shl ",
-    "T9 s_mov_b64 exec (lanes on)           -> DPP quad_perm"};
+    "T9 s_mov_b64 exec (lanes on)           -> DPP quad_perm",
+    "T10 CONTROL v_mov writes src1 (LLVM: 2)-> DPP wave_shl",
+    "T11 CONTROL v_mov writes fmac's acc    -> DPP wave_shl"};
 
 int main(int argc, char** argv) {
   const int iters = argc > 1 ? atoi(argv[1]) : 4096;
+  setvbuf(stdout, nullptr, _IONBF, 0);
   Res* d;
   hipMalloc(&d, sizeof(Res));
   // waves per SIMD ~ blocks / 1024 for one-wave blocks on 256 CUs x 4 SIMDs; 256-thread blocks put 4 waves on a CU at once
@@ -186,7 +217,7 @@ int main(int argc, char** argv) {
   for (const Geo& g : geos) {
     printf("== %s, %d iterations per lane (%.2e DPP results per cell) ==\n", g.what, iters, (double)g.blocks * g.threads * iters);
     printf("%-56s %10s %10s %10s %10s %10s %10s %10s\n", "wrong lanes at k wait states:", "k=0", "k=1", "k=2", "k=3", "k=4", "k=5", "k=6");
-    for (int t = 0; t < 9; ++t) {
+    for (int t = 0; t < 11; ++t) {
       printf("%-56s", names[t]);
       Res firsts[7];
       for (int k = 0; k < 7; ++k) {
