@@ -222,7 +222,11 @@ std::string pack_model(const jxs_model_desc& d, Packed<T>& out) {
   std::vector<int> subtree(nL, 1);
   for (int i = nL - 1; i >= 1; --i) subtree[d.parent[i]] += subtree[i];  // BFS indices: children after parents
   P.child_off = 0;
-  if (std::getenv("JXS_DISABLE_CHILD_DPP") == nullptr)  // developer knob: A/B
+  // The DPP child gather (jxs_core.h pass 2, jxs_rigid.inc response) masks by MULTIPLICATION: acc += okf * x@(lane + off),
+  // and a lane with okf = 0 still reads lane + off.  Inside a lane group of >= 16 lanes that lane belongs to the same
+  // environment or lies beyond the 16-lane DPP row (bound_ctrl: 0); with G = 4 or 8 one row holds several environments
+  // and 0 x (non-finite value of a diverged NEIGHBOUR) would not be 0 -- those groups keep the shuffle.  [ADVICE r3]
+  if (G >= 16 && std::getenv("JXS_DISABLE_CHILD_DPP") == nullptr)  // (the environment variable: developer knob, A/B)
     for (int k = 1; k <= 5; ++k) {
       int off = -1;
       for (int i = 0; i < nL; ++i) {

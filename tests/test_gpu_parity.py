@@ -1393,7 +1393,7 @@ def test_discarded_rigid_solves_are_counted_gpu(models):
         os.environ.pop("JAXSIM_ENABLE_EXCEPTIONS")
 
 
-ISOLATION_CASES = ["cartpole", "chain5", "chain9f", "anymal", "icub", "icub16", "anymal_rigid4", "anymal_relaxed4", "icub_relaxed16"]
+ISOLATION_CASES = ["cartpole", "chain5", "chain9f", "anymal", "icub", "icub16", "anymal_rigid4", "anymal_relaxed4", "icub_relaxed16", "tree3_rigid2"]
 
 
 @pytest.mark.gpu
@@ -1410,10 +1410,21 @@ def test_a_non_finite_environment_does_not_touch_its_neighbours(models, case, dt
         name, model = "anymal", helpers.relaxed_model(models("anymal"), helpers.ANYMAL_FEET_4)
     elif case == "icub_relaxed16":
         name, model = "icub", helpers.relaxed_model(models("icub"), list(range(16)))
+    elif case == "tree3_rigid2":
+        # [ADVICE r3] a base with two children in a FOUR-lane group (sixteen environments share a DPP row): the DPP child
+        # gather masks by multiplication and must not be used there (jxs_pack.h child_off)
+        from jaxsim_amd import robots
+
+        name = None
+        model = helpers.rigid_model(ja.JaxSimModel.build_from_model_description(robots.chain_urdf(3, fixed_base=False, seed=20, max_back=2)), [0, 9], K=1e4, D=2e2)
+        assert list(np.asarray(model.kin_dyn_parameters.parent_array)) == [-1, 0, 0]
     else:
         name, model = case, models(case)
     N = 24
-    d = models.random_data(name, N, seed=11, dtype=dtype)
+    if name is None:
+        d = oracle.random_model_data(model, batch_size=N, seed=11, dtype=dtype, base_pos_bounds=((-1, -1, 0.0), (1, 1, 0.3)), base_rpy_bounds=((-0.3, -0.3, -3), (0.3, 0.3, 3)))
+    else:
+        d = models.random_data(name, N, seed=11, dtype=dtype)
     blk = helpers.odata_to_block(model, d)
     clean = js.model.step(model, js.data.JaxSimModelData.from_state_block(model, blk.copy())).state_block()
     assert np.isfinite(clean).all()
