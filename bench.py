@@ -82,6 +82,45 @@ def profiled_config5_traffic():
     return None, "no PMC profile committed"
 
 
+SHADER_CLOCK_GHZ = 2.4   # MI355X peak engine clock (MI355X_MICROARCH.md); 157.3 TFLOP/s fp32 = 1024 SIMDs x 32 lanes x 2 flop x 2.4 GHz
+N_SIMDS = 1024            # 256 CUs x 4
+VALU_ISSUE_CYCLES = 2.0   # a wave64 fp32 instruction occupies a SIMD for two cycles at that peak
+
+
+def kernel_valu_count(dm, mode=0):
+    """Static VALU instruction count of the step kernel a device model launches (the model-specialised object that is
+    attached, disassembled with llvm-objdump; None when there is none or the tool is missing).  The kernel is almost
+    straight-line code, so this is the instruction count of one wave to a few per cent."""
+    try:
+        from jaxsim_amd import isa_lint, specialize
+
+        name = specialize.attached_files(dm).get(mode)
+        if name is None:
+            return None
+        best = None
+        for elf in isa_lint.code_objects(str(specialize.CACHE / name)):
+            for sym, insts in isa_lint.parse(isa_lint.disassemble(elf)).items():
+                if "jxs_kernel" in sym and "duo" not in sym:
+                    n = sum(i.op.startswith("v_") for i in insts)
+                    best = n if best is None else min(best, n)
+        return best
+    except Exception:
+        return None
+
+
+def issue_figures(valu_per_wave, envs_per_wave, n_envs, us_per_step):
+    """Two numbers that say where the step kernel's time goes once the HBM roofline is out of reach:
+    `valu_issue_util` = the cycles the SIMDs spend issuing this launch's vector instructions / the cycles they had;
+    `lane_slot_efficiency` = modelled lane-operations (FLOPS_PER_ENV_STEP / 2 multiply-adds) / lane slots issued."""
+    if not valu_per_wave:
+        return {}
+    waves = -(-n_envs // envs_per_wave)
+    cycles_available = N_SIMDS * us_per_step * 1e-6 * SHADER_CLOCK_GHZ * 1e9
+    return {"valu_per_wave_static": int(valu_per_wave), "waves": int(waves),
+            "valu_issue_util": waves * valu_per_wave * VALU_ISSUE_CYCLES / cycles_available,
+            "lane_slot_efficiency": (FLOPS_PER_ENV_STEP / 2) / (valu_per_wave * 64 / envs_per_wave)}
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -718,7 +757,10 @@ def main():
             ev5.record(stream)
             runtime.synchronize(stream)
             us = ev4.elapsed_ms(ev5) / 200 * 1e3
-            saturated = {"envs": n_sat, "us_per_step": us, "env_steps_per_s": n_sat / (us * 1e-6)}
+            saturated = {"envs": n_sat, "us_per_step": us, "env_steps_per_s": n_sat / (us * 1e-6),
+                         "finite_envs": float(np.isfinite(big.state_block()).all(axis=0).mean()), "steps_taken": 220,
+                         "finite_note": "the rate at which environments leave is the explicit contact model's, the same in the fp64 oracle: "
+                                        "profiles/r04_divergence_audit.txt (65536 distinct states x 1000 steps: HIP fp32 47, HIP fp64 51, C port fp32 47, C port fp64 51 gone)"}
             del big
         except Exception as e:  # secondary: never lose the headline for it
             saturated = {"error": repr(e)}
@@ -752,6 +794,7 @@ def main():
         n, n_cp = lay.n_joints, lay.n_points
         alg_bytes_per_env = (2 * (13 + 2 * n + 3 * n_cp) + n) * dtype.itemsize
         achieved_gbs = alg_bytes_per_env * n_local / (kernel_ms * 1e-3) / 1e9
+        valu_count = kernel_valu_count(dm) if dtype == np.float32 else None
         traffic, traffic_note = profiled_traffic(args.model, n_local, dtype.name)
         tname = "float" if dtype == np.float32 else "double"
         out = {
@@ -806,6 +849,7 @@ def main():
                 "kernel_avg_launch_us": kernel_ms * 1e3,
                 "fp32_flop_model_per_env_step": FLOPS_PER_ENV_STEP,
                 "fp32_frac_of_vector_peak": FLOPS_PER_ENV_STEP * n_local / (kernel_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
+                **issue_figures(valu_count, 64 // lay.group, n_local, kernel_ms * 1e3),
             },
             "nonfinite_envs_rank0": nonfinite_envs,
             "nonfinite_note": "fp32 + explicit contacts at their stability limit: single environments can leave the finite range after some "
@@ -825,6 +869,7 @@ def main():
                 saturated["hbm_frac"] = alg_bytes_per_env * saturated["env_steps_per_s"] / 1e9 / HBM_PEAK_GBS
                 saturated["fp32_frac_of_vector_peak"] = FLOPS_PER_ENV_STEP * saturated["env_steps_per_s"] / 1e12 / FP32_PEAK_TFLOPS
                 saturated["note"] = "same step kernel, one GPU filled; secondary figure, not `value`"
+                saturated.update(issue_figures(valu_count, 64 // lay.group, saturated["envs"], saturated["us_per_step"]))
             out["saturated"] = saturated
         if world == 1 and not args.no_other_contact_models:
             try:

@@ -505,7 +505,9 @@ class OracleData:
             base_angular_velocity_inertial=self.base_angular_velocity,
             joint_velocities=self.joint_velocities,
         )
-        return dataclasses.replace(self, base_quaternion=q, link_transforms=H, link_velocities=V)
+        out = dataclasses.replace(self, base_quaternion=q, link_transforms=H, link_velocities=V)
+        out._model = model  # (not a field: lets tests/helpers.py::upcast refresh the caches in the new precision)
+        return out
 
 
 # =============================================================================================

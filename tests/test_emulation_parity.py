@@ -4,6 +4,7 @@ the gfx950 kernels -- only the lane backend differs -- so this is the -m "not gp
 the kernel *logic*.  Tolerances (helpers.py): fp64 1e-10, fp32 1e-3 worst-case (2e-2 for the noise-limited chain9f) relative to the fp64 oracle on the same inputs.
 """
 
+import dataclasses
 import numpy as np
 import pytest
 
@@ -158,7 +159,7 @@ def test_far_from_origin_is_well_conditioned(models):
     d64.base_linear_velocity[:] = 0
     d64.base_angular_velocity[:] = 0
     d64 = d64.update_caches(model)
-    ref = oracle.forward_dynamics_aba(model, oracle.OracleData(**{**d64.__dict__, "velocity_representation": VelRepr.Inertial}))
+    ref = oracle.forward_dynamics_aba(model, dataclasses.replace(d64, velocity_representation=VelRepr.Inertial))
     blk32 = helpers.odata_to_block(model, d64, np.float32)
     out = eb.run(model, eb.MODE_FD, blk32)
     assert helpers.rel_err(out.T[:, 6:], ref[1]) < 5e-3  # joint accelerations stay accurate

@@ -222,9 +222,11 @@ def test_full_size_round_trip_fd_id(models):
 
 
 def test_full_size_quadruped_step_error_distribution(models):
-    """[round 3] The quadruped at full batch size, fp32: per-environment error distribution against the fp64 oracle,
-    gated at three times what was measured on MI355X (profiles/r03_fp32_error_gpu.txt: median 1.0e-7 .. 1.2e-7,
-    99th percentile 5.7e-5 .. 6.9e-5, worst 2.5e-4 .. 3.6e-4 over 2 x 512 states)."""
+    """The quadruped at full batch size, fp32: per-environment error distribution against the fp64 oracle on the same
+    state, gated at three times what was measured on MI355X (profiles/r04_fp32_error_gpu.txt: median 1.0e-7, 99th
+    percentile 1.5e-5 .. 2.0e-5, worst 3.0e-5 .. 3.6e-5 over 2 x 512 states; the reference's own formulation run in
+    fp32: 99th percentile 6.9e-5 .. 9.3e-5, worst 2.9e-4 .. 3.7e-4).  [round 4: the round-3 figures, 6e-5 / 3.6e-4,
+    were measured against a truth with fp32-rounded kinematics caches -- helpers.upcast.]"""
     model = models("anymal")
     N = 1024
     d = models.random_data("anymal", N, seed=9, dtype=np.float32)
@@ -232,7 +234,7 @@ def test_full_size_quadruped_step_error_distribution(models):
     out = js.model.step(model, to_gpu(model, d)).state_block()
     per_env = (np.abs(out - truth) / np.maximum(1.0, np.abs(truth))).max(axis=0)
     assert per_env.max() < helpers.tol_of(np.float32, "anymal")
-    assert np.median(per_env) < 3.6e-7 and np.percentile(per_env, 99) < 2.1e-4, (np.median(per_env), np.percentile(per_env, 99))
+    assert np.median(per_env) < 3.6e-7 and np.percentile(per_env, 99) < 6e-5, (np.median(per_env), np.percentile(per_env, 99))
 
 
 def test_full_size_batch_independence(models):
