@@ -163,7 +163,10 @@ hipError_t launch_one(const jxs::KParams<T>& P, const unsigned char* mblk, const
     }
     // two waves per SIMD pay off once there are more waves than SIMDs (256 CUs x 4) and eight of them fit
     // the LDS of a CU (160 KiB)
-    constexpr bool kHasOcc2 = (MODE == jxs::MODE_STEP_RIGID || MODE == jxs::MODE_STEP_RK4_RIGID) && sizeof(T) == 4;
+    // [round 4] semi-implicit Euler only: the RungeKutta4 variant squeezed into 256 registers spills to scratch, and hipcc
+    // (ROCm 7.2) placed those spills in front of the EXEC restore of a join block (jaxsim_amd/isa_lint.py, rule
+    // masked_join -- the build fails on it); the one-wave kernel of that mode has the registers it needs.
+    constexpr bool kHasOcc2 = MODE == jxs::MODE_STEP_RIGID && sizeof(T) == 4;
     if (kHasOcc2 && blocks > 1024 && lds_bytes * 8 <= 160 * 1024 && P.n_cp <= 8) {
       hipLaunchKernelGGL((jxs_kernel<T, G, MODE, kHasOcc2 ? KV_OCC2 : KV_GENERIC>), dim3(blocks), dim3(64), lds_bytes, s, A.state_in, A.state_out, mblk,
                          A.tau, A.link_f, A.N, P.n_rows, P.n, A.force_repr, A.n_steps, tail);

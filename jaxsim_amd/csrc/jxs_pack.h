@@ -67,6 +67,8 @@ std::string kernel_spec_string(const Packed<T>& pk, int mode) {
   add("flat", P.flat), add("enable_friction", P.enable_friction), add("pq_half", P.pq_half), add("anchored", P.anchored);
   add("rigid", P.rigid), add("n_cp", P.n_cp), add("rg_merge", P.rg_merge), add("rr_refine", P.rr_refine), add("rk4fast", P.rk4fast);
   add("jump_pad", P.jump_pad), add("jrow_seq", P.jrow_seq), add("prow_seq", P.prow_seq);
+  add("rl_n", P.rl_n), add("rl_lane[0]", P.rl_lane[0]), add("rl_lane[1]", P.rl_lane[1]);
+  add("rl_s0[0]", P.rl_s0[0]), add("rl_s1[0]", P.rl_s1[0]), add("rl_s0[1]", P.rl_s0[1]), add("rl_s1[1]", P.rl_s1[1]);
   s.pop_back();
   return s;
 }
@@ -421,6 +423,31 @@ std::string pack_model(const jxs_model_desc& d, Packed<T>& out) {
           if (level[a] == 1) break;
         }
       }
+    }
+  }
+  // [round 4] RelaxedRigidContacts in link space (jxs_rigid.inc relaxed_linkspace): at most two contact links (the twelve
+  // rows of the link-space system sit in the first twelve lanes of one 16-lane DPP row), none of them a fixed base (its
+  // row of the inverse operational-space inertia would be zero), and a regulariser that is not negligible against the
+  // Delassus entries: the solve forms R^-1 (c - P v), which cancels when R -> 0 (the bare defaults, mu = 0.005:
+  // 2 mu^2 (1 + mu^2) = 5e-5; estimate_good_contact_parameters gives mu = 0.5: 0.625) -- those models keep the dense path.
+  P.rl_n = 0;
+  for (int k = 0; k < 2; ++k) P.rl_lane[k] = 0, P.rl_s0[k] = 0, P.rl_s1[k] = 0;
+  if (d.contact_model == JXS_CONTACT_RELAXED_RIGID && n_en >= 1 && n_chunks == 1 && G >= 16 &&
+      2.0 * d.mu * d.mu * (1.0 + d.mu * d.mu) >= 0.02 && std::getenv("JXS_DISABLE_LINKSPACE") == nullptr) {  // developer knob: A/B
+    int nl = 0, body[3] = {-1, -1, -1}, s0[3] = {0, 0, 0}, s1[3] = {0, 0, 0};
+    for (int s = 0; s < n_en && nl <= 2; ++s) {
+      const int b = d.point_body[en[s]];
+      if (nl == 0 || body[nl - 1] != b) {
+        if (nl < 3) body[nl] = b, s0[nl] = s;
+        ++nl;
+      }
+      if (nl <= 2) s1[nl - 1] = s + 1;
+    }
+    bool ok = nl >= 1 && nl <= 2;
+    for (int k = 0; k < nl && ok; ++k) ok = d.floating_base || body[k] != 0;
+    if (ok) {
+      P.rl_n = nl;
+      for (int k = 0; k < nl; ++k) P.rl_lane[k] = lane_of[body[k]], P.rl_s0[k] = s0[k], P.rl_s1[k] = s1[k];
     }
   }
   for (int ch = 0; ch < n_chunks; ++ch) {

@@ -6,6 +6,6 @@
 set -u
 mkdir -p gpurun_out
 rm -f gpurun_out/spec_manifest.raw
-JAXSIM_AMD_TEST_RECORD=1 JAXSIM_AMD_SPEC_RECORD=$PWD/gpurun_out/spec_manifest.raw timeout ${T:-900} python -m pytest tests -m gpu -q -x --durations=8 > gpurun_out/record_pytest.log 2>&1
+JAXSIM_AMD_TEST_RECORD=1 JAXSIM_AMD_SPEC_RECORD=$PWD/gpurun_out/spec_manifest.raw timeout ${T:-900} python -m pytest tests -m gpu -q --durations=8 > gpurun_out/record_pytest.log 2>&1
 echo "pytest rc=$?"; tail -15 gpurun_out/record_pytest.log
 sort -u gpurun_out/spec_manifest.raw > gpurun_out/spec_manifest.txt; wc -l gpurun_out/spec_manifest.txt; rm -f gpurun_out/spec_manifest.raw
