@@ -2223,15 +2223,10 @@ struct Core {
   JXS_HD void point_physics(const VM& valid, const V* Lp, const V* m, const V* Rb, const V* rb, const V* vbl,
                             const V* vba, const V* rab, const V* pB, const V* doff, const V* vBc, const V* om, V* w6, V* md) const {
     const V zero = V(T(0));
-    V rc0[3], rc[3], pw[3], pd[3], t[3], lever[3];
+    V rc0[3], rc[3], pw[3], pd[3], t[3];
     mat3vec(Rb, Lp, rc0);
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      // [round 4] lever of the contact force about the anchor of the link's chain, formed from SMALL quantities:
-      // (R Lp) + (r_link - r_anchor).  The points of a legged robot sit on the leaf links, which ARE the anchors of their
-      // chains (r_link - r_anchor = 0 exactly), so the lever is R Lp as in the reference's link-frame formulation,
-      // instead of (R Lp + r_link) - r_anchor with the rounding of a 0.6 m position in it.
-      lever[k] = rc0[k] + ((rb[k] - rab[k]) + (P.has_base_off ? doff[k] : zero));
       rc0[k] = rc0[k] + rb[k];                               // relative to the ABA base origin
       rc[k] = P.has_base_off ? rc0[k] + doff[k] : rc0[k];    // relative to the base position, cached (FK) placement
       pw[k] = rc[k] + pB[k];                                 // world position
@@ -2336,6 +2331,7 @@ struct Core {
       w6[2] = vsel(valid, fn * nh[2] + ft[2], zero);
     }
     // moment about the anchor of the parent link's chain (rab = 0: about the origin of C)
+    V lever[3] = {rc[0] - rab[0], rc[1] - rab[1], rc[2] - rab[2]};
     cross(lever, w6, w6 + 3);
   }
 

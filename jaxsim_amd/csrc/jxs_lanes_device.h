@@ -759,6 +759,18 @@ struct DeviceLanes {
     if (mask) lds_writev<N>(addr, v);
     lds_publish();
   }
+  // Masked writes WITHOUT an exec-masked region: lanes outside `mask` write to `sink` (words nobody reads) instead.  No
+  // branch, no join block -- the construct hipcc's spill placement mishandles under register pressure (isa_lint.py
+  // masked_join) cannot arise.  Used where a kernel is at the limit of the register file (jxs_rigid.inc ls_*).
+  template <int N>
+  __device__ __forceinline__ void lds_writev_sel(int addr, const T* v, bool mask, int sink) const {
+    lds_writev<N>(mask ? addr : sink, v);
+    lds_publish();
+  }
+  __device__ __forceinline__ void lds_write_sel(int addr, T v, bool mask, int sink) const {
+    lds_[mask ? addr : sink] = v;
+    lds_publish();
+  }
   template <int N>
   __device__ __forceinline__ void lds_readv(int addr, T* v) const {
     constexpr int W = 16 / (int)sizeof(T);

@@ -155,12 +155,45 @@ std::string pack_model(const jxs_model_desc& d, Packed<T>& out) {
   if (P.rk4fast && !P.rigid)
     return "RungeKutta4Fast is built for RigidContacts / RelaxedRigidContacts with collidable points: the reference's "
            "version corrupts the tangential deformation of SoftContacts and fails without collidable points";
+  // [round 4] Contact problems in link space (jxs_rigid.inc ls_*): at most two contact links (the twelve rows of the
+  // link-space system sit in the first twelve lanes of one 16-lane DPP row), none of them a fixed base (its row of the
+  // inverse operational-space inertia would be zero).  RelaxedRigidContacts in addition needs a regulariser that is
+  // not negligible against the Delassus entries: the solve forms R^-1 (c - P v), which cancels when R -> 0 (the bare
+  // defaults, mu = 0.005: 2 mu^2 (1 + mu^2) = 5e-5; estimate_good_contact_parameters gives mu = 0.5: 0.625) -- those
+  // models keep the dense path.  RigidContacts: in fp64 only.  The blocks of its interior-point iterations are
+  // reg I + G_c^T diag(z / s) G_c with reg = 1e-6 and barrier weights that go to zero on the inactive faces, i.e. D^-1
+  // up to 1e6 against Delassus entries of O(1): c - P v cancels six digits, which fp64 has and fp32 has not (measured
+  // in the host emulation: humanoid with 8 points 1.2e-11 in fp64, no correct digit in fp32; the dense Cholesky of the
+  // LDS path is backward stable and stays the fp32 path, 6.6e-5).  fp64 is the reference's default precision and the one
+  // whose triangles do not fit the LDS beyond 47 points.  And for solver_tol >= 1e-7 only (default 1e-3): the same
+  // cancellation bounds what fp64 can resolve at ~1e6 x 1e-16 -- at solver_tol = 1e-10 single environments left the
+  // iteration with a poor iterate on the device (1e-3; 1e-8 still fine on one model, not on the other), where the
+  // dense path reaches 5e-10 (tools/ab/ls_gpu_check.py); those models keep the triangles.
+  int rl_n = 0, rl_body[2] = {0, 0}, rl_s0[2] = {0, 0}, rl_s1[2] = {0, 0};
+  if (P.rigid && n_en >= 1 && (n_en + G - 1) / G == 1 && G >= 16 && std::getenv("JXS_DISABLE_LINKSPACE") == nullptr &&  // (developer knob: A/B)
+      (P.rigid == 1 ? ((sizeof(T) == 8 && d.solver_tol >= 1e-7) || std::getenv("JXS_LINKSPACE_FP32") != nullptr) : 2.0 * d.mu * d.mu * (1.0 + d.mu * d.mu) >= 0.02)) {  // (the second knob: the fp32 experiment -- 8.7e-3 / no digit on the two test models, see above)
+    int nl = 0, body[3] = {-1, -1, -1}, s0[3] = {0, 0, 0}, s1[3] = {0, 0, 0};
+    for (int s = 0; s < n_en && nl <= 2; ++s) {
+      const int b = d.point_body[en[s]];
+      if (nl == 0 || body[nl - 1] != b) {
+        if (nl < 3) body[nl] = b, s0[nl] = s;
+        ++nl;
+      }
+      if (nl <= 2) s1[nl - 1] = s + 1;
+    }
+    bool ok = nl >= 1 && nl <= 2;
+    for (int k = 0; k < nl && ok; ++k) ok = d.floating_base || body[k] != 0;
+    if (ok) {
+      rl_n = nl;
+      for (int k = 0; k < nl; ++k) rl_body[k] = body[k], rl_s0[k] = s0[k], rl_s1[k] = s1[k];
+    }
+  }
   if (P.rigid) {
     // one point per lane, three rows of the QP per point, both matrices in LDS (jxs_rigid.inc)
     if (n_en > kRigidMaxPoints) return "RigidContacts / RelaxedRigidContacts: at most 64 enabled collidable points are supported";
     {
       // the Delassus matrix (and the working factor of RigidContacts) of one environment must fit the LDS of a CU
-      const size_t bytes = sizeof(T) * (size_t)(64 / G) * (size_t)rigid_lds_words_per_env(n_en, d.contact_model == JXS_CONTACT_RELAXED_RIGID ? 2 : 1);
+      const size_t bytes = sizeof(T) * (size_t)(64 / G) * (size_t)rigid_lds_words_per_env(n_en, d.contact_model == JXS_CONTACT_RELAXED_RIGID ? 2 : 1, rl_n);
       if (bytes > (size_t)160 * 1024 && std::getenv("JXS_IGNORE_LDS_BUDGET") == nullptr)  // (the knob: host emulation of the tests only)
         return "RigidContacts / RelaxedRigidContacts: the contact problem of this many enabled points does not fit the 160 KB of LDS of a CU "
                "in this precision (64 points: fp32, or RelaxedRigidContacts in fp64)";
@@ -425,31 +458,8 @@ std::string pack_model(const jxs_model_desc& d, Packed<T>& out) {
       }
     }
   }
-  // [round 4] RelaxedRigidContacts in link space (jxs_rigid.inc relaxed_linkspace): at most two contact links (the twelve
-  // rows of the link-space system sit in the first twelve lanes of one 16-lane DPP row), none of them a fixed base (its
-  // row of the inverse operational-space inertia would be zero), and a regulariser that is not negligible against the
-  // Delassus entries: the solve forms R^-1 (c - P v), which cancels when R -> 0 (the bare defaults, mu = 0.005:
-  // 2 mu^2 (1 + mu^2) = 5e-5; estimate_good_contact_parameters gives mu = 0.5: 0.625) -- those models keep the dense path.
-  P.rl_n = 0;
-  for (int k = 0; k < 2; ++k) P.rl_lane[k] = 0, P.rl_s0[k] = 0, P.rl_s1[k] = 0;
-  if (d.contact_model == JXS_CONTACT_RELAXED_RIGID && n_en >= 1 && n_chunks == 1 && G >= 16 &&
-      2.0 * d.mu * d.mu * (1.0 + d.mu * d.mu) >= 0.02 && std::getenv("JXS_DISABLE_LINKSPACE") == nullptr) {  // developer knob: A/B
-    int nl = 0, body[3] = {-1, -1, -1}, s0[3] = {0, 0, 0}, s1[3] = {0, 0, 0};
-    for (int s = 0; s < n_en && nl <= 2; ++s) {
-      const int b = d.point_body[en[s]];
-      if (nl == 0 || body[nl - 1] != b) {
-        if (nl < 3) body[nl] = b, s0[nl] = s;
-        ++nl;
-      }
-      if (nl <= 2) s1[nl - 1] = s + 1;
-    }
-    bool ok = nl >= 1 && nl <= 2;
-    for (int k = 0; k < nl && ok; ++k) ok = d.floating_base || body[k] != 0;
-    if (ok) {
-      P.rl_n = nl;
-      for (int k = 0; k < nl; ++k) P.rl_lane[k] = lane_of[body[k]], P.rl_s0[k] = s0[k], P.rl_s1[k] = s1[k];
-    }
-  }
+  P.rl_n = rl_n;
+  for (int k = 0; k < 2; ++k) P.rl_lane[k] = k < rl_n ? lane_of[rl_body[k]] : 0, P.rl_s0[k] = rl_s0[k], P.rl_s1[k] = rl_s1[k];
   for (int ch = 0; ch < n_chunks; ++ch) {
     int s = ch * G;
     const int end = std::min(n_en, (ch + 1) * G);

@@ -172,15 +172,19 @@ constexpr int kRgMergeRec = 40;  // [0, 18) wrench handed to the base per unit f
 JXS_HD constexpr int rigid_lds_merge_off(int n_cp, int rigid = 1) {
   return ((rigid == 2 ? 1 : 2) * ((3 * n_cp * (3 * n_cp + 1)) / 2) + 3 * n_cp + 8 + (n_cp <= 4 ? 16 : 0) + 3) / 4 * 4;
 }
-// [round 4] link-space solve of RelaxedRigidContacts (jxs_rigid.inc relaxed_linkspace): the 12 x 12 inverse
+// [round 4] contact problems solved in link space (jxs_rigid.inc ls_*): the 12 x 12 inverse
 // operational-space inertia of the contact links (rows of 16 words), one 12-word record per point, 16 words of exchange
 constexpr int kRlRowStride = 16, kRlPtRec = 12;
 JXS_HD constexpr int rl_lds_pt_off() { return 12 * kRlRowStride; }
 JXS_HD constexpr int rl_lds_vec_off(int n_cp) { return rl_lds_pt_off() + kRlPtRec * n_cp; }
-JXS_HD constexpr int rl_lds_words(int n_cp) { return rl_lds_vec_off(n_cp) + 16; }
-JXS_HD constexpr int rigid_lds_words_per_env(int n_cp, int rigid = 1) {
-  const int dense = rigid_lds_merge_off(n_cp, rigid) + (n_cp <= 4 ? 4 * kRgMergeRec : 0);
-  return (rigid == 2 && rl_lds_words(n_cp) > dense) ? rl_lds_words(n_cp) : dense;
+JXS_HD constexpr int rl_lds_sink_off(int n_cp) { return rl_lds_vec_off(n_cp) + 16; }  // 8 words nobody reads (lds_write*_sel)
+JXS_HD constexpr int rl_lds_words(int n_cp) { return rl_lds_sink_off(n_cp) + 8; }
+// the model's contact problem is solved in link space (rl_n: contact links found eligible by the packer); RigidContacts
+// with <= 4 points keeps the row-distributed register solver (config 5)
+JXS_HD constexpr bool rl_linkspace(int rl_n, int n_cp, int rigid) { return rl_n > 0 && (rigid == 2 || (rigid == 1 && n_cp > 4)); }
+JXS_HD constexpr int rigid_lds_words_per_env(int n_cp, int rigid = 1, int rl_n = 0) {
+  return rl_linkspace(rl_n, n_cp, rigid) ? rl_lds_words(n_cp)  // no triangle at all
+                                         : rigid_lds_merge_off(n_cp, rigid) + (n_cp <= 4 ? 4 * kRgMergeRec : 0);
 }
 constexpr int kQpMaxIter = 30;    // interior-point iterations (oracle/refrigid.py QP_MAX_ITER)
 constexpr int kRigidMaxPoints = 64;  // one lane per point: a full wave ([round 3]: 32 -> 64; the point masks are 64 bits wide)
@@ -270,7 +274,7 @@ struct KParams {
   T rr_rcoef;                    // 2 mu^2 (1 + mu^2)
   T rr_tiny;                     // smallest positive normal number (guards pow of a non-positive base)
   int rr_refine;                 // refinement steps against the operator applied through the tree
-  // [round 4] RelaxedRigidContacts solved in LINK space (jxs_rigid.inc relaxed_linkspace): all points of a link move with the
+  // [round 4] contact problems solved in LINK space (jxs_rigid.inc ls_*): all points of a link move with the
   // link's twist, J M^-1 J^T = P B P^T with B the inverse operational-space inertia of the contact links.  rl_n: number
   // of contact links (1 or 2; 0: the dense Delassus path), their lanes, and the slots [s0, s1) of their points.
   int rl_n, rl_lane[2], rl_s0[2], rl_s1[2];

@@ -313,6 +313,12 @@ struct HostLanes {
   void lds_writev_if(const VI& addr, const V* v, const VM& mask) const {
     for (int k = 0; k < N; ++k) lds_write(addr + k, v[k], mask);
   }
+  // (device: lanes outside the mask write to the sink words; here they simply do not write -- nobody reads the sink)
+  template <int N>
+  void lds_writev_sel(const VI& addr, const V* v, const VM& mask, int) const {
+    for (int k = 0; k < N; ++k) lds_write(addr + k, v[k], mask);
+  }
+  void lds_write_sel(const VI& addr, const V& v, const VM& mask, int) const { lds_write(addr, v, mask); }
   template <int N>
   void lds_readv(const VI& addr, V* v) const {
     for (int k = 0; k < N; ++k) v[k] = lds_read(addr + k);

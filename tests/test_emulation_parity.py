@@ -705,13 +705,18 @@ def test_rk4fast_is_refused_where_the_reference_is_broken(models):
         oracle.step(helpers.with_params(models("box"), integrator=ja.IntegratorType.RungeKutta4Fast), models.random_data("box", 1))
 
 
-def test_rigid_unsupported_configurations_are_rejected(models):
+def test_rigid_unsupported_configurations_are_rejected(models, monkeypatch):
     import jaxsim_amd as ja
 
-    # [round 3] up to 64 enabled points; the two triangles of RigidContacts for 50 points are 182 KB in fp64: more than
-    # the LDS of a CU -- refused with the reason (fp32 fits: 91 KB)
+    # up to 64 enabled points.  [round 4] The 50-point sphere of the reference in fp64 -- refused in round 3: the two
+    # triangles of RigidContacts are 182 KB, more than the LDS of a CU -- is accepted: its points sit on ONE link and the
+    # contact problem is solved in link space, without any triangle (jxs_rigid.inc ls_*).  The dense path still says why
+    # it cannot take it (the developer knob switches the link-space solve off).
+    assert eb.layout(helpers.rigid_model(models("sphere"), list(range(50))), np.float64).group == 64
+    monkeypatch.setenv("JXS_DISABLE_LINKSPACE", "1")
     with pytest.raises(RuntimeError, match="does not fit"):
         eb.layout(helpers.rigid_model(models("sphere"), list(range(50))), np.float64)
+    monkeypatch.delenv("JXS_DISABLE_LINKSPACE")
     assert eb.layout(helpers.rigid_model(models("sphere"), list(range(50))), np.float32).group == 64
     # [round 3] fixed-base models are accepted (test_fixed_base_rigid_contacts_match_oracle)
     fixed = ja.JaxSimModel.build_from_model_description(ja.robots.cartpole_urdf(with_collisions=True))
@@ -912,12 +917,15 @@ def test_fixed_base_rigid_contacts_match_oracle(reduced_qp, kind, base_velocity)
 
 
 @pytest.mark.parametrize("kind", ["rigid", "relaxed"])
-def test_fifty_point_sphere_matches_oracle(models, reduced_qp, kind, monkeypatch):
+@pytest.mark.parametrize("path", ["linkspace", "dense"])
+def test_fifty_point_sphere_matches_oracle(models, reduced_qp, kind, path, monkeypatch):
     """[round 3] More than 32 enabled points (one lane per point, 64-bit point masks): the reference's sphere collision
     shape is 50 points (parsers/rod/utils.py:200-204).  fp64 against the oracle: 1e-7 (RigidContacts: QP + impact) /
     1e-9 (RelaxedRigidContacts).  (The emulation ignores the LDS budget that refuses 50-point RigidContacts in fp64 on
     the device -- two 150 x 150 triangles of doubles are 182 KB; the GPU test runs that case in fp32.)"""
     monkeypatch.setenv("JXS_IGNORE_LDS_BUDGET", "1")
+    if path == "dense":  # [round 4] the default is the link-space solve (one contact link); the triangles in the LDS stay covered
+        monkeypatch.setenv("JXS_DISABLE_LINKSPACE", "1")
     make = helpers.rigid_model if kind == "rigid" else helpers.relaxed_model
     model = make(models("sphere"), list(range(50)), **(dict(K=1e5) if kind == "rigid" else dict(mu=0.5)))
     N = 3
