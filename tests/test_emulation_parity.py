@@ -723,6 +723,38 @@ def test_rigid_unsupported_configurations_are_rejected(models, monkeypatch):
     assert eb.layout(helpers.rigid_model(fixed, [0, 1, 2, 3])).group >= 4
 
 
+@pytest.mark.parametrize("kind,key,dtype,tol", [
+    ("relaxed", "icub16", np.float64, 1e-11), ("relaxed", "icub16", np.float32, 2e-4), ("relaxed", "chain9f6", np.float64, 1e-11),
+    ("relaxed", "chain9f6", np.float32, 1e-4), ("rigid", "icub8", np.float64, 1e-7), ("rigid", "chain9f6", np.float64, 1e-7),
+])  # fmt: skip
+def test_link_space_solve_agrees_with_the_dense_path(models, reduced_qp, kind, key, dtype, tol, monkeypatch):
+    """[round 4] Contact problems whose points sit on at most two links are solved in link space (jxs_rigid.inc ls_*:
+    P B P^T + D through the 12 x 12 inverse operational-space inertia of the contact links); the developer knob switches
+    back to the packed triangles in the LDS.  Both paths against the oracle within the stated tolerance, and within
+    it of each other; the layout says which path a model takes."""
+    from jaxsim_amd import specialize
+
+    table, make = (RIGID_CASES, helpers.rigid_model) if kind == "rigid" else (RELAXED_CASES, helpers.relaxed_model)
+    name, idx, params = table[key]
+    model = make(models(name), idx, **params)
+    d = models.random_data(name, 16, seed=5, dtype=dtype)
+    truth = helpers.odata_to_block(model, oracle.step(model, helpers.upcast(d) if dtype == np.float32 else d))
+    blk = helpers.odata_to_block(model, d)
+    assert "P.rl_n=2" in specialize.spec(model, dtype, specialize.MODE_STEP_RIGID)
+    ls = eb.run(model, eb.MODE_STEP, blk)
+    monkeypatch.setenv("JXS_DISABLE_LINKSPACE", "1")
+    assert "P.rl_n=0" in specialize.spec(model, dtype, specialize.MODE_STEP_RIGID)
+    dense = eb.run(model, eb.MODE_STEP, blk)
+    assert helpers.rel_err(ls, truth) < tol and helpers.rel_err(dense, truth) < tol
+    assert helpers.rel_err(ls, dense) < 2 * tol and not np.array_equal(ls, dense)
+    # RigidContacts in fp32 and at tight solver tolerances keeps the triangles (jxs_pack.h: the cancellation in c - P v)
+    monkeypatch.delenv("JXS_DISABLE_LINKSPACE")
+    if kind == "rigid":
+        assert "P.rl_n=0" in specialize.spec(model, np.float32, specialize.MODE_STEP_RIGID)
+        tight = make(models(name), idx, build=dict(solver_options={"solver_tol": 1e-10}), **params)
+        assert "P.rl_n=0" in specialize.spec(tight, np.float64, specialize.MODE_STEP_RIGID)
+
+
 @pytest.mark.parametrize("fixed_base,max_back", [(True, 1), (False, 1), (False, 3)])
 def test_maximum_size_models(models, fixed_base, max_back):
     """The largest supported model: 64 links, one per lane of a full wave; a serial chain makes the tree
