@@ -12,7 +12,7 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 OUT=${JXS_OUT:-libjaxsim_amd.so}
 OBJ=build/${OUT%.so}
 mkdir -p "$OBJ"
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize -mllvm -amdgpu-kernarg-preload-count=16 -Wall -Wno-unused-function -Wno-cuda-compat ${JXS_EXTRA_FLAGS:-}"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize -mllvm -amdgpu-kernarg-preload-count=16 -Wall -Wno-unused-function -Wno-cuda-compat -DJXS_WITH_DUO ${JXS_EXTRA_FLAGS:-}"
 JOBS=${JXS_JOBS:-$(nproc)}
 UNITS=${JXS_ONLY:-}
 if [ -z "$UNITS" ]; then

@@ -177,6 +177,8 @@ hipError_t launch_one(const jxs::KParams<T>& P, const unsigned char* mblk, const
   // variant runs at parity with the single-wave kernel (7.70 vs 7.65 us, profiles/r03_two_wave_experiment.md): the
   // inertia recursion stays the critical path and the waves of a CU share its LDS and vector-memory pipelines.
   // JXS_DUO_MAX_BLOCKS bounds the grids it is used for.
+#ifdef JXS_WITH_DUO  // [round 4] compiled into the library only (csrc/build.sh): a model-specialised object no longer carries
+                     // the kernel of an experiment that lost (a second kernel per object: compile time on first use)
   if constexpr (MODE == jxs::MODE_STEP && G >= 8) {
     const int duo_env = (A.knobs & jxs::KNOB_DUO) ? 1 : 0;
     const int duo_max_blocks = A.duo_max_blocks > 0 ? A.duo_max_blocks : (1 << 30);
@@ -197,6 +199,7 @@ hipError_t launch_one(const jxs::KParams<T>& P, const unsigned char* mblk, const
       return hipGetLastError();
     }
   }
+#endif
 #ifndef JXS_SPEC_ASSIGN  // (a model-specialised build has these constants anyway)
   constexpr bool kHasCommon = (MODE == jxs::MODE_STEP || MODE == jxs::MODE_ROLLOUT) && G >= 8;
   const bool common_off = (A.knobs & jxs::KNOB_NO_COMMON_VARIANT) != 0;  // developer knob: A/B against KV_GENERIC

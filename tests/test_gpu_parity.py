@@ -360,7 +360,7 @@ def test_fused_rollout_equals_repeated_steps_gpu(models, knobs):
 
 @pytest.mark.parametrize("name", ["anymal", "icub", "icub16"])
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
-def test_two_wave_step_matches_oracle_and_single_wave_gpu(models, name, dtype, knobs):
+def test_two_wave_step_matches_oracle_and_single_wave_gpu(models, name, dtype, knobs, kernel_policy):
     """The opt-in two-wave workgroup variant of the step kernel (JXS_DUO=1; jxs_core.h run_inertia + run<MODE_STEP,
     ROLE_MAIN>): against the oracle within the stated tolerance, against the single-wave kernel to rounding, for a
     ragged batch (an odd number of tiles: the second pair of the last workgroup is empty)."""
@@ -376,7 +376,9 @@ def test_two_wave_step_matches_oracle_and_single_wave_gpu(models, name, dtype, k
     assert helpers.rel_err(duo, helpers.odata_to_block(model, ref)) < helpers.tol_of(dtype, name)
     # (fp32: other contraction choices in two instruction streams; measured 4e-5 on the humanoid's contact-rich states)
     assert helpers.rel_err(duo, solo) < (1e-12 if dtype == np.float64 else 1e-4)
-    if dtype == np.float32:  # (fp64: two pairs of waves exceed the 160 KB of LDS of a CU, the single-wave kernel runs)
+    # (fp64: two pairs of waves exceed the 160 KB of LDS of a CU, the single-wave kernel runs; [round 4] the variant is
+    # compiled into the library only, -DJXS_WITH_DUO: a model-specialised object ignores the knob)
+    if dtype == np.float32 and kernel_policy == "library":
         assert not np.array_equal(duo, solo), "the two-wave variant did not run"
 
 

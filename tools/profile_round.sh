@@ -16,6 +16,8 @@ rocprofv3 --output-format csv --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WA
   -d "$OUT/pmc_sq" -- $B > "$OUT/pmc_sq.log" 2>&1
 rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/c5" -- python "$R/tools/bench_c5.py" > "$OUT/c5.log" 2>&1
 rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/c5_relaxed" -- python "$R/tools/bench_c5.py" --contact relaxed --points 16 > "$OUT/c5_relaxed.log" 2>&1
+# the reference's own step-benchmark idiom: humanoid, all 32 points, RelaxedRigidContacts with estimated parameters (link space)
+rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/relaxed_humanoid" -- python "$R/tools/bench_c5.py" --contact relaxed --points 32 --envs 1024 > "$OUT/relaxed_humanoid.log" 2>&1
 cd "$R"
 python bench.py > "$OUT/bench_N1.json" 2> "$OUT/bench_N1.err"
 python bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/bench_steps20.json" 2> "$OUT/bench_steps20.err"
@@ -23,7 +25,7 @@ python bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/bench_steps20.json" 2> "$
 # kernels of a timing build of the library (cd jaxsim_amd/csrc && JXS_EXTRA_FLAGS=-DJXS_PHASE_TIMING JXS_OUT=libjaxsim_amd_timing.so bash build.sh)
 export JAXSIM_AMD_SPEC_EXTRA_FLAGS=-DJXS_PHASE_TIMING
 JAXSIM_AMD_SPECIALIZE=1 python tools/phase_timing.py > "$OUT/phases.log" 2>&1
-JXS_DUO=1 JAXSIM_AMD_SPECIALIZE=1 python tools/phase_timing.py > "$OUT/phases_two_wave.log" 2>&1
+# (the two-wave experiment of round 3 is closed: profiles/r03_two_wave_experiment.md; the variant lives in the library only)
 for a in "4 4096" "4 4096 rigid standing" "16 4096" "16 4096 relaxed standing" "32 1024 relaxed standing"; do
   JAXSIM_AMD_SPECIALIZE=1 python tools/phase_timing_rigid.py $a >> "$OUT/phases_contact_models.log" 2>&1
 done
@@ -35,7 +37,7 @@ fi
 python tools/fp32_error_gpu.py 512 > "$OUT/fp32_error_gpu.log" 2>&1
 timeout 60 tools/ubench/issue_rate > "$OUT/issue_rate.log" 2>&1
 timeout 120 tools/ubench/cu_share > "$OUT/cu_share.log" 2>&1
-for duo in 0 1; do JXS_DUO=$duo timeout 300 python tools/sweep.py --sizes 1024,2048,4096,65536 --steps 1000 2>&1 | sed "s/^/JXS_DUO=$duo /" >> "$OUT/sweep.log"; done
+timeout 300 python tools/sweep.py --sizes 1024,2048,4096,65536 --steps 1000 >> "$OUT/sweep.log" 2>&1
 # PMC pass for the config-5 kernel (HBM-side traffic of the rigid-contact step)
 cd /tmp
 BC="python $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline --saturated-envs 0"   # (with the secondary contact-model figures: config 5 runs inside)

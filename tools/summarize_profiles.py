@@ -85,7 +85,7 @@ if summary:
 print("\n".join(lines))
 
 # the other artefacts of tools/profile_round.sh, copied under the round's tag
-for src, dst in (("c5", "c5_kernel_stats.csv"), ("c5_relaxed", "c5_relaxed_kernel_stats.csv")):
+for src, dst in (("c5", "c5_kernel_stats.csv"), ("c5_relaxed", "c5_relaxed_kernel_stats.csv"), ("relaxed_humanoid", "relaxed_humanoid_kernel_stats.csv")):
     ks = glob.glob(str(run / src / "*" / "*_kernel_stats.csv"))
     if ks:
         shutil.copy(ks[0], out / f"{tag}_{dst}")
