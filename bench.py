@@ -219,6 +219,7 @@ def other_contact_models(dtype, stream, steps=200, warmup=20):
 
     def timed(model, n_envs, seed, with_tau, kernel):
         data = synthetic_state(model, n_envs, seed=seed, dtype=dtype)
+        start = data._state.copy()  # (every measured loop below starts from the same state: the work depends on the contact state)
         dm = runtime.device_model(model, dtype)
         st = C.c_void_p(data._state.ptr)
         tau = runtime.DeviceArray(model.dofs(), n_envs, dtype, tile=data._state.tile, zero=True)
@@ -257,6 +258,23 @@ def other_contact_models(dtype, stream, steps=200, warmup=20):
             e1.record(stream)
             stream.synchronize()
             us_step = us - e0.elapsed_ms(e1) / steps * 1e3
+        fused_us = None
+        if with_tau:
+            # [round 4] the same controller loop as ONE launch per step (jxs_step_gravity_compensated: g(q) formed inside
+            # the step kernel from the kinematics it has in registers anyway)
+            def run_fused(k):
+                for _ in range(k):
+                    _lib.check(lib.jxs_step_gravity_compensated(dm.handle, st, st, None, None, 2, n_envs, stream.handle), "jxs_step_gravity_compensated")
+
+            _lib.check(lib.jxs_memcpy_d2d(st, C.c_void_p(start.ptr), start.nbytes, stream.handle), "jxs_memcpy_d2d")
+            run_fused(warmup)
+            stream.synchronize()
+            e0, e1 = runtime.Event(), runtime.Event()
+            e0.record(stream)
+            run_fused(steps)
+            e1.record(stream)
+            stream.synchronize()
+            fused_us = e0.elapsed_ms(e1) / steps * 1e3
         finite = float(np.isfinite(data.state_block()).all(axis=0).mean())
         lay = dm.layout
         # read state + read tau + write state; the rigid contact models carry no
@@ -265,7 +283,10 @@ def other_contact_models(dtype, stream, steps=200, warmup=20):
         gbs = alg * n_envs / (us_step * 1e-6) / 1e9
         from jaxsim_amd import specialize
 
-        return {"envs": n_envs, "steps": steps, "us_per_step": us, "env_steps_per_s": n_envs / (us * 1e-6), "finite_envs": finite,
+        fused = {} if fused_us is None else {"one_launch_per_step": {
+            "us_per_step": fused_us, "env_steps_per_s": n_envs / (fused_us * 1e-6),
+            "note": "jxs_step_gravity_compensated: tau = g(q) formed inside the step kernel; same controller loop, one launch instead of two"}}
+        return {"envs": n_envs, "steps": steps, "us_per_step": us, "env_steps_per_s": n_envs / (us * 1e-6), "finite_envs": finite, **fused,
                 "model_specialised_kernel": bool(specialize.modes(dm)),
                 "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                              "traffic": None, "algorithmic_bytes_per_env_step": alg, "kernel": kernel,

@@ -227,6 +227,14 @@ int jxs_validate_state(jxs_model* model, const void* state, int N, int* counts3,
  * solves, counts2[1] = impact solves, in environments, since the last reset.  Synchronous.          */
 int jxs_solver_fault_counts(jxs_model* model, int* counts2, int reset, void* stream);
 
+/* [round 4] jxs_step with tau_ref + g(q): the joint part of free_floating_gravity_forces (src/jaxsim/api/model.py:1897-1931)
+ * of the INPUT state is added to the joint force references inside the step kernel -- the controller loop
+ *     tau = js.model.free_floating_gravity_forces(model, data)[6:] (+ tau_user);  data = js.model.step(model, data, joint_force_references=tau)
+ * (BASELINE config 5) in one launch instead of two.  `tau` may be null (pure gravity compensation) or hold tau_user.
+ * Models with a rigid contact model (RigidContacts / RelaxedRigidContacts and enabled points) only: JXS_EINVAL otherwise.      */
+int jxs_step_gravity_compensated(jxs_model* model, const void* state_in, void* state_out, const void* tau,
+                                 const void* link_forces, int force_repr, int N, void* stream);
+
 /* Developer knobs of the launcher (JXS_DUO, JXS_DUO_MAX_BLOCKS, JXS_NO_MFMA, JXS_DISABLE_COMMON_VARIANT: A/B switches
  * between kernel variants that compute the same thing) are read from the environment once per process, at the first
  * launch.  This call reads them again -- for test programs that switch variants between launches.  No reference

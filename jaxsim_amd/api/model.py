@@ -138,8 +138,14 @@ def step(
     link_forces=None,
     joint_force_references=None,
     inplace: bool = False,
+    gravity_compensation: bool = False,
 ) -> JaxSimModelData:
     """``js.model.step`` (``src/jaxsim/api/model.py:2601-2681``).
+
+    ``gravity_compensation=True`` (extension): the joint part of ``free_floating_gravity_forces`` of ``data`` is added
+    to ``joint_force_references`` -- what ``step(..., joint_force_references=gravity_compensation_torques(model, data) +
+    tau)`` computes, in one launch for the rigid contact models (``jxs_step_gravity_compensated``) and as those two
+    launches otherwise.
 
     ``link_forces`` ([N, nL, 6] or [nL, 6]) are expressed in ``data.velocity_representation``
     exactly like the reference (``:2641-2646``); ``joint_force_references`` is [N, n] or [n].
@@ -152,8 +158,18 @@ def step(
     f = _as_device(link_forces, nL * 6, N, data.dtype, (nL, 6), data._state.tile)
     tau = _as_device(joint_force_references, n, N, data.dtype, (n,), data._state.tile)
     out = data._state if inplace else DeviceArray(data._state.rows, N, data.dtype, tile=data._state.tile)
+    fn = _lib.load().jxs_step
+    if gravity_compensation:
+        from .. import specialize as _sp
+
+        if _sp.mode_of(model) in (_sp.MODE_STEP_RIGID, _sp.MODE_STEP_RK4_RIGID):
+            fn = _lib.load().jxs_step_gravity_compensated
+        else:  # soft contacts: g(q) through the host (no fused kernel for this mode), the user's references added to it
+            g = np.asarray(free_floating_gravity_forces(model, data))[..., 6:]
+            tau_np = g if joint_force_references is None else g + np.asarray(joint_force_references, dtype=g.dtype)
+            tau = _as_device(tau_np, n, N, data.dtype, (n,), data._state.tile)
     _lib.check(
-        _lib.load().jxs_step(
+        fn(
             dm.handle, C.c_void_p(data._state.ptr), C.c_void_p(out.ptr), _ptr(tau), _ptr(f),
             int(data.velocity_representation), N, runtime._sp(),
         ),

@@ -158,7 +158,7 @@ int create_typed(const jxs_model_desc* d, std::unique_ptr<ModelT<T>>& slot) {
 template <typename T>
 int run_typed(jxs_model* model, int mode, const void* state_in, void* state_out, const void* tau,
               const void* link_f, int force_repr, const void* in_a, void* out_a, void* out_H, void* out_V, int N,
-              int repeat, void* stream, void* out_tau, bool fuse) {
+              int repeat, void* stream, void* out_tau, bool fuse, int extra_flags) {
   ModelT<T>* mt = typed<T>(model);
   hipStream_t s = static_cast<hipStream_t>(stream);
   jxs::KArgs<T> a = mt->args(N);
@@ -180,6 +180,7 @@ int run_typed(jxs_model* model, int mode, const void* state_in, void* state_out,
     JXS_HIP(hipMemcpyAsync(state_out, state_in, sizeof(T) * elems, hipMemcpyDeviceToDevice, s));
   }
   a.dbg = g_dbg;
+  a.flags |= extra_flags;
   a.out_tau = static_cast<T*>(out_tau);  // jxs_gravity_torques: RNEA at zero velocity, joint torques only
   a.id_zero_vel = out_tau != nullptr ? 1 : 0;
   a.n_steps = 1;
@@ -206,16 +207,16 @@ int run_typed(jxs_model* model, int mode, const void* state_in, void* state_out,
 
 int run_any(jxs_model* model, int mode, const void* state_in, void* state_out, const void* tau, const void* link_f,
             int force_repr, const void* in_a, void* out_a, void* out_H, void* out_V, int N, int repeat,
-            void* stream, void* out_tau = nullptr, bool fuse = true) {
+            void* stream, void* out_tau = nullptr, bool fuse = true, int extra_flags = 0) {
   if (model == nullptr) return fail(JXS_EINVAL, "null model");
   if (state_in == nullptr) return fail(JXS_EINVAL, "null state");
   if (N <= 0) return fail(JXS_EINVAL, "N must be positive");
   if (force_repr < 0 || force_repr > 2) return fail(JXS_EINVAL, "invalid force representation");
   if (model->dtype == JXS_F64)
     return run_typed<double>(model, mode, state_in, state_out, tau, link_f, force_repr, in_a, out_a, out_H, out_V, N,
-                             repeat, stream, out_tau, fuse);
+                             repeat, stream, out_tau, fuse, extra_flags);
   return run_typed<float>(model, mode, state_in, state_out, tau, link_f, force_repr, in_a, out_a, out_H, out_V, N,
-                          repeat, stream, out_tau, fuse);
+                          repeat, stream, out_tau, fuse, extra_flags);
 }
 
 // ---- RCCL, resolved lazily so that the library loads (and the CPU symbol test passes)
@@ -544,6 +545,17 @@ int jxs_step(jxs_model* model, const void* state_in, void* state_out, const void
   if (state_out == nullptr) return fail(JXS_EINVAL, "null state_out");
   return run_any(model, jxs::MODE_STEP, state_in, state_out, tau, link_forces, force_repr, nullptr, nullptr, nullptr,
                  nullptr, N, 1, stream);
+}
+int jxs_step_gravity_compensated(jxs_model* model, const void* state_in, void* state_out, const void* tau,
+                                 const void* link_forces, int force_repr, int N, void* stream) {
+  if (state_out == nullptr) return fail(JXS_EINVAL, "null state_out");
+  if (model == nullptr) return fail(JXS_EINVAL, "null model");
+  const bool rigid = model->dtype == JXS_F64 ? (model->f64->pk.P.rigid != 0) : (model->f32->pk.P.rigid != 0);
+  if (!rigid)
+    return fail(JXS_EINVAL, "jxs_step_gravity_compensated: built for the rigid contact models (RigidContacts / RelaxedRigidContacts with "
+                            "enabled points); use jxs_gravity_torques + jxs_step");
+  return run_any(model, jxs::MODE_STEP, state_in, state_out, tau, link_forces, force_repr, nullptr, nullptr, nullptr, nullptr, N, 1,
+                 stream, nullptr, true, 2);
 }
 int jxs_rollout(jxs_model* model, void* state, const void* tau, const void* link_forces, int force_repr, int N,
                 int n_steps, void* stream) {

@@ -598,6 +598,12 @@ struct Core {
         tq = has_tau ? tq : V(T(0));
       }
       tau = vsel(is_joint, tq, V(T(0)));
+      if constexpr (kRigid) {
+        // [round 4] gravity-compensated step (jxs_step_gravity_compensated): tau_ref += g(q), the joint part of
+        // free_floating_gravity_forces (api/model.py:1897-1931) of the state the step starts from -- the controller
+        // loop "tau = g(q); step(tau)" of BASELINE config 5 in ONE launch (the kinematics are in registers anyway)
+        if (A.flags & 2) tau = tau + vsel(is_joint, gravity_tq(level, child, R, r, cL, mass, Sl, Sa), V(T(0)));
+      }
       if (kStep) {
         const V lower = vmin(s - smin, V(T(0)));  // clip(max=0)
         const V upper = vmax(s - smax, V(T(0)));  // clip(min=0)
@@ -2388,6 +2394,13 @@ struct Core {
   // subtree sums, tau_i = S_i . f_i.  MODE_GRAV: no velocity rows, no prefix sums, no rotated inertias.
   JXS_HD void gravity_torques(const VI& lane, const VI& jrow, const VI& level, const VI* child, const VM& is_joint,
                               const V* R, const V* r, const V* cL, const V& mass, const V* Sl, const V* Sa) const {
+    const V tq = gravity_tq(level, child, R, r, cL, mass, Sl, Sa);
+    if (A.out_tau != nullptr) ln.gstore(A.out_tau, jrow, tq, is_joint, P.n);
+    if (A.out_a != nullptr) ln.gstore(A.out_a, jrow + 6, tq, is_joint, 6 + P.n);
+  }
+  // (the value per joint lane: also used by the gravity-compensated step of the rigid contact modes, KArgs::flags bit 1)
+  JXS_HD V gravity_tq(const VI& level, const VI* child, const V* R, const V* r, const V* cL, const V& mass, const V* Sl,
+                      const V* Sa) const {
     const V zero = V(T(0));
     V cw[3];
     mat3vec(R, cL, cw);
@@ -2415,9 +2428,7 @@ struct Core {
         }
       }
     }
-    const V tq = Sl[2] * f3[0] + Sa[0] * f3[1] + Sa[1] * f3[2];
-    if (A.out_tau != nullptr) ln.gstore(A.out_tau, jrow, tq, is_joint, P.n);
-    if (A.out_a != nullptr) ln.gstore(A.out_a, jrow + 6, tq, is_joint, 6 + P.n);
+    return Sl[2] * f3[0] + Sa[0] * f3[1] + Sa[1] * f3[2];
   }
 
   // ==========================================================================================

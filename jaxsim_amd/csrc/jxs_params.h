@@ -311,7 +311,8 @@ struct KArgs {
   int id_zero_vel;     // MODE_ID: evaluate at zero velocity (gravity term g(q), api/model.py:1897-1931)
   long long* dbg;      // developer builds (-DJXS_PHASE_TIMING): [blocks][kDbgSlots] cycle stamps, else null
   int* faults;         // [2] environments whose QP contact-force solve / impact solve was discarded (non-finite), or null
-  int flags;           // developer switches of a launch: bit 0 = no MFMA in the contact solvers' Cholesky (A/B against the vector path)
+  int flags;           // switches of a launch: bit 0 = no MFMA in the contact solvers' Cholesky (developer A/B against the vector
+                       // path); bit 1 = gravity-compensated step of the rigid contact modes (tau_ref += g(q))
   int spec_consts;     // 1: the integer model flags of KParams are compile-time constants in this kernel (jxs_spec.hip)
   int knobs;           // host only: developer knobs of the launcher (KNOB_*), read from the environment ONCE by the
                        // library (jxs_api.hip debug_knobs; jxs_debug_reload_env re-reads them for the tests)

@@ -723,6 +723,35 @@ def test_config5_quadruped_rigid_contacts_with_gravity_compensation(models, redu
     np.testing.assert_array_equal(out24, out[:, :24])
 
 
+@pytest.mark.parametrize("kind,dtype", [("rigid", np.float32), ("rigid", np.float64), ("relaxed", np.float32), ("soft", np.float32)])
+def test_gravity_compensated_step_equals_the_two_launch_loop(models, reduced_qp, kind, dtype):
+    """[round 4] `step(..., gravity_compensation=True)` (C-ABI `jxs_step_gravity_compensated`): the controller loop of
+    BASELINE config 5, tau = g(q) (+ tau_user); step(tau), in one launch for the rigid contact models.  Same result as the
+    two launches up to the rounding of one addition, and the oracle's step with the oracle's gravity torques."""
+    base = models("anymal")
+    model = (helpers.rigid_model(base, helpers.ANYMAL_FEET_4, K=1e4, D=2e2) if kind == "rigid"
+             else helpers.relaxed_model(base, helpers.ANYMAL_FEET_16, mu=0.5) if kind == "relaxed" else base)
+    N = 70
+    d = models.random_data("anymal", N, seed=12, dtype=dtype)
+    rng = np.random.default_rng(3)
+    tau_user = rng.uniform(-2, 2, size=(N, model.dofs())).astype(dtype)
+    g = to_gpu(model, d)
+    gq = js.model.free_floating_gravity_forces(model, g)[:, 6:]
+    two = js.model.step(model, g, joint_force_references=(gq + tau_user).astype(dtype)).state_block()
+    one = js.model.step(model, to_gpu(model, d), joint_force_references=tau_user, gravity_compensation=True).state_block()
+    assert np.isfinite(one).all()
+    # (fp32: the torques differ in their last bit -- formed in registers here, read back from a block there -- and the
+    # interior-point iteration of the contact forces stops at solver_tol = 1e-3: measured 8.6e-5 on the specialised kernel)
+    tol = 1e-11 if dtype == np.float64 else 3e-4
+    assert helpers.rel_err(one, two) < tol
+    pure = js.model.step(model, to_gpu(model, d), gravity_compensation=True).state_block()
+    assert helpers.rel_err(pure, js.model.step(model, to_gpu(model, d), joint_force_references=gq.astype(dtype)).state_block()) < tol
+    d64 = helpers.upcast(d) if dtype == np.float32 else d
+    ref_tau = oracle.free_floating_gravity_forces(model, d64)[:, 6:] + tau_user.astype(np.float64)
+    ref = oracle.step(model, d64, joint_force_references=ref_tau)
+    assert helpers.rel_err(one, helpers.odata_to_block(model, ref)) < (1e-7 if dtype == np.float64 else 3e-3)
+
+
 # ---- RelaxedRigidContacts (rbda/contacts/relaxed_rigid.py; the model of the reference's own
 # test_simulation_step benchmark, tests/test_benchmark.py:142-152) ---------------------------------
 RELAXED_CASES = {
