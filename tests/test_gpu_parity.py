@@ -723,6 +723,31 @@ def test_config5_quadruped_rigid_contacts_with_gravity_compensation(models, redu
     np.testing.assert_array_equal(out24, out[:, :24])
 
 
+@pytest.mark.parametrize("n_links,seed,max_back", [(7, 31, 2), (12, 32, 3), (20, 33, 2), (5, 34, 1)])
+@pytest.mark.parametrize("kind", ["relaxed", "rigid"])
+def test_link_space_solve_on_random_trees_gpu(reduced_qp, kind, n_links, seed, max_back):
+    """[round 4] The link-space contact solve (jxs_rigid.inc ls_*) on random floating trees -- serial and branching, 5 to
+    20 links, mixed revolute / prismatic joints -- with both contact boxes (base and last link: two contact links, 16
+    points) enabled: RelaxedRigidContacts and RigidContacts in fp64 against the oracle, and RelaxedRigidContacts in fp32."""
+    from jaxsim_amd import robots, specialize
+
+    base = ja.JaxSimModel.build_from_model_description(robots.chain_urdf(n_links, fixed_base=False, seed=seed, max_back=max_back))
+    model = (helpers.relaxed_model(base, list(range(16)), mu=0.5) if kind == "relaxed" else helpers.rigid_model(base, list(range(16)), K=1e4, D=1e2))
+    assert "P.rl_n=2" in specialize.spec(model, np.float64, specialize.MODE_STEP_RIGID)
+    N = 9
+    d = oracle.random_model_data(model, batch_size=N, seed=seed, base_pos_bounds=((-1, -1, 0.0), (1, 1, 0.25)), base_rpy_bounds=((-0.4, -0.4, -3), (0.4, 0.4, 3)))
+    ref = helpers.odata_to_block(model, oracle.step(model, d))
+    out = js.model.step(model, to_gpu(model, d)).state_block()
+    assert helpers.rel_err(out, ref) < (1e-9 if kind == "relaxed" else 1e-7)
+    if kind == "relaxed":
+        d32 = oracle.random_model_data(model, batch_size=N, seed=seed, dtype=np.float32, base_pos_bounds=((-1, -1, 0.0), (1, 1, 0.25)),
+                                       base_rpy_bounds=((-0.4, -0.4, -3), (0.4, 0.4, 3)))  # fmt: skip
+        out32 = js.model.step(model, to_gpu(model, d32)).state_block()
+        err32 = helpers.rel_err(out32, helpers.odata_to_block(model, oracle.step(model, helpers.upcast(d32))))
+        helpers.note(f"linkspace_random_fp32/{n_links}", err32)
+        assert err32 < 2e-3
+
+
 @pytest.mark.parametrize("kind,dtype", [("rigid", np.float32), ("rigid", np.float64), ("relaxed", np.float32), ("soft", np.float32)])
 def test_gravity_compensated_step_equals_the_two_launch_loop(models, reduced_qp, kind, dtype):
     """[round 4] `step(..., gravity_compensation=True)` (C-ABI `jxs_step_gravity_compensated`): the controller loop of
