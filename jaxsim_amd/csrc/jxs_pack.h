@@ -69,6 +69,7 @@ std::string kernel_spec_string(const Packed<T>& pk, int mode) {
   add("jump_pad", P.jump_pad), add("jrow_seq", P.jrow_seq), add("prow_seq", P.prow_seq);
   add("rl_n", P.rl_n), add("rl_lane[0]", P.rl_lane[0]), add("rl_lane[1]", P.rl_lane[1]);
   add("rl_s0[0]", P.rl_s0[0]), add("rl_s1[0]", P.rl_s1[0]), add("rl_s0[1]", P.rl_s0[1]), add("rl_s1[1]", P.rl_s1[1]);
+  add("rl_merge", P.rl_merge);
   s.pop_back();
   return s;
 }
@@ -460,6 +461,30 @@ std::string pack_model(const jxs_model_desc& d, Packed<T>& out) {
   }
   P.rl_n = rl_n;
   for (int k = 0; k < 2; ++k) P.rl_lane[k] = k < rl_n ? lane_of[rl_body[k]] : 0, P.rl_s0[k] = rl_s0[k], P.rl_s1[k] = rl_s1[k];
+  // Merged sweeps for B (jxs_rigid.inc ls_build_B_merged): two contact links below DIFFERENT children of a floating base
+  // (the feet of a humanoid).  The unit wrenches on both links travel in one sweep up to level 1, the level-1 link of each
+  // solves the base acceleration itself, the cross blocks come from the records (force propagator = transpose of the
+  // acceleration propagator): two sweeps instead of four.  The per-lane table LI_RGPT (the point below a link lane of
+  // the merged Delassus sweeps, rg_merge) carries the contact link index below the lane instead.
+  P.rl_merge = 0;
+  if (rl_n == 2 && !P.rg_merge && d.floating_base && rl_linkspace(rl_n, n_en, P.rigid) && std::getenv("JXS_DISABLE_RL_MERGE") == nullptr) {  // developer knob: A/B
+    int l1[2] = {-1, -1};
+    bool ok = true;
+    for (int k = 0; k < 2 && ok; ++k) {
+      int a = rl_body[k];
+      if (level[a] < 1) ok = false;
+      while (ok && level[a] > 1) a = d.parent[a];
+      l1[k] = a;
+    }
+    if (ok && l1[0] != l1[1]) {
+      P.rl_merge = 1;
+      for (int k = 0; k < 2; ++k)
+        for (int a = rl_body[k];; a = d.parent[a]) {
+          I(LI_RGPT, lane_of[a]) = k;
+          if (level[a] == 1) break;
+        }
+    }
+  }
   for (int ch = 0; ch < n_chunks; ++ch) {
     int s = ch * G;
     const int end = std::min(n_en, (ch + 1) * G);

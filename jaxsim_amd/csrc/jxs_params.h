@@ -178,7 +178,10 @@ constexpr int kRlRowStride = 16, kRlPtRec = 12;
 JXS_HD constexpr int rl_lds_pt_off() { return 12 * kRlRowStride; }
 JXS_HD constexpr int rl_lds_vec_off(int n_cp) { return rl_lds_pt_off() + kRlPtRec * n_cp; }
 JXS_HD constexpr int rl_lds_sink_off(int n_cp) { return rl_lds_vec_off(n_cp) + 16; }  // 8 words nobody reads (lds_write*_sel)
-JXS_HD constexpr int rl_lds_words(int n_cp) { return rl_lds_sink_off(n_cp) + 8; }
+// merged sweeps (KParams::rl_merge): per contact link six wrenches handed to the base and six base accelerations, rows of 8 words
+constexpr int kRlMergeRec = 96;
+JXS_HD constexpr int rl_lds_merge_off(int n_cp) { return rl_lds_sink_off(n_cp) + 8; }
+JXS_HD constexpr int rl_lds_words(int n_cp) { return rl_lds_merge_off(n_cp) + 2 * kRlMergeRec; }
 // the model's contact problem is solved in link space (rl_n: contact links found eligible by the packer); RigidContacts
 // with <= 4 points keeps the row-distributed register solver (config 5)
 JXS_HD constexpr bool rl_linkspace(int rl_n, int n_cp, int rigid) { return rl_n > 0 && (rigid == 2 || (rigid == 1 && n_cp > 4)); }
@@ -278,6 +281,7 @@ struct KParams {
   // link's twist, J M^-1 J^T = P B P^T with B the inverse operational-space inertia of the contact links.  rl_n: number
   // of contact links (1 or 2; 0: the dense Delassus path), their lanes, and the slots [s0, s1) of their points.
   int rl_n, rl_lane[2], rl_s0[2], rl_s1[2];
+  int rl_merge;                  // the two contact links sit in different subtrees of a floating base: B from TWO merged sweeps (ls_build_B_merged)
   int jump_pad;                  // 1: pointer-jumping sources beyond the base point at a padding lane that holds the identity
                                  // transform and zero vectors (no selects in the rounds); 0: they are -1 (no padding lane: nL == G)
   // [round 3] The joint rows (and, with one point chunk of <= G collidable points, the deformation rows) of the state are
