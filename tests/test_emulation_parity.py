@@ -755,6 +755,31 @@ def test_link_space_solve_agrees_with_the_dense_path(models, reduced_qp, kind, k
         assert "P.rl_n=0" in specialize.spec(tight, np.float64, specialize.MODE_STEP_RIGID)
 
 
+@pytest.mark.parametrize("kind,key,dtype,tol", [("relaxed", "icub16", np.float64, 1e-12), ("relaxed", "icub16", np.float32, 5e-5), ("rigid", "icub8", np.float64, 1e-10)])  # fmt: skip
+def test_merged_link_space_sweeps_equal_the_four_sweep_form(models, kind, key, dtype, tol, monkeypatch):
+    """[round 4] Two contact links below different children of a floating base (the feet of a humanoid): `B` comes from
+    two merged tree sweeps (`KParams::rl_merge`, jxs_rigid.inc ls_fill_B_merged) -- the cross blocks from the records
+    the level-1 links keep -- instead of four.  Same matrix to rounding: the step agrees with the four-sweep form
+    (developer knob) and both with the oracle."""
+    from jaxsim_amd import specialize
+
+    table, make = (RIGID_CASES, helpers.rigid_model) if kind == "rigid" else (RELAXED_CASES, helpers.relaxed_model)
+    name, idx, params = table[key]
+    model = make(models(name), idx, **params)
+    d = models.random_data(name, 16, seed=5, dtype=dtype)
+    truth = helpers.odata_to_block(model, oracle.step(model, helpers.upcast(d) if dtype == np.float32 else d))
+    blk = helpers.odata_to_block(model, d)
+    assert "P.rl_merge=1" in specialize.spec(model, dtype, specialize.MODE_STEP_RIGID)
+    merged = eb.run(model, eb.MODE_STEP, blk)
+    monkeypatch.setenv("JXS_DISABLE_RL_MERGE", "1")
+    assert "P.rl_merge=0" in specialize.spec(model, dtype, specialize.MODE_STEP_RIGID)
+    four = eb.run(model, eb.MODE_STEP, blk)
+    assert helpers.rel_err(merged, four) < tol and not np.array_equal(merged, four)
+    # (RigidContacts at the default solver_tol = 1e-3: every path agrees with the oracle to the tolerance of the QP only)
+    ref_tol = max(tol, 2e-4 if dtype == np.float32 else 1e-11) if kind == "relaxed" else 1e-4
+    assert helpers.rel_err(merged, truth) < ref_tol and helpers.rel_err(four, truth) < ref_tol
+
+
 @pytest.mark.parametrize("fixed_base,max_back", [(True, 1), (False, 1), (False, 3)])
 def test_maximum_size_models(models, fixed_base, max_back):
     """The largest supported model: 64 links, one per lane of a full wave; a serial chain makes the tree
