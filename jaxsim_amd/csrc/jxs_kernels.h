@@ -43,8 +43,11 @@ struct KTail {
 // part of a model-specialised build (jxs_spec.hip) that needs no knowledge of the tree: 9.74 -> 8.55 us per
 // step for the 23-DoF humanoid where the full specialisation reaches 7.68 (tools/spec_split_experiment.py).
 enum KernelVariant : int { KV_GENERIC = 0, KV_OCC2 = 1, KV_COMMON = 2 };
+#ifndef JXS_MIN_WAVES
+#define JXS_MIN_WAVES 1  // experiment knob (JAXSIM_AMD_SPEC_EXTRA_FLAGS=-DJXS_MIN_WAVES=4): register budget for that many waves per SIMD
+#endif
 template <typename T, int G, int MODE, int VARIANT = KV_GENERIC>
-__global__ __launch_bounds__(64, VARIANT == KV_OCC2 ? 2 : 1) void jxs_kernel(const T* pre_state_in, T* pre_state_out, const unsigned char* __restrict__ pre_mblk,
+__global__ __launch_bounds__(64, VARIANT == KV_OCC2 ? 2 : JXS_MIN_WAVES) void jxs_kernel(const T* pre_state_in, T* pre_state_out, const unsigned char* __restrict__ pre_mblk,
                                                  const T* pre_tau, const T* pre_link_f, int pre_N, int pre_n_rows,
                                                  int pre_n, int pre_force_repr, int pre_n_steps,
                                                  const KTail<T> tail) {
