@@ -131,6 +131,7 @@ def parse_args():
     ap.add_argument("--model", default="icub23", choices=["icub23", "icub23_16", "anymal12", "cartpole"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="developer: run the multi-rank code path even with WORLD_SIZE=1")
+    ap.add_argument("--share-device", action="store_true", help="developer: ranks take device LOCAL_RANK %% device_count -- the N > 1 path on a box with fewer GPUs than ranks (RCCL refuses two ranks on one device: the host-side file collective takes over, `comm.kind` says so); the figure is not a scaling measurement")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=10.0)
     ap.add_argument("--saturated-envs", type=int, default=65536, help="secondary figure: batch that saturates one GPU (0 = skip)")
     ap.add_argument("--no-other-contact-models", action="store_true", help="skip the secondary RigidContacts / RelaxedRigidContacts figures")
@@ -638,7 +639,7 @@ def main():
     from jaxsim_amd import _lib, distributed, runtime
 
     runtime.require_device()
-    runtime.set_device(local_rank)
+    runtime.set_device(local_rank % runtime.device_count() if args.share_device else local_rank)
     # Multi-rank runs: RANK/LOCAL_RANK/WORLD_SIZE/MASTER_PORT come from torch.distributed.run; the
     # ranks rendezvous through a temp file and talk RCCL through the C-ABI library only.  (torch is
     # NOT imported: its wheel bundles a second ROCm runtime with the same sonames, and two HIP

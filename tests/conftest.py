@@ -23,8 +23,8 @@ KERNEL_POLICIES = {"library": "0", "specialised": "cached" if os.environ.get("JA
 
 
 def pytest_generate_tests(metafunc):
-    # tests/test_specialize.py chooses the policy itself, test by test
-    if metafunc.definition.get_closest_marker("gpu") and metafunc.module.__name__ != "test_specialize":
+    # tests/test_specialize.py chooses the policy itself, test by test; tests/test_bench_gpu.py runs bench.py (its own policy)
+    if metafunc.definition.get_closest_marker("gpu") and metafunc.module.__name__ not in ("test_specialize", "test_bench_gpu"):
         metafunc.parametrize("kernel_policy", list(KERNEL_POLICIES), indirect=True)
 
 
