@@ -585,7 +585,7 @@ struct Core {
       for (int k = 0; k < 3; ++k) ps0.md[k] = mdl[k];
       link_wrench_sums(lane, ps0.tail, ps0.hd, w6, fl, fa);
     } else
-    if (with_contacts) contacts(lane, ps0, R, r, vl, va, ra, pB, doff, vBc, om, fl, fa);  // sets ps0.md
+    if (with_contacts) contacts<kRK4>(lane, ps0, R, r, vl, va, ra, pB, doff, vBc, om, fl, fa, stage);  // sets ps0.md
     ln.stamp(A, 5);  // contacts
 
     // ---- B: joint torques (api/actuation_model.py:7-126): once per step, from the state the step starts from (stage 0
@@ -2345,14 +2345,27 @@ struct Core {
   // by run()); further chunks go through memory every step (rollouts are not fused then).  Two separate
   // instantiations instead of one loop that selects between `ps0` and a local slot: the select would be a
   // pointer phi that keeps the slot structs in scratch memory.
-  template <bool kFirst>
+  // [round 4] kStages (RungeKutta4, chunks behind the first): ps.m is the deformation of the state the step starts
+  // from (read from memory at every stage); the stage's deformation is m0 + h * (rate of the previous stage), the new
+  // state m0 + dt/6 * (k1 + 2 k2 + 2 k3 + k4) is stored at the last stage (api/integrators.py:91-167).  The rate of
+  // the previous stage and the weighted sum live in the LDS, eight words per slot (`sc`: word offset of this lane's
+  // slot), touched by the slot's own lane only -- no synchronisation beyond program order.
+  template <bool kFirst, bool kStages = false>
   JXS_HD void contact_chunk(const VI& lane, PointSlot& ps, const V* R, const V* r, const V* vl, const V* va,
-                            const V* ra, const V* pB, const V* doff, const V* vBc, const V* om, V* fl, V* fa) const {
+                            const V* ra, const V* pB, const V* doff, const V* vBc, const V* om, V* fl, V* fa,
+                            int stage = 0, const VI* sc = nullptr) const {
     const V zero = V(T(0));
     const VM valid = ps.body >= 0;
-    V m[3];
+    V m[3], m0[3], ksum[3] = {zero, zero, zero};
 #pragma unroll
-    for (int k = 0; k < 3; ++k) m[k] = vsel(valid, ps.m[k], zero);
+    for (int k = 0; k < 3; ++k) m[k] = m0[k] = vsel(valid, ps.m[k], zero);
+    if (kStages && stage > 0) {
+      V s6[kRk4SlotWords];
+      ln.template lds_readv<kRk4SlotWords>(*sc, s6);
+      const V h = V(stage == 3 ? P.dt : P.dt * T(0.5));  // euler_mid, euler_mid, euler_fin
+#pragma unroll
+      for (int k = 0; k < 3; ++k) m[k] = m0[k] + h * s6[k], ksum[k] = s6[3 + k];
+    }
     // kinematics of the parent link
     V Rb[9], rb[3], vbl[3], vba[3], rab[3];
 #pragma unroll
@@ -2367,22 +2380,39 @@ struct Core {
     ln.fence();
     V w6[6], md[3];
     point_physics(valid, ps.Lp, m, Rb, rb, vbl, vba, rab, pB, doff, vBc, om, w6, md);
+    if (kStages) {
+      const T wgt = (stage == 0 || stage == 3) ? T(1) : T(2);
+      V s6[kRk4SlotWords];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) s6[k] = md[k], s6[3 + k] = ksum[k] + wgt * md[k];
+      s6[6] = s6[7] = zero;
+      if (stage < 3) {
+        ln.template lds_writev<kRk4SlotWords>(*sc, s6);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+          ln.gstore(A.state_out, ps.prow * 3 + (P.row_m + k), m0[k] + (P.dt * T(1.0 / 6.0)) * s6[3 + k], valid, P.n_rows);
+      }
+    } else {
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       if (kFirst) ps.md[k] = md[k];
       else ln.gstore(A.state_out, ps.prow * 3 + (P.row_m + k), m[k] + P.dt * md[k], valid, P.n_rows);
     }
+    }
     link_wrench_sums(lane, ps.tail, ps.hd, w6, fl, fa);
   }
 
+  template <bool kStages = false>
   JXS_HD void contacts(const VI& lane, PointSlot& ps0, const V* R, const V* r, const V* vl, const V* va,
-                       const V* ra, const V* pB, const V* doff, const V* vBc, const V* om, V* fl, V* fa) const {
+                       const V* ra, const V* pB, const V* doff, const V* vBc, const V* om, V* fl, V* fa, int stage = 0) const {
     contact_chunk<true>(lane, ps0, R, r, vl, va, ra, pB, doff, vBc, om, fl, fa);  // sets ps0.md
     for (int ch = 1; ch < P.n_chunks; ++ch) {
       PointSlot ps;
       load_slot_tables(lane, ch, ps);
       load_slot_state(ps);
-      contact_chunk<false>(lane, ps, R, r, vl, va, ra, pB, doff, vBc, om, fl, fa);
+      const VI sc = (lane + (ch - 1) * G) * kRk4SlotWords + rk4_chunk_off(G);
+      contact_chunk<false, kStages>(lane, ps, R, r, vl, va, ra, pB, doff, vBc, om, fl, fa, stage, &sc);
     }
   }
 

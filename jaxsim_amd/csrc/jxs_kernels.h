@@ -95,6 +95,7 @@ __global__ __launch_bounds__(64, VARIANT == KV_OCC2 ? 2 : JXS_MIN_WAVES) void jx
   extern __shared__ __align__(16) unsigned char jxs_smem[];
   const jxs::DeviceLanes<T, G> ln(A.N, reinterpret_cast<T*>(jxs_smem),
                                   (MODE == jxs::MODE_STEP_RIGID || MODE == jxs::MODE_STEP_RK4_RIGID) ? jxs::rigid_lds_words_per_env(P.n_cp, P.rigid, P.rl_n)
+                                  : MODE == jxs::MODE_STEP_RK4 ? jxs::rk4_lds_words_per_env(G, P.n_chunks)
                                                                : jxs::lds_words_per_env(G));
   jxs::Core<jxs::DeviceLanes<T, G>> core(P, A, ln);
   core.template run<MODE>();
@@ -153,6 +154,8 @@ hipError_t launch_one(const jxs::KParams<T>& P, const unsigned char* mblk, const
   const bool rows = P.row_mode && (MODE == jxs::MODE_STEP || MODE == jxs::MODE_ROLLOUT || MODE == jxs::MODE_FD ||
                                    MODE == jxs::MODE_STEP_RK4);
   size_t lds_bytes = rows ? sizeof(T) * (size_t)envs_per_wave * jxs::lds_words_per_env(G) : 0;
+  // RungeKutta4 with several point chunks keeps its per-slot stage data in the LDS (jxs_params.h rk4_lds_words_per_env)
+  if (MODE == jxs::MODE_STEP_RK4 && P.n_chunks > 1) lds_bytes = sizeof(T) * (size_t)envs_per_wave * jxs::rk4_lds_words_per_env(G, P.n_chunks);
   // (developer knobs arrive in A.knobs: the library reads the environment once, jxs_api.hip debug_knobs -- no getenv on the
   // launch path, no race with a Python thread that edits os.environ)
   const KTail<T> tail{A.in_a, A.out_a, A.out_H, A.out_V, A.out_tau, A.id_zero_vel, A.dbg, A.faults,

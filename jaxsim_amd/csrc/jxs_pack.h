@@ -145,8 +145,13 @@ std::string pack_model(const jxs_model_desc& d, Packed<T>& out) {
   P.n_points = d.n_points;
   P.n_slots = n_slots;
   P.n_chunks = n_chunks;
-  if (d.integrator != JXS_INTEGRATOR_SEMI_IMPLICIT_EULER && n_chunks > 1)
-    return "RungeKutta4 needs every enabled collidable point in one lane group (at most 64 points)";
+  if (d.integrator != JXS_INTEGRATOR_SEMI_IMPLICIT_EULER && n_chunks > 1) {
+    // [round 4] SoftContacts: the chunks behind the first keep their stage data in the LDS (jxs_core.h contact_chunk)
+    if (d.contact_model != JXS_CONTACT_SOFT)
+      return "RungeKutta4 with a rigid contact model needs every enabled collidable point in one lane group (at most 64 points)";
+    if (sizeof(T) * (size_t)(64 / G) * (size_t)rk4_lds_words_per_env(G, n_chunks) > (size_t)64 * 1024)
+      return "RungeKutta4: the stage data of the collidable points exceed 64 KB of LDS per wave (several hundred points)";
+  }
   if (d.contact_model != JXS_CONTACT_SOFT && d.contact_model != JXS_CONTACT_RIGID &&
       d.contact_model != JXS_CONTACT_RELAXED_RIGID)
     return "unknown contact model";

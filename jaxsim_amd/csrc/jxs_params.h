@@ -142,6 +142,16 @@ JXS_HD constexpr int lds_kin_offset(int) { return 0; }
 // zeros from it instead of selecting them (nine v_cndmask per level saved)
 JXS_HD constexpr int lds_zero_rec(int G) { return G * kRowRec + 48; }
 JXS_HD constexpr int lds_words_per_env(int G) { return (lds_zero_rec(G) + kRowRec + 3) / 4 * 4; }
+// [round 4] RungeKutta4 with more collidable points than lanes (SoftContacts): the points of the chunks behind the first
+// go through memory at every stage (jxs_core.h contact_chunk); what RungeKutta4 carries between its stages for them --
+// the deformation rate of the previous stage (3 words) and the weighted sum of the rates (3) -- sits in the LDS
+// behind the area of the row layout, eight words per slot (six used: 128-bit LDS accesses want 16-byte alignment),
+// written and read by the slot's own lane only
+constexpr int kRk4SlotWords = 8;
+JXS_HD constexpr int rk4_chunk_off(int G) { return lds_words_per_env(G); }
+JXS_HD constexpr int rk4_lds_words_per_env(int G, int n_chunks) {
+  return lds_words_per_env(G) + (n_chunks > 1 ? (n_chunks - 1) * G * kRk4SlotWords : 0);
+}
 // ---- two-wave workgroups: the inertia wave and the main wave work on the same
 // environments; per environment the LDS holds
 //   [0, W)        the inertia wave's records, base rows and zero record (the single-wave layout above)

@@ -363,18 +363,61 @@ def test_config1_double_pendulum_from_sdf(models):
     np.testing.assert_allclose(helpers.odata_to_block(model, ref), helpers.odata_to_block(models("double_pendulum"), ref_urdf), atol=1e-12)
 
 
-def test_rk4_needs_one_chunk_of_points(models):
-    """More enabled points than lanes of a group would need a second contact pass per stage:
-    rejected at model creation (documented limit), not silently integrated with Euler."""
+def _icub80():
+    import jaxsim_amd as ja
+    from jaxsim_amd import robots
+
+    return ja.JaxSimModel.build_from_model_description(robots.icub23_urdf(sole_boxes_per_foot=5))  # 80 points on two links
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-10), (np.float32, 2e-4)])
+def test_rk4_with_more_points_than_lanes(models, dtype, tol):
+    """[round 4] RungeKutta4 with several chunks of collidable points (SoftContacts): the points behind the first
+    chunk go through memory at every stage, their stage data (rate of the previous stage, weighted sum of the rates)
+    sit in the LDS (jxs_core.h contact_chunk).  80 points on a 24-link humanoid: 32 lanes, three chunks.  Against the
+    oracle, one step and a short rollout (in place: the deformation rows are read at every stage and written at the last)."""
+    model = _rk4(_icub80())
+    lay = eb.layout(model)
+    assert lay.group == 32 and lay.n_points == 80
+    N = 6
+    d = oracle.random_model_data(model, batch_size=N, seed=3, dtype=dtype, base_pos_bounds=((-1, -1, 0.56), (1, 1, 0.66)),
+                                 base_rpy_bounds=((-0.3, -0.3, -3), (0.3, 0.3, 3)))  # fmt: skip
+    rng = np.random.default_rng(5)
+    d.tangential_deformation[:] = (1e-3 * rng.normal(size=d.tangential_deformation.shape)).astype(dtype)
+    tau, f = helpers.random_inputs(model, N, 7, dtype)
+    kw = dict(link_forces=f.astype(np.float64), joint_force_references=tau.astype(np.float64))
+    ref = oracle.step(model, helpers.upcast(d), **kw)
+    blk = helpers.odata_to_block(model, d)
+    run = dict(tau=tau.T, link_forces=f.reshape(N, -1).T, force_repr=REPR_CODE[d.velocity_representation])
+    out = eb.run(model, eb.MODE_STEP, blk, **run)
+    truth = helpers.odata_to_block(model, ref)
+    assert helpers.rel_err(out, truth) < tol
+    # the deformation rows of the LAST chunk moved, and not by the Euler rule
+    lay_rows = slice(truth.shape[0] - 3 * 16, truth.shape[0])
+    assert np.abs(out[lay_rows] - blk[lay_rows]).max() > 0
+    euler = helpers.odata_to_block(model, oracle.step(helpers.with_params(model, integrator=0), helpers.upcast(d), **kw))
+    assert helpers.rel_err(euler, truth) > 1e-7
+    if dtype == np.float64:
+        ref3 = helpers.upcast(d)
+        for _ in range(3):
+            ref3 = oracle.step(model, ref3, **kw)
+        out3 = eb.run(model, eb.MODE_STEP, blk, n_steps=3, **run)
+        assert helpers.rel_err(out3, helpers.odata_to_block(model, ref3)) < 1e-9
+
+
+def test_rk4_point_limits(models):
+    """One lane per point up to 64 points (a group of 64 lanes), chunks beyond; the rigid contact models and an LDS
+    budget still bound RungeKutta4 (documented limits, rejected at model creation)."""
     import jaxsim_amd as ja
     from jaxsim_amd import robots
 
     mid = ja.JaxSimModel.build_from_model_description(robots.icub23_urdf(sole_boxes_per_foot=3))  # 48 points
     assert eb.layout(mid).group == 32 and eb.layout(_rk4(mid)).group == 64  # RK4: one lane per point
-    big = ja.JaxSimModel.build_from_model_description(robots.icub23_urdf(sole_boxes_per_foot=5))  # 80 points
-    assert eb.layout(big).n_points > 64  # fine with the Euler integrator
-    with pytest.raises(RuntimeError, match="RungeKutta4"):
-        eb.layout(_rk4(big))
+    big = _icub80()
+    assert eb.layout(big).n_points > 64 and eb.layout(_rk4(big)).group == 32  # three chunks of 32
+    rigid = helpers.with_params(helpers.rigid_model(big, list(range(80)), K=1e4, D=2e2), integrator=ja.IntegratorType.RungeKutta4)
+    with pytest.raises(RuntimeError, match="one lane group"):
+        eb.layout(rigid)
     with pytest.raises(RuntimeError, match="unsupported integrator"):
         eb.layout(helpers.with_params(models("box"), integrator=7))
 

@@ -401,6 +401,32 @@ def test_rk4_step_matches_oracle_gpu(models, name, dtype):
     assert helpers.rel_err(out.state_block(), helpers.odata_to_block(model, ref)) < helpers.tol_of(dtype, name)
 
 
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-10), (np.float32, 2e-4)])
+def test_rk4_with_more_points_than_lanes_gpu(models, dtype, tol):
+    """[round 4] RungeKutta4 + SoftContacts with 80 collidable points on 32 lanes: three chunks, the stage data of the
+    chunks behind the first in the LDS (jxs_core.h contact_chunk); one step against the oracle, then ten in place
+    (the deformation rows are read at every stage and written at the last) -- was refused up to round 3."""
+    from jaxsim_amd import robots
+
+    model = _rk4(ja.JaxSimModel.build_from_model_description(robots.icub23_urdf(sole_boxes_per_foot=5)))
+    N = 37
+    d = oracle.random_model_data(model, batch_size=N, seed=3, dtype=dtype, base_pos_bounds=((-1, -1, 0.56), (1, 1, 0.66)),
+                                 base_rpy_bounds=((-0.3, -0.3, -3), (0.3, 0.3, 3)))  # fmt: skip
+    rng = np.random.default_rng(5)
+    d.tangential_deformation[:] = (1e-3 * rng.normal(size=d.tangential_deformation.shape)).astype(dtype)
+    tau, f = helpers.random_inputs(model, N, 7, dtype)
+    kw = dict(link_forces=f.astype(np.float64), joint_force_references=tau.astype(np.float64))
+    ref = oracle.step(model, helpers.upcast(d), **kw)
+    out = js.model.step(model, to_gpu(model, d), link_forces=f, joint_force_references=tau)
+    assert helpers.rel_err(out.state_block(), helpers.odata_to_block(model, ref)) < tol
+    if dtype == np.float64:
+        ref10 = d
+        for _ in range(10):
+            ref10 = oracle.step(model, ref10)
+        out10 = js.model.rollout(model, to_gpu(model, d), 10).state_block()
+        assert helpers.rel_err(out10, helpers.odata_to_block(model, ref10)) < 1e-8
+
+
 @pytest.mark.parametrize("rep", [VelRepr.Inertial, VelRepr.Body, VelRepr.Mixed])
 def test_rk4_link_force_representations_gpu(models, rep):
     model = _rk4(models("icub"))
