@@ -399,7 +399,9 @@ def timed_repetitions(timed_region, run_steps, steps, reps, stream, barrier, lib
     stream synchronisation on both sides and timed with the host wall clock; the synchronisation waits poll
     (a blocking wait adds its wake-up latency, comparable to the whole region when `steps` is small), and
     the bracket itself runs inside ONE C call (`jxs_step_repeat_timed`: sync, clock, launches, sync, clock) so
-    that no interpreter overhead sits inside the region.  Alternate repetitions take HIP events on the launch
+    that no interpreter overhead sits inside the region; [round 4] the closing synchronisation polls a word in pinned
+    host memory that the stream writes behind the last launch (hipStreamWriteValue32) instead of calling
+    hipStreamQuery in a loop: the host sees the end ~2 us sooner (12 instead of 14 us of bracket per region).  Alternate repetitions take HIP events on the launch
     stream instead (the two event records would otherwise sit inside the wall-clock region)."""
     from jaxsim_amd import _lib, runtime
 
@@ -837,7 +839,7 @@ def main():
                 f"semi-implicit Euler dt=1e-3, nL={lay.n_links} n={n} n_cp={n_cp}, "
                 f"{n_local} envs per GPU x {world} GPU(s) = {n_total} envs, one step kernel launch per step (jxs_step_repeat: hipGraph replays of blocks of 250 / 50 launches captured during warm-up, fewer than 50 launched plainly)",
                 "note_on_value": "`value` is the wall clock of the median timed region of exactly --steps launches, launch and "
-                "synchronisation latency of the region included (~11 us per region: 7 % at --steps 20, 0.1 % at 2000); "
+                "synchronisation latency of the region included (~12 us per region: 9 % at --steps 20, 0.1 % at 2000); "
                 "`steady_state` is the same launch path measured over >= 2000 launches",
                 "envs_per_gpu": n_local,
                 "global_batch": n_total,

@@ -5,6 +5,7 @@
 // single-wave workgroups, i.e. two waves on each of the 256 CUs, placed by the dispatcher on
 // different SIMDs; all cross-lane traffic is wavefront shuffles, no LDS allocation, no
 // barriers.
+#include <cstdint>
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
@@ -637,7 +638,31 @@ int jxs_step_repeat_timed(jxs_model* model, void* state, const void* tau, const 
   const auto t0 = std::chrono::steady_clock::now();
   rc = jxs_step_repeat(model, state, tau, link_forces, force_repr, N, n_launches, stream);
   if (rc != JXS_OK) return rc;
-  rc = jxs_stream_wait_spin(stream);      // ... and ends when the last launch has completed
+  // ... and ends when the last launch has completed.  The host learns of it from a word in pinned host memory that the
+  // stream writes behind the last launch (hipStreamWriteValue32) and this thread polls -- no runtime call inside the
+  // wait (JXS_TIMED_WAIT_QUERY=1: poll hipStreamQuery instead, the round-3 bracket; developer knob, A/B)
+  static const bool by_query = std::getenv("JXS_TIMED_WAIT_QUERY") != nullptr;
+  static thread_local volatile uint32_t* flag = nullptr;
+  static thread_local uint32_t seq = 0;
+  if (!by_query && flag == nullptr) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, 64, hipHostMallocDefault) == hipSuccess) {
+      flag = static_cast<volatile uint32_t*>(p);
+      *flag = 0;
+    }
+  }
+  bool polled = false;
+  if (!by_query && flag != nullptr && stream != nullptr) {
+    const uint32_t want = ++seq;
+    if (hipStreamWriteValue32(static_cast<hipStream_t>(stream), const_cast<uint32_t*>(flag), want, 0) == hipSuccess) {
+      while (*flag != want) {
+      }
+      polled = true;
+    } else {
+      (void)hipGetLastError();
+    }
+  }
+  if (!polled) rc = jxs_stream_wait_spin(stream);
   *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   return rc;
 }
