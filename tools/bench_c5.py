@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--dtype", default="float32")
     ap.add_argument("--contact", default="rigid", choices=["rigid", "relaxed"])
+    ap.add_argument("--default-params", action="store_true", help="relaxed: the reference's default RelaxedRigidContactsParams (mu = 0.005) instead of estimate_good_contact_parameters")
     args = ap.parse_args()
 
     import helpers  # tests/helpers.py: model zoo + rigid_model
@@ -46,7 +47,8 @@ def main():
         model = helpers.rigid_model(zoo(robot), idx, K=1e4, D=2e2)
     else:
         model = helpers.relaxed_model(zoo(robot), idx)
-        model = helpers.with_params(model, contact_params=js.contact.estimate_good_contact_parameters(model))
+        if not args.default_params:
+            model = helpers.with_params(model, contact_params=js.contact.estimate_good_contact_parameters(model))
     dtype = np.dtype(args.dtype)
     if args.standing:
         d = helpers.standing_data(model, args.envs, seed=0, dtype=dtype, noise=0.003)
