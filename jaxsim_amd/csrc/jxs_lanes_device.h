@@ -19,7 +19,15 @@ __device__ __forceinline__ float vrcp(float x) {
   const float r = __builtin_amdgcn_rcpf(x);
   return __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);  // one Newton step
 }
-__device__ __forceinline__ double vrcp(double x) { return 1.0 / x; }
+// [round 4] fp64: v_rcp_f64 (24 good bits) and two Newton steps -- 5 instructions, 0 ulp from 1.0 / x over 1e6 random
+// arguments (tools/ubench/rcp64.hip, profiles/r04_experiments.md) -- instead of the compiler's correctly rounded
+// division (div_scale, rcp, six fma, div_fmas, div_fixup: ~14).  Like the fp32 form it returns NaN, not infinity, for
+// x = 0: every caller guards its argument or discards that lane (the same code runs in fp32).
+__device__ __forceinline__ double vrcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+  return __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+}
 // 1 / x to half an ulp (a second, residual-based Newton step): the joint accelerations of the ABA are
 // (u - U'a) / d with values of 1e4 rad/s^2 on the contact links, where the ~1.5 ulp of vrcp is a step error of
 // 1e-6 on its own (measured: GPU median 1.4e-6 against 5e-7 in IEEE emulation)
@@ -27,7 +35,7 @@ __device__ __forceinline__ float vrcp_acc(float x) {
   const float r = vrcp(x);
   return __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
 }
-__device__ __forceinline__ double vrcp_acc(double x) { return 1.0 / x; }
+__device__ __forceinline__ double vrcp_acc(double x) { return vrcp(x); }
 __device__ __forceinline__ float vsqrt(float x) {
   // x * rsq(x) with one Newton step; exact zeros stay zero
   const float y = __builtin_amdgcn_rsqf(x);
@@ -36,14 +44,26 @@ __device__ __forceinline__ float vsqrt(float x) {
   const float r = __builtin_fmaf(0.5f * y, e, s);
   return x > 0.0f ? r : x;
 }
-__device__ __forceinline__ double vsqrt(double x) { return sqrt(x); }
+__device__ __forceinline__ double vrsqrt(double x);
+__device__ __forceinline__ double vsqrt(double x) {
+  // x * rsqrt(x) and one residual step; exact zeros (and negative arguments, as sqrt's NaN is never used) stay as they are
+  const double y = vrsqrt(x);
+  const double s = x * y;
+  const double r = __builtin_fma(0.5 * y, __builtin_fma(-s, s, x), s);
+  return x > 0.0 ? r : x;
+}
 // 1 / sqrt(x), x > 0: hardware rsq and one Newton step (4 instructions instead of the 10 of vrcp(vsqrt(x)))
 __device__ __forceinline__ float vrsqrt(float x) {
   const float y = __builtin_amdgcn_rsqf(x);
   const float e = __builtin_fmaf(-x * y, y, 1.0f);
   return __builtin_fmaf(0.5f * y, e, y);
 }
-__device__ __forceinline__ double vrsqrt(double x) { return 1.0 / sqrt(x); }
+// fp64: v_rsq_f64 and two Newton steps (3.4 ulp worst over 1e6 random arguments, tools/ubench/rcp64.hip)
+__device__ __forceinline__ double vrsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  y = y * __builtin_fma(-0.5 * x * y, y, 1.5);
+  return y * __builtin_fma(-0.5 * x * y, y, 1.5);
+}
 __device__ __forceinline__ float vabs(float x) { return __builtin_fabsf(x); }
 __device__ __forceinline__ double vabs(double x) { return fabs(x); }
 __device__ __forceinline__ float vmin(float a, float b) { return fminf(a, b); }
