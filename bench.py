@@ -762,6 +762,24 @@ def main():
     runtime.synchronize(stream)
     _lib.check(rc, "jxs_rollout")
     rollout_ms_per_step = ev2.elapsed_ms(ev3) / k_roll
+    # ... and with a SEQUENCE of joint torques, one block per step (jxs_rollout_controlled: jax.lax.scan over step with
+    # precomputed joint_force_references -- open-loop rollouts): one more load per step inside the same fused launch
+    controlled_us = None
+    try:
+        n_j = model.dofs()
+        seq_host = np.random.default_rng(3).uniform(-1.0, 1.0, size=(k_roll * n_j, n_local))
+        seq = runtime.DeviceArray.from_host(seq_host, tile=data._state.tile, dtype=dtype)
+        _lib.check(lib.jxs_rollout_controlled(dm.handle, state_ptr, C.c_void_p(seq.ptr), None, 2, n_local, k_roll, stream.handle), "jxs_rollout_controlled")
+        runtime.synchronize(stream)
+        ev4, ev5 = runtime.Event(), runtime.Event()
+        ev4.record(stream)
+        _lib.check(lib.jxs_rollout_controlled(dm.handle, state_ptr, C.c_void_p(seq.ptr), None, 2, n_local, k_roll, stream.handle), "jxs_rollout_controlled")
+        ev5.record(stream)
+        runtime.synchronize(stream)
+        controlled_us = ev4.elapsed_ms(ev5) / k_roll * 1e3
+        del seq
+    except Exception as e:  # secondary: never lose the headline for it
+        controlled_us = repr(e)
 
     # secondary figure: the same kernel with the chip saturated (64 Ki environments on this GPU) -- what
     # the step costs once enough waves hide each other's latencies.  Not the headline configuration.
@@ -886,7 +904,9 @@ def main():
             "steady_state": steady,
             "generic_kernel": generic,
             "fused_rollout": {"us_per_step": rollout_ms_per_step * 1e3, "env_steps_per_s_rank0": n_local / (rollout_ms_per_step * 1e-3),
-                              "note": "same steps as one jxs_rollout launch; secondary figure, not `value`"},
+                              "controlled_us_per_step": controlled_us,
+                              "note": "same steps as one jxs_rollout launch; `controlled`: with one block of joint torques per step "
+                                      "(jxs_rollout_controlled); secondary figures, not `value`"},
         }
         if saturated is not None:
             if "env_steps_per_s" in saturated:

@@ -192,6 +192,16 @@ int jxs_step_repeat_timed(jxs_model* model, void* state, const void* tau, const 
 int jxs_rollout(jxs_model* model, void* state, const void* tau, const void* link_forces,
                 int force_repr, int N, int n_steps, void* stream);
 
+/* [round 4] `n_steps` consecutive steps with a SEQUENCE of joint torques -- what a `jax.lax.scan` of `step` over
+ * precomputed `joint_force_references` does (open-loop rollouts: trajectory sampling, MPPI); in place.
+ * `tau_seq` = [n_steps * n][N] in the usual [row][N] convention: rows k*n .. (k+1)*n-1 are the torques of step k
+ * (the actuation model is applied to them at every step, like `step`).  `link_forces` stay constant.  Where the
+ * steps fuse (semi-implicit Euler, SoftContacts, one chunk of collidable points) this is ONE launch with the state in
+ * registers and one torque load per step; otherwise one launch per step, the step's torques gathered by a strided
+ * device copy.                                                                                  */
+int jxs_rollout_controlled(jxs_model* model, void* state, const void* tau_seq, const void* link_forces,
+                           int force_repr, int N, int n_steps, void* stream);
+
 /* forward_dynamics_aba (src/jaxsim/api/model.py:1269-1406) in inertial representation:
  * out_acc = [6+n][N] = inertial-fixed base acceleration then joint accelerations.
  * `joint_forces` are applied as given (no actuation model), no contact forces.          */

@@ -185,13 +185,35 @@ def step(
 
 def rollout(model: JaxSimModel, data: JaxSimModelData, n_steps: int, *, link_forces=None,
             joint_force_references=None) -> JaxSimModelData:  # fmt: skip
-    """``n_steps`` back-to-back steps with constant inputs (what ``jax.lax.fori_loop`` over
-    ``step`` does in the reference's notebooks); the input data is not modified."""
+    """``n_steps`` back-to-back steps (what ``jax.lax.fori_loop`` / ``jax.lax.scan`` over ``step`` does in the
+    reference's notebooks); the input data is not modified.  ``joint_force_references``: constant over the steps
+    (``[N, n]`` / ``[n]``), or -- [round 4] -- a SEQUENCE ``[n_steps, N, n]`` (``[n_steps, n]`` for one environment):
+    step ``k`` applies ``joint_force_references[k]`` (``jxs_rollout_controlled``: one launch with the state in
+    registers where the steps fuse)."""
     dm = runtime.device_model(model, data.dtype)
     N, nL, n = data.batch_size, model.number_of_links(), model.dofs()
     f = _as_device(link_forces, nL * 6, N, data.dtype, (nL, 6), data._state.tile)
-    tau = _as_device(joint_force_references, n, N, data.dtype, (n,), data._state.tile)
     out = data._state.copy()
+    seq = None
+    if joint_force_references is not None and not isinstance(joint_force_references, DeviceArray) and \
+            getattr(joint_force_references, "__cuda_array_interface__", None) is None:
+        a = np.asarray(joint_force_references, dtype=np.float64)
+        if a.ndim == 3 or (a.ndim == 2 and N == 1 and n > 0 and a.shape == (int(n_steps), n) and int(n_steps) != N):
+            a = a.reshape(int(n_steps), N, n) if a.ndim == 2 else a
+            if a.shape != (int(n_steps), N, n):
+                raise ValueError((a.shape, (int(n_steps), N, n)))
+            # rows k * n + j of the [n_steps * n][N] block: torque of joint j at step k
+            seq = DeviceArray.from_host(np.ascontiguousarray(a.transpose(0, 2, 1).reshape(int(n_steps) * n, N)), tile=data._state.tile, dtype=data.dtype)
+    if seq is not None and n > 0 and int(n_steps) > 0:
+        _lib.check(
+            _lib.load().jxs_rollout_controlled(
+                dm.handle, C.c_void_p(out.ptr), C.c_void_p(seq.ptr), _ptr(f), int(data.velocity_representation), N,
+                int(n_steps), runtime._sp(),
+            ),
+            "jxs_rollout_controlled",
+        )  # fmt: skip
+        return JaxSimModelData(model, out, data.velocity_representation, data._batched)
+    tau = _as_device(joint_force_references, n, N, data.dtype, (n,), data._state.tile)
     _lib.check(
         _lib.load().jxs_rollout(
             dm.handle, C.c_void_p(out.ptr), _ptr(tau), _ptr(f), int(data.velocity_representation), N,

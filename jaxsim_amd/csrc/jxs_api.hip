@@ -100,6 +100,8 @@ struct ModelT {
   SpecLaunch spec_launch[16] = {};
   void* spec_handle[16] = {};
   int* faults = nullptr;  // [2] discarded contact-force / impact solves since the last reset (rigid contact models)
+  void* tau_scratch = nullptr;  // jxs_rollout_controlled, one launch per step: the torques of the current step, [n][N]
+  size_t tau_scratch_bytes = 0;
 
   ~ModelT() {
     // The specialised-kernel objects are NOT unloaded (attach_typed): launches of this model may still be in
@@ -108,6 +110,7 @@ struct ModelT {
     // which also keeps them visible in /proc/self/maps to whoever audits which native code ran.
     (void)hipFree(mblk);
     (void)hipFree(faults);
+    if (tau_scratch != nullptr) (void)hipFree(tau_scratch);
   }
 
   hipError_t upload_all() {
@@ -196,7 +199,31 @@ int run_typed(jxs_model* model, int mode, const void* state_in, void* state_out,
     repeat = 1;
     mode = jxs::MODE_ROLLOUT;
   }
+  const bool tau_seq = (extra_flags & 4) != 0 && a.tau != nullptr;
+  const T* const tau_all = a.tau;
+  const int seq_steps = a.n_steps > 1 ? a.n_steps : repeat;
+  if (tau_seq && mode != jxs::MODE_ROLLOUT) {
+    // one launch per step (RungeKutta4, the rigid contact models, several point chunks): the torques of step `it` are
+    // rows it * n ... of every tile of the sequence [n_steps * n][N] -- gathered into a [n][N] block per step (a strided
+    // device copy), which the step kernel reads like any joint_force_references
+    a.flags &= ~4;
+    const int tile = 64 / mt->pk.G;
+    const size_t need = sizeof(T) * (size_t)((N + tile - 1) / tile) * tile * mt->pk.P.n;
+    if (mt->tau_scratch_bytes < need) {
+      if (mt->tau_scratch != nullptr) (void)hipFree(mt->tau_scratch);
+      mt->tau_scratch = nullptr, mt->tau_scratch_bytes = 0;
+      JXS_HIP(hipMalloc(&mt->tau_scratch, need));
+      mt->tau_scratch_bytes = need;
+    }
+  }
   for (int it = 0; it < repeat; ++it) {
+    if (tau_seq && mode != jxs::MODE_ROLLOUT) {
+      const int tile = 64 / mt->pk.G, n = mt->pk.P.n;
+      const size_t row_bytes = sizeof(T) * (size_t)tile;
+      JXS_HIP(hipMemcpy2DAsync(mt->tau_scratch, row_bytes * n, reinterpret_cast<const char*>(tau_all) + row_bytes * n * it,
+                               row_bytes * n * seq_steps, row_bytes * n, (size_t)((N + tile - 1) / tile), hipMemcpyDeviceToDevice, s));
+      a.tau = static_cast<const T*>(mt->tau_scratch);
+    }
     hipError_t e = (mode >= 0 && mode < 16 && mt->spec_launch[mode] != nullptr)
                        ? static_cast<hipError_t>(mt->spec_launch[mode](&mt->pk.P, mt->mblk, &a, s))
                        : launch_mode<T>(mode, mt->pk.G, mt->pk.P, mt->mblk, a, s);
@@ -563,6 +590,15 @@ int jxs_rollout(jxs_model* model, void* state, const void* tau, const void* link
   if (n_steps < 0) return fail(JXS_EINVAL, "n_steps must be >= 0");
   return run_any(model, jxs::MODE_STEP, state, state, tau, link_forces, force_repr, nullptr, nullptr, nullptr, nullptr,
                  N, n_steps, stream);
+}
+int jxs_rollout_controlled(jxs_model* model, void* state, const void* tau_seq, const void* link_forces, int force_repr,
+                           int N, int n_steps, void* stream) {
+  if (n_steps < 0) return fail(JXS_EINVAL, "n_steps must be >= 0");
+  if (n_steps == 0) return JXS_OK;
+  if (tau_seq == nullptr) return fail(JXS_EINVAL, "null torque sequence (jxs_rollout takes constant or no torques)");
+  if (n_steps == 1) return run_any(model, jxs::MODE_STEP, state, state, tau_seq, link_forces, force_repr, nullptr, nullptr, nullptr, nullptr, N, 1, stream);
+  return run_any(model, jxs::MODE_STEP, state, state, tau_seq, link_forces, force_repr, nullptr, nullptr, nullptr, nullptr,
+                 N, n_steps, stream, nullptr, /*fuse=*/true, /*extra_flags=*/4);
 }
 int jxs_step_repeat(jxs_model* model, void* state, const void* tau, const void* link_forces, int force_repr, int N,
                     int n_launches, void* stream) {

@@ -285,11 +285,15 @@ struct Core {
     // the joint-position rows when there are none: a row that exists; the value is dropped), last in the queue, and
     // first used by the actuation model right before ABA; the link wrenches are loaded where they are used.
     const bool has_tau = A.tau != nullptr;
+    // [round 4] controlled rollout (jxs_rollout_controlled, KArgs::flags bit 2): `tau` holds one block of joint torques
+    // per fused step, [n_steps * n][N]; step `it` reads rows it * n ... (reloaded at the top of every step below)
+    const bool tau_seq = MODE == MODE_ROLLOUT && has_tau && (A.flags & 4) != 0;
+    const int tau_rows = tau_seq ? A.n_steps * P.n : P.n;
     V tau_in;
     if (kLaneRows) {
-      tau_in = ln.gload(has_tau ? A.tau : A.state_in, jl + (has_tau ? 0 : P.row_s), has_tau ? P.n : P.n_rows);
+      tau_in = ln.gload(has_tau ? A.tau : A.state_in, jl + (has_tau ? 0 : P.row_s), has_tau ? tau_rows : P.n_rows);
     } else {
-      tau_in = has_tau ? ln.gload(A.tau, jrow_c, P.n) : V(T(0));
+      tau_in = has_tau ? ln.gload(A.tau, jrow_c, tau_rows) : V(T(0));
     }
     const bool with_rows = P.row_mode && (kStep || MODE == MODE_FD) && !kRigid;
     const bool with_contacts = (kStep && !kRigid) && P.n_chunks > 0;  // soft contacts (state m)
@@ -319,6 +323,8 @@ struct Core {
     const int n_steps = (MODE == MODE_ROLLOUT) ? A.n_steps : 1;  // compile-time 1 for a plain step
     for (int it = 0; it < n_steps; ++it) {
     V tau = V(T(0));  // (set at stage 0, right before ABA: see "B: joint torques" below)
+    if (MODE == MODE_ROLLOUT && tau_seq && it > 0)  // this step's torques: issued here, first used right before ABA
+      tau_in = kLaneRows ? ln.gload(A.tau, jl + it * P.n, tau_rows) : ln.gload(A.tau, jrow_c + it * P.n, tau_rows);
 
     // Runge-Kutta 4 (api/integrators.py:91-167): the joint torques (B, below) are computed once from the
     // initial state (api/model.py:2658), the stage loop below evaluates system_dynamics

@@ -327,6 +327,7 @@ struct KArgs {
   int* faults;         // [2] environments whose QP contact-force solve / impact solve was discarded (non-finite), or null
   int flags;           // switches of a launch: bit 0 = no MFMA in the contact solvers' Cholesky (developer A/B against the vector
                        // path); bit 1 = gravity-compensated step of the rigid contact modes (tau_ref += g(q))
+                       // bit 2 = MODE_ROLLOUT: `tau` is a sequence, one [n][N] block of rows per fused step (jxs_rollout_controlled)
   int spec_consts;     // 1: the integer model flags of KParams are compile-time constants in this kernel (jxs_spec.hip)
   int knobs;           // host only: developer knobs of the launcher (KNOB_*), read from the environment ONCE by the
                        // library (jxs_api.hip debug_knobs; jxs_debug_reload_env re-reads them for the tests)

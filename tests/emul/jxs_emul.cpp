@@ -5,6 +5,7 @@
 // logic (table packing, shuffles along the tree, level loops, contacts, integrator) with the
 // oracle on a machine without a GPU.  Not part of the product: jaxsim_amd/ never loads it.
 #include <algorithm>
+#include <vector>
 #include <cstring>
 #include <string>
 
@@ -81,6 +82,9 @@ int run_typed(const jxs_model_desc* d, int mode, const void* state_in, void* sta
     std::memcpy(state_out, state_in, sizeof(T) * (size_t)((N + tile - 1) / tile) * tile * pk.P.n_rows);
   }
   int launches = 1;
+  // bit 9 of the mode: `tau` is a sequence [n_steps * n][N], one block of rows per step (jxs_rollout_controlled)
+  const bool tau_seq = (mode & 0x200) != 0 && a.tau != nullptr;
+  mode &= ~0x200;
   const bool duo = (mode == (jxs::MODE_STEP | 0x100));  // emulate the two-wave workgroup variant of the step kernel
   if (duo) {
     mode = jxs::MODE_STEP;
@@ -108,8 +112,18 @@ int run_typed(const jxs_model_desc* d, int mode, const void* state_in, void* sta
     mode = jxs::MODE_STEP | 0x100;
   }
   g_err.clear();
+  const T* const tau_all = a.tau;
+  std::vector<T> tau_step;
+  if (tau_seq && mode == jxs::MODE_ROLLOUT) a.flags |= 4;
   for (int it = 0; it < launches; ++it) {
     if (it == 1) a.state_in = a.state_out;
+    if (tau_seq && mode != jxs::MODE_ROLLOUT) {  // one launch per step: the step's rows of every tile, like the library's strided copy
+      const int tile = 64 / pk.G, n = pk.P.n, tiles = (N + tile - 1) / tile;
+      tau_step.resize((size_t)tiles * n * tile);
+      for (int t = 0; t < tiles; ++t)
+        std::memcpy(&tau_step[(size_t)t * n * tile], tau_all + ((size_t)t * n_steps + it) * n * tile, sizeof(T) * (size_t)n * tile);
+      a.tau = tau_step.data();
+    }
   switch (pk.G) {
     case 4: run_group<T, 4>(pk, a, mode); break;
     case 8: run_group<T, 8>(pk, a, mode); break;

@@ -64,8 +64,9 @@ def layout(model, dtype=np.float64) -> _lib.Layout:
     return out
 
 
-def run(model, mode, state, *, tau=None, link_forces=None, force_repr=0, in_acc=None, dtype=None, n_steps=1):
-    """Run one emulated launch.  All arrays are [rows, N] C-contiguous of the model dtype."""
+def run(model, mode, state, *, tau=None, link_forces=None, force_repr=0, in_acc=None, dtype=None, n_steps=1, tau_seq=False):
+    """Run one emulated launch.  All arrays are [rows, N] C-contiguous of the model dtype.  ``tau_seq``: `tau` is
+    [n_steps * n, N], one block of rows per step (jxs_rollout_controlled)."""
     dtype = np.dtype(dtype or state.dtype)
     d, keep = _lib.make_desc(model, dtype)
     N = state.shape[1]
@@ -88,7 +89,7 @@ def run(model, mode, state, *, tau=None, link_forces=None, force_repr=0, in_acc=
     out_H = alloc(nL * 12) if mode in (MODE_KIN, MODE_JAC) else None
     out_V = alloc(nL * 6) if mode == MODE_KIN else None
     rc = lib().jxs_emul_run(
-        C.byref(d), mode, _p(st), _p(state_out), _p(tau), _p(link_forces), int(force_repr), _p(in_acc),
+        C.byref(d), mode | (0x200 if tau_seq else 0), _p(st), _p(state_out), _p(tau), _p(link_forces), int(force_repr), _p(in_acc),
         _p(out_a), _p(out_H), _p(out_V), N, int(n_steps),
     )  # fmt: skip
     if rc != 0:

@@ -843,6 +843,39 @@ def test_merged_link_space_sweeps_equal_the_four_sweep_form(models, kind, key, d
     assert helpers.rel_err(merged, truth) < ref_tol and helpers.rel_err(four, truth) < ref_tol
 
 
+@pytest.mark.parametrize("name,kind", [("icub16", "euler"), ("cartpole", "euler"), ("double_pendulum", "euler"), ("chain9f", "rk4"), ("anymal", "rigid"), ("icub80", "euler")])
+def test_controlled_rollout_equals_the_step_loop(models, name, kind):
+    """[round 4] jxs_rollout_controlled: K steps with a torque SEQUENCE [K * n][N] (what jax.lax.scan over step with
+    precomputed joint_force_references does) -- one fused launch with a torque load per step where the steps fuse
+    (semi-implicit Euler, SoftContacts, one point chunk), one launch per step with the step's rows gathered otherwise
+    (RungeKutta4, RigidContacts, several chunks: icub80).  Against the oracle stepping with tau[k], and not equal to
+    the rollout that holds tau[0]."""
+    K, N = 4, 5
+    if name == "icub80":
+        model = _icub80()
+        d = oracle.random_model_data(model, batch_size=N, seed=3, base_pos_bounds=((-1, -1, 0.56), (1, 1, 0.66)), base_rpy_bounds=((-0.3, -0.3, -3), (0.3, 0.3, 3)))
+    else:
+        model = models(name)
+        d = models.random_data(name, N, seed=21)
+    if kind == "rk4":
+        model = _rk4(model)
+    if kind == "rigid":
+        model = helpers.rigid_model(model, helpers.ANYMAL_FEET_4, K=1e4, D=2e2)
+    n = model.dofs()
+    rng = np.random.default_rng(11)
+    tau = rng.uniform(-3, 3, size=(K, N, n))
+    ref = d
+    for k in range(K):
+        ref = oracle.step(model, ref, joint_force_references=tau[k])
+    blk = helpers.odata_to_block(model, d)
+    seq = np.ascontiguousarray(tau.transpose(0, 2, 1).reshape(K * n, N))
+    out = eb.run(model, eb.MODE_STEP, blk, tau=seq, n_steps=K, tau_seq=True, force_repr=2)
+    # (RigidContacts at the default solver_tol = 1e-3: four steps agree to the tolerance of the QP iterates)
+    assert helpers.rel_err(out, helpers.odata_to_block(model, ref)) < (1e-5 if kind == "rigid" else 1e-9)
+    held = eb.run(model, eb.MODE_STEP, blk, tau=np.ascontiguousarray(tau[0].T), n_steps=K, force_repr=2)
+    assert helpers.rel_err(held, out) > 1e-6
+
+
 @pytest.mark.parametrize("fixed_base,max_back", [(True, 1), (False, 1), (False, 3)])
 def test_maximum_size_models(models, fixed_base, max_back):
     """The largest supported model: 64 links, one per lane of a full wave; a serial chain makes the tree

@@ -401,6 +401,49 @@ def test_rk4_step_matches_oracle_gpu(models, name, dtype):
     assert helpers.rel_err(out.state_block(), helpers.odata_to_block(model, ref)) < helpers.tol_of(dtype, name)
 
 
+@pytest.mark.parametrize("name,kind", [("icub", "euler"), ("cartpole", "euler"), ("chain9f", "rk4"), ("anymal", "rigid"), ("icub80", "euler")])
+def test_controlled_rollout_equals_the_step_loop_gpu(models, name, kind):
+    """[round 4] js.model.rollout with a torque SEQUENCE [K, N, n] (jxs_rollout_controlled; jax.lax.scan over step
+    with precomputed joint_force_references in the reference): one fused launch with a torque load per step where the
+    steps fuse, one launch per step with the step's rows gathered by a strided device copy otherwise (RungeKutta4,
+    RigidContacts, several point chunks).  Against the oracle stepping with tau[k]; equal to K single steps on the
+    device; not the rollout that holds tau[0]."""
+    from jaxsim_amd import robots
+
+    K, N = 6, 37
+    if name == "icub80":
+        model = ja.JaxSimModel.build_from_model_description(robots.icub23_urdf(sole_boxes_per_foot=5))
+        d = oracle.random_model_data(model, batch_size=N, seed=3, base_pos_bounds=((-1, -1, 0.56), (1, 1, 0.66)), base_rpy_bounds=((-0.3, -0.3, -3), (0.3, 0.3, 3)))
+    else:
+        model = models(name)
+        d = models.random_data(name, N, seed=21)
+    if kind == "rk4":
+        model = _rk4(model)
+    if kind == "rigid":
+        model = helpers.rigid_model(model, helpers.ANYMAL_FEET_4, K=1e4, D=2e2)
+    n = model.dofs()
+    tau = np.random.default_rng(11).uniform(-3, 3, size=(K, N, n))
+    ref = d
+    for k in range(K):
+        ref = oracle.step(model, ref, joint_force_references=tau[k])
+    out = js.model.rollout(model, to_gpu(model, d), K, joint_force_references=tau).state_block()
+    assert helpers.rel_err(out, helpers.odata_to_block(model, ref)) < (1e-5 if kind == "rigid" else 1e-9)
+    data = to_gpu(model, d)
+    for k in range(K):
+        data = js.model.step(model, data, joint_force_references=tau[k])
+    assert helpers.rel_err(out, data.state_block()) < (1e-6 if kind == "rigid" else 1e-11)
+    held = js.model.rollout(model, to_gpu(model, d), K, joint_force_references=tau[0]).state_block()
+    assert helpers.rel_err(held, out) > 1e-6
+    # fp32, fused: same steps as the single launches
+    if kind == "euler":
+        d32 = helpers.block_to_odata(model, helpers.odata_to_block(model, d).astype(np.float32), d.velocity_representation)
+        o32 = js.model.rollout(model, to_gpu(model, d32), K, joint_force_references=tau).state_block()
+        s32 = to_gpu(model, d32)
+        for k in range(K):
+            s32 = js.model.step(model, s32, joint_force_references=tau[k])
+        assert o32.dtype == np.float32 and helpers.rel_err(o32, s32.state_block()) < 2e-4
+
+
 @pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-10), (np.float32, 2e-4)])
 def test_rk4_with_more_points_than_lanes_gpu(models, dtype, tol):
     """[round 4] RungeKutta4 + SoftContacts with 80 collidable points on 32 lanes: three chunks, the stage data of the
