@@ -764,7 +764,7 @@ def main():
     rollout_ms_per_step = ev2.elapsed_ms(ev3) / k_roll
     # ... and with a SEQUENCE of joint torques, one block per step (jxs_rollout_controlled: jax.lax.scan over step with
     # precomputed joint_force_references -- open-loop rollouts): one more load per step inside the same fused launch
-    controlled_us = None
+    controlled_us, recorded_us = None, None
     try:
         n_j = model.dofs()
         seq_host = np.random.default_rng(3).uniform(-1.0, 1.0, size=(k_roll * n_j, n_local))
@@ -777,9 +777,22 @@ def main():
         ev5.record(stream)
         runtime.synchronize(stream)
         controlled_us = ev4.elapsed_ms(ev5) / k_roll * 1e3
-        del seq
+        # ... and RECORDED: the state block after every step stored from registers (jxs_rollout_recorded: the stacked
+        # outputs of a scan), with the torque sequence -- controls in, trajectory out, one launch
+        traj = runtime.DeviceArray(k_roll * data._state.shape[0], n_local, dtype, tile=data._state.tile)
+        tp = C.c_void_p(traj.ptr)
+        _lib.check(lib.jxs_rollout_recorded(dm.handle, state_ptr, C.c_void_p(seq.ptr), 1, None, 2, n_local, k_roll, tp, stream.handle), "jxs_rollout_recorded")
+        runtime.synchronize(stream)
+        ev6, ev7 = runtime.Event(), runtime.Event()
+        ev6.record(stream)
+        _lib.check(lib.jxs_rollout_recorded(dm.handle, state_ptr, C.c_void_p(seq.ptr), 1, None, 2, n_local, k_roll, tp, stream.handle), "jxs_rollout_recorded")
+        ev7.record(stream)
+        runtime.synchronize(stream)
+        recorded_us = ev6.elapsed_ms(ev7) / k_roll * 1e3
+        del seq, traj
     except Exception as e:  # secondary: never lose the headline for it
-        controlled_us = repr(e)
+        controlled_us = controlled_us if controlled_us is not None else repr(e)
+        recorded_us = repr(e)
 
     # secondary figure: the same kernel with the chip saturated (64 Ki environments on this GPU) -- what
     # the step costs once enough waves hide each other's latencies.  Not the headline configuration.
@@ -905,8 +918,9 @@ def main():
             "generic_kernel": generic,
             "fused_rollout": {"us_per_step": rollout_ms_per_step * 1e3, "env_steps_per_s_rank0": n_local / (rollout_ms_per_step * 1e-3),
                               "controlled_us_per_step": controlled_us,
+                              "controlled_and_recorded_us_per_step": recorded_us,
                               "note": "same steps as one jxs_rollout launch; `controlled`: with one block of joint torques per step "
-                                      "(jxs_rollout_controlled); secondary figures, not `value`"},
+                                      "(jxs_rollout_controlled); `recorded`: and the state block after every step stored (jxs_rollout_recorded); secondary figures, not `value`"},
         }
         if saturated is not None:
             if "env_steps_per_s" in saturated:

@@ -202,6 +202,15 @@ int jxs_rollout(jxs_model* model, void* state, const void* tau, const void* link
 int jxs_rollout_controlled(jxs_model* model, void* state, const void* tau_seq, const void* link_forces,
                            int force_repr, int N, int n_steps, void* stream);
 
+/* [round 4] A rollout that RECORDS: the state block after every step goes to `out_states` = [n_steps * n_rows][N]
+ * (rows k*n_rows .. (k+1)*n_rows-1 = the state after step k, the layout of `state`), what `jax.lax.scan` over `step`
+ * returns as its stacked outputs; `state` is advanced in place as by jxs_rollout.  `tau`: constant [n][N] or NULL, or
+ * -- `tau_per_step` != 0 -- a sequence [n_steps * n][N] as in jxs_rollout_controlled.  Fused into one launch where the
+ * steps fuse (one store of the state per step from registers); otherwise one launch and one strided device copy
+ * per step.                                                                                     */
+int jxs_rollout_recorded(jxs_model* model, void* state, const void* tau, int tau_per_step, const void* link_forces,
+                         int force_repr, int N, int n_steps, void* out_states, void* stream);
+
 /* forward_dynamics_aba (src/jaxsim/api/model.py:1269-1406) in inertial representation:
  * out_acc = [6+n][N] = inertial-fixed base acceleration then joint accelerations.
  * `joint_forces` are applied as given (no actuation model), no contact forces.          */

@@ -213,6 +213,7 @@ def _declare(lib):
         "jxs_step_gravity_compensated": [vp, vp, vp, vp, vp, C.c_int, C.c_int, vp],
         "jxs_rollout": [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp],
         "jxs_rollout_controlled": [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp],
+        "jxs_rollout_recorded": [vp, vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, vp],
         "jxs_forward_dynamics_aba": [vp, vp, vp, vp, C.c_int, vp, C.c_int, vp],
         "jxs_inverse_dynamics": [vp, vp, vp, vp, C.c_int, vp, C.c_int, vp],
         "jxs_gravity_torques": [vp, vp, vp, C.c_int, vp],

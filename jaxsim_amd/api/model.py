@@ -184,12 +184,14 @@ def step(
 
 
 def rollout(model: JaxSimModel, data: JaxSimModelData, n_steps: int, *, link_forces=None,
-            joint_force_references=None) -> JaxSimModelData:  # fmt: skip
+            joint_force_references=None, return_trajectory: bool = False):  # fmt: skip
     """``n_steps`` back-to-back steps (what ``jax.lax.fori_loop`` / ``jax.lax.scan`` over ``step`` does in the
     reference's notebooks); the input data is not modified.  ``joint_force_references``: constant over the steps
     (``[N, n]`` / ``[n]``), or -- [round 4] -- a SEQUENCE ``[n_steps, N, n]`` (``[n_steps, n]`` for one environment):
     step ``k`` applies ``joint_force_references[k]`` (``jxs_rollout_controlled``: one launch with the state in
-    registers where the steps fuse)."""
+    registers where the steps fuse).  ``return_trajectory=True`` [round 4]: returns ``(data, states)`` with
+    ``states`` the host array ``[n_steps, rows, N]`` of the state block after every step (``jxs_rollout_recorded``: the
+    stacked outputs of the reference's ``scan``; ``JaxSimModelData.from_state_block(model, states[k])`` rebuilds step k)."""
     dm = runtime.device_model(model, data.dtype)
     N, nL, n = data.batch_size, model.number_of_links(), model.dofs()
     f = _as_device(link_forces, nL * 6, N, data.dtype, (nL, 6), data._state.tile)
@@ -204,6 +206,18 @@ def rollout(model: JaxSimModel, data: JaxSimModelData, n_steps: int, *, link_for
                 raise ValueError((a.shape, (int(n_steps), N, n)))
             # rows k * n + j of the [n_steps * n][N] block: torque of joint j at step k
             seq = DeviceArray.from_host(np.ascontiguousarray(a.transpose(0, 2, 1).reshape(int(n_steps) * n, N)), tile=data._state.tile, dtype=data.dtype)
+    if return_trajectory:
+        K, rows = int(n_steps), data._state.shape[0]
+        tau = seq if seq is not None else _as_device(joint_force_references, n, N, data.dtype, (n,), data._state.tile)
+        traj = DeviceArray(K * rows, N, data.dtype, tile=data._state.tile)
+        _lib.check(
+            _lib.load().jxs_rollout_recorded(
+                dm.handle, C.c_void_p(out.ptr), _ptr(tau), 1 if seq is not None else 0, _ptr(f),
+                int(data.velocity_representation), N, K, C.c_void_p(traj.ptr), runtime._sp(),
+            ),
+            "jxs_rollout_recorded",
+        )  # fmt: skip
+        return JaxSimModelData(model, out, data.velocity_representation, data._batched), traj.to_host().reshape(K, rows, N)
     if seq is not None and n > 0 and int(n_steps) > 0:
         _lib.check(
             _lib.load().jxs_rollout_controlled(

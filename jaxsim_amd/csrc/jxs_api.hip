@@ -162,7 +162,7 @@ int create_typed(const jxs_model_desc* d, std::unique_ptr<ModelT<T>>& slot) {
 template <typename T>
 int run_typed(jxs_model* model, int mode, const void* state_in, void* state_out, const void* tau,
               const void* link_f, int force_repr, const void* in_a, void* out_a, void* out_H, void* out_V, int N,
-              int repeat, void* stream, void* out_tau, bool fuse, int extra_flags) {
+              int repeat, void* stream, void* out_tau, bool fuse, int extra_flags, void* traj = nullptr) {
   ModelT<T>* mt = typed<T>(model);
   hipStream_t s = static_cast<hipStream_t>(stream);
   jxs::KArgs<T> a = mt->args(N);
@@ -193,11 +193,13 @@ int run_typed(jxs_model* model, int mode, const void* state_in, void* state_out,
     mode = mt->pk.P.rigid ? jxs::MODE_STEP_RK4_RIGID : jxs::MODE_STEP_RK4;
   }
   if (mode == jxs::MODE_STEP && mt->pk.P.rigid) mode = jxs::MODE_STEP_RIGID;  // QP contacts + impact, one launch per step
-  if (fuse && mode == jxs::MODE_STEP && repeat > 1 && mt->pk.P.n_chunks <= 1) {
+  // (a recorded rollout of a model with disabled collidable points is not fused: their rows are not written by the kernel)
+  if (fuse && mode == jxs::MODE_STEP && repeat > 1 && mt->pk.P.n_chunks <= 1 && (traj == nullptr || mt->pk.n_disabled == 0)) {
     // fused rollout: one launch, the state stays in registers between the steps
     a.n_steps = repeat;
     repeat = 1;
     mode = jxs::MODE_ROLLOUT;
+    if (traj != nullptr) a.out_a = static_cast<T*>(traj);  // recorded: the kernel stores the state after every step (jxs_core.h)
   }
   const bool tau_seq = (extra_flags & 4) != 0 && a.tau != nullptr;
   const T* const tau_all = a.tau;
@@ -228,6 +230,13 @@ int run_typed(jxs_model* model, int mode, const void* state_in, void* state_out,
                        ? static_cast<hipError_t>(mt->spec_launch[mode](&mt->pk.P, mt->mblk, &a, s))
                        : launch_mode<T>(mode, mt->pk.G, mt->pk.P, mt->mblk, a, s);
     if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    if (traj != nullptr && mode != jxs::MODE_ROLLOUT) {
+      // recorded rollout, one launch per step: the state block after step `it` goes to rows it * n_rows ... of every tile
+      const int tile = 64 / mt->pk.G, rows = mt->pk.P.n_rows;
+      const size_t blk_bytes = sizeof(T) * (size_t)tile * rows;
+      JXS_HIP(hipMemcpy2DAsync(static_cast<char*>(traj) + blk_bytes * it, blk_bytes * seq_steps, a.state_out, blk_bytes, blk_bytes,
+                               (size_t)((N + tile - 1) / tile), hipMemcpyDeviceToDevice, s));
+    }
     if (it == 0 && repeat > 1) a.state_in = a.state_out;  // unfused rollout continues from its own output
   }
   return JXS_OK;
@@ -235,16 +244,16 @@ int run_typed(jxs_model* model, int mode, const void* state_in, void* state_out,
 
 int run_any(jxs_model* model, int mode, const void* state_in, void* state_out, const void* tau, const void* link_f,
             int force_repr, const void* in_a, void* out_a, void* out_H, void* out_V, int N, int repeat,
-            void* stream, void* out_tau = nullptr, bool fuse = true, int extra_flags = 0) {
+            void* stream, void* out_tau = nullptr, bool fuse = true, int extra_flags = 0, void* traj = nullptr) {
   if (model == nullptr) return fail(JXS_EINVAL, "null model");
   if (state_in == nullptr) return fail(JXS_EINVAL, "null state");
   if (N <= 0) return fail(JXS_EINVAL, "N must be positive");
   if (force_repr < 0 || force_repr > 2) return fail(JXS_EINVAL, "invalid force representation");
   if (model->dtype == JXS_F64)
     return run_typed<double>(model, mode, state_in, state_out, tau, link_f, force_repr, in_a, out_a, out_H, out_V, N,
-                             repeat, stream, out_tau, fuse, extra_flags);
+                             repeat, stream, out_tau, fuse, extra_flags, traj);
   return run_typed<float>(model, mode, state_in, state_out, tau, link_f, force_repr, in_a, out_a, out_H, out_V, N,
-                          repeat, stream, out_tau, fuse, extra_flags);
+                          repeat, stream, out_tau, fuse, extra_flags, traj);
 }
 
 // ---- RCCL, resolved lazily so that the library loads (and the CPU symbol test passes)
@@ -599,6 +608,15 @@ int jxs_rollout_controlled(jxs_model* model, void* state, const void* tau_seq, c
   if (n_steps == 1) return run_any(model, jxs::MODE_STEP, state, state, tau_seq, link_forces, force_repr, nullptr, nullptr, nullptr, nullptr, N, 1, stream);
   return run_any(model, jxs::MODE_STEP, state, state, tau_seq, link_forces, force_repr, nullptr, nullptr, nullptr, nullptr,
                  N, n_steps, stream, nullptr, /*fuse=*/true, /*extra_flags=*/4);
+}
+int jxs_rollout_recorded(jxs_model* model, void* state, const void* tau, int tau_per_step, const void* link_forces,
+                         int force_repr, int N, int n_steps, void* out_states, void* stream) {
+  if (n_steps < 0) return fail(JXS_EINVAL, "n_steps must be >= 0");
+  if (n_steps == 0) return JXS_OK;
+  if (out_states == nullptr) return fail(JXS_EINVAL, "null out_states (jxs_rollout / jxs_rollout_controlled do not record)");
+  if (tau_per_step && tau == nullptr) return fail(JXS_EINVAL, "tau_per_step without a torque sequence");
+  return run_any(model, jxs::MODE_STEP, state, state, tau, link_forces, force_repr, nullptr, nullptr, nullptr, nullptr,
+                 N, n_steps, stream, nullptr, /*fuse=*/true, /*extra_flags=*/(tau_per_step && n_steps > 1) ? 4 : 0, out_states);
 }
 int jxs_step_repeat(jxs_model* model, void* state, const void* tau, const void* link_forces, int force_repr, int N,
                     int n_launches, void* stream) {

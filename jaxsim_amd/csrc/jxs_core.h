@@ -320,6 +320,41 @@ struct Core {
 
     // Fused rollout: `n_steps` consecutive steps with the state carried in registers -- tables,
     // inputs and state are read once, the state is written once (jxs_rollout).  One step otherwise.
+    // ---- the state block of this environment: written back once -- and, for a recorded rollout, after every step ----
+    auto write_state = [&](T* dst, int roff, int nrows) {
+      const VI zl = lane * 0;
+      ln.gstore(dst, roff + jrow + P.row_s, s, is_joint, nrows);
+      ln.gstore(dst, roff + jrow + P.row_sd, sd, is_joint, nrows);
+      if (G >= 16) {
+        // [round 3] the thirteen base rows with ONE store instruction: every lane of an environment carries the same
+        // new base state (it was integrated from values that are uniform over the environment), so lane k < 13 picks
+        // value k and stores row k (rows 0..6 and 7+n..12+n) -- instead of thirteen exec-masked stores of the root lane
+        const V b13[13] = {pB[0], pB[1], pB[2], q[0], q[1], q[2], q[3], vW[0], vW[1], vW[2], om[0], om[1], om[2]};
+        // (a tree over the bits of the lane index: four masks and a depth of four, where a chain of twelve
+        // compare-and-select pairs cost a wait state each -- a compare writes the mask its select reads)
+        const VM b0 = (lane & 1) != 0, b1 = (lane & 2) != 0, b2 = (lane & 4) != 0, b3 = (lane & 8) != 0;
+        const V t01 = vsel(b0, b13[1], b13[0]), t23 = vsel(b0, b13[3], b13[2]), t45 = vsel(b0, b13[5], b13[4]);
+        const V t67 = vsel(b0, b13[7], b13[6]), t89 = vsel(b0, b13[9], b13[8]), tab = vsel(b0, b13[11], b13[10]);
+        const V q0 = vsel(b1, t23, t01), q1 = vsel(b1, t67, t45), q2 = vsel(b1, tab, t89);
+        const V val = vsel(b3, vsel(b2, b13[12], q2), vsel(b2, q1, q0));
+        const VI brow = vsel(lane < 7, lane, vsel(lane < 13, lane + P.n, lane * 0));
+        ln.gstore(dst, roff + brow, val, lane < 13, nrows);
+      } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) ln.gstore(dst, roff + zl + (P.row_quat + k), q[k], is_root, nrows);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        ln.gstore(dst, roff + zl + (P.row_pos + k), pB[k], is_root, nrows);
+        ln.gstore(dst, roff + zl + (P.row_vlin + k), vW[k], is_root, nrows);
+        ln.gstore(dst, roff + zl + (P.row_vang + k), om[k], is_root, nrows);
+      }
+      }
+      if (with_contacts) {
+        const VM valid = ps0.body >= 0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) ln.gstore(dst, roff + ps0.prow * 3 + (P.row_m + k), ps0.m[k], valid, nrows);
+      }
+    };
     const int n_steps = (MODE == MODE_ROLLOUT) ? A.n_steps : 1;  // compile-time 1 for a plain step
     for (int it = 0; it < n_steps; ++it) {
     V tau = V(T(0));  // (set at stage 0, right before ABA: see "B: joint torques" below)
@@ -1100,43 +1135,13 @@ struct Core {
       }
     }
     }  // integrator stages
+    // [round 4] recorded rollout (jxs_rollout_recorded): the state after EVERY step goes to the trajectory block
+    // [n_steps * n_rows][N] (rows it * n_rows ...), what jax.lax.scan over step returns as its stacked outputs.  The
+    // pointer travels in KArgs::out_a, which the step modes do not use otherwise.
+    if (MODE == MODE_ROLLOUT && A.out_a != nullptr) write_state(A.out_a, it * P.n_rows, n_steps * P.n_rows);
     }  // fused step loop
 
-    // ---- write the state back once ---------------------------------------------------------------
-    {
-      const VI zl = lane * 0;
-      ln.gstore(A.state_out, jrow + P.row_s, s, is_joint, P.n_rows);
-      ln.gstore(A.state_out, jrow + P.row_sd, sd, is_joint, P.n_rows);
-      if (G >= 16) {
-        // [round 3] the thirteen base rows with ONE store instruction: every lane of an environment carries the same
-        // new base state (it was integrated from values that are uniform over the environment), so lane k < 13 picks
-        // value k and stores row k (rows 0..6 and 7+n..12+n) -- instead of thirteen exec-masked stores of the root lane
-        const V b13[13] = {pB[0], pB[1], pB[2], q[0], q[1], q[2], q[3], vW[0], vW[1], vW[2], om[0], om[1], om[2]};
-        // (a tree over the bits of the lane index: four masks and a depth of four, where a chain of twelve
-        // compare-and-select pairs cost a wait state each -- a compare writes the mask its select reads)
-        const VM b0 = (lane & 1) != 0, b1 = (lane & 2) != 0, b2 = (lane & 4) != 0, b3 = (lane & 8) != 0;
-        const V t01 = vsel(b0, b13[1], b13[0]), t23 = vsel(b0, b13[3], b13[2]), t45 = vsel(b0, b13[5], b13[4]);
-        const V t67 = vsel(b0, b13[7], b13[6]), t89 = vsel(b0, b13[9], b13[8]), tab = vsel(b0, b13[11], b13[10]);
-        const V q0 = vsel(b1, t23, t01), q1 = vsel(b1, t67, t45), q2 = vsel(b1, tab, t89);
-        const V val = vsel(b3, vsel(b2, b13[12], q2), vsel(b2, q1, q0));
-        const VI brow = vsel(lane < 7, lane, vsel(lane < 13, lane + P.n, lane * 0));
-        ln.gstore(A.state_out, brow, val, lane < 13, P.n_rows);
-      } else {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) ln.gstore(A.state_out, zl + (P.row_quat + k), q[k], is_root, P.n_rows);
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        ln.gstore(A.state_out, zl + (P.row_pos + k), pB[k], is_root, P.n_rows);
-        ln.gstore(A.state_out, zl + (P.row_vlin + k), vW[k], is_root, P.n_rows);
-        ln.gstore(A.state_out, zl + (P.row_vang + k), om[k], is_root, P.n_rows);
-      }
-      }
-      if (with_contacts) {
-        const VM valid = ps0.body >= 0;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) ln.gstore(A.state_out, ps0.prow * 3 + (P.row_m + k), ps0.m[k], valid, P.n_rows);
-      }
-    }
+    write_state(A.state_out, 0, P.n_rows);
     ln.stamp(A, 10);  // integrate + stores issued
   }
 

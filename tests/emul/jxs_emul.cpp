@@ -84,7 +84,10 @@ int run_typed(const jxs_model_desc* d, int mode, const void* state_in, void* sta
   int launches = 1;
   // bit 9 of the mode: `tau` is a sequence [n_steps * n][N], one block of rows per step (jxs_rollout_controlled)
   const bool tau_seq = (mode & 0x200) != 0 && a.tau != nullptr;
-  mode &= ~0x200;
+  // bit 10: recorded rollout -- `out_a` is the trajectory block [n_steps * n_rows][N] (jxs_rollout_recorded)
+  T* const traj = (mode & 0x400) != 0 ? static_cast<T*>(out_a) : nullptr;
+  if (traj != nullptr) a.out_a = nullptr;
+  mode &= ~0x600;
   const bool duo = (mode == (jxs::MODE_STEP | 0x100));  // emulate the two-wave workgroup variant of the step kernel
   if (duo) {
     mode = jxs::MODE_STEP;
@@ -115,6 +118,11 @@ int run_typed(const jxs_model_desc* d, int mode, const void* state_in, void* sta
   const T* const tau_all = a.tau;
   std::vector<T> tau_step;
   if (tau_seq && mode == jxs::MODE_ROLLOUT) a.flags |= 4;
+  if (traj != nullptr && mode == jxs::MODE_ROLLOUT && pk.n_disabled > 0) {  // like the library: not fused
+    launches = n_steps, a.n_steps = 1, mode = jxs::MODE_STEP;
+    if (tau_seq) a.flags &= ~4;
+  }
+  if (traj != nullptr && mode == jxs::MODE_ROLLOUT) a.out_a = traj;
   for (int it = 0; it < launches; ++it) {
     if (it == 1) a.state_in = a.state_out;
     if (tau_seq && mode != jxs::MODE_ROLLOUT) {  // one launch per step: the step's rows of every tile, like the library's strided copy
@@ -132,6 +140,11 @@ int run_typed(const jxs_model_desc* d, int mode, const void* state_in, void* sta
     case 64: run_group<T, 64>(pk, a, mode); break;
     default: g_err = "bad group size"; return JXS_EINVAL;
   }
+    if (traj != nullptr && mode != jxs::MODE_ROLLOUT) {  // one launch per step: copy the state block into its rows of every tile
+      const int tile = 64 / pk.G, rows = pk.P.n_rows, tiles = (N + tile - 1) / tile;
+      for (int t = 0; t < tiles; ++t)
+        std::memcpy(traj + ((size_t)t * n_steps + it) * rows * tile, a.state_out + (size_t)t * rows * tile, sizeof(T) * (size_t)rows * tile);
+    }
   }
   if (!g_err.empty()) return JXS_EINVAL;
   return JXS_OK;

@@ -64,9 +64,10 @@ def layout(model, dtype=np.float64) -> _lib.Layout:
     return out
 
 
-def run(model, mode, state, *, tau=None, link_forces=None, force_repr=0, in_acc=None, dtype=None, n_steps=1, tau_seq=False):
+def run(model, mode, state, *, tau=None, link_forces=None, force_repr=0, in_acc=None, dtype=None, n_steps=1, tau_seq=False, record=False):
     """Run one emulated launch.  All arrays are [rows, N] C-contiguous of the model dtype.  ``tau_seq``: `tau` is
-    [n_steps * n, N], one block of rows per step (jxs_rollout_controlled)."""
+    [n_steps * n, N], one block of rows per step (jxs_rollout_controlled); ``record``: returns (final state, states
+    [n_steps, rows, N]) like jxs_rollout_recorded."""
     dtype = np.dtype(dtype or state.dtype)
     d, keep = _lib.make_desc(model, dtype)
     N = state.shape[1]
@@ -86,14 +87,18 @@ def run(model, mode, state, *, tau=None, link_forces=None, force_repr=0, in_acc=
     out_a = alloc(6 + n) if mode in (MODE_FD, MODE_ID, MODE_GRAV) else (alloc((6 + n) ** 2) if mode in (MODE_CRBA, MODE_MINV) else None)
     if mode == MODE_JAC:
         out_a = alloc(12 * (6 + n))
+    if record:
+        out_a = alloc(int(n_steps) * rows_state)
     out_H = alloc(nL * 12) if mode in (MODE_KIN, MODE_JAC) else None
     out_V = alloc(nL * 6) if mode == MODE_KIN else None
     rc = lib().jxs_emul_run(
-        C.byref(d), mode | (0x200 if tau_seq else 0), _p(st), _p(state_out), _p(tau), _p(link_forces), int(force_repr), _p(in_acc),
+        C.byref(d), mode | (0x200 if tau_seq else 0) | (0x400 if record else 0), _p(st), _p(state_out), _p(tau), _p(link_forces), int(force_repr), _p(in_acc),
         _p(out_a), _p(out_H), _p(out_V), N, int(n_steps),
     )  # fmt: skip
     if rc != 0:
         raise RuntimeError(lib().jxs_emul_last_error().decode())
+    if record:
+        return untile_block(state_out, rows_state, N, tile), untile_block(out_a, int(n_steps) * rows_state, N, tile).reshape(int(n_steps), rows_state, N)
     if mode in (MODE_STEP, MODE_STEP_DUO):
         return untile_block(state_out, rows_state, N, tile)
     if mode == MODE_KIN:

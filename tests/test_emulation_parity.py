@@ -876,6 +876,43 @@ def test_controlled_rollout_equals_the_step_loop(models, name, kind):
     assert helpers.rel_err(held, out) > 1e-6
 
 
+@pytest.mark.parametrize("name,kind,seq", [("icub16", "euler", True), ("cartpole", "euler", False), ("chain9f", "rk4", True), ("anymal", "rigid", False), ("icub80", "euler", True), ("icub16", "disabled", True)])
+def test_recorded_rollout_returns_every_step(models, name, kind, seq):
+    """[round 4] jxs_rollout_recorded: the state block after EVERY step of a rollout (the stacked outputs of the
+    reference's jax.lax.scan over step) -- stored from registers inside the fused launch, or copied per step where the
+    steps do not fuse (RungeKutta4, RigidContacts, several point chunks, disabled points).  Every recorded state equals
+    the oracle's after that many steps; the last one is the final state."""
+    K, N = 4, 5
+    if name == "icub80":
+        model = _icub80()
+        d = oracle.random_model_data(model, batch_size=N, seed=3, base_pos_bounds=((-1, -1, 0.56), (1, 1, 0.66)), base_rpy_bounds=((-0.3, -0.3, -3), (0.3, 0.3, 3)))
+    else:
+        model = models(name)
+        d = models.random_data(name, N, seed=23)
+    if kind == "rk4":
+        model = _rk4(model)
+    if kind == "rigid":
+        model = helpers.rigid_model(model, helpers.ANYMAL_FEET_4, K=1e4, D=2e2)
+    if kind == "disabled":
+        model = helpers.enable_points(model, [0, 1, 2, 3, 8, 9, 10, 11])
+    n = model.dofs()
+    tau = np.random.default_rng(13).uniform(-3, 3, size=(K, N, n))
+    if not seq:
+        tau[:] = tau[0]
+    blk = helpers.odata_to_block(model, d)
+    arg = np.ascontiguousarray(tau.transpose(0, 2, 1).reshape(K * n, N)) if seq else np.ascontiguousarray(tau[0].T)
+    final, states = eb.run(model, eb.MODE_STEP, blk, tau=arg, n_steps=K, tau_seq=seq, record=True, force_repr=2)
+    assert states.shape == (K,) + blk.shape
+    ref = d
+    tol = 1e-5 if kind == "rigid" else 1e-9
+    for k in range(K):
+        ref = oracle.step(model, ref, joint_force_references=tau[k])
+        assert helpers.rel_err(states[k], helpers.odata_to_block(model, ref)) < tol, k
+    np.testing.assert_array_equal(states[-1], final)
+    plain = eb.run(model, eb.MODE_STEP, blk, tau=arg, n_steps=K, tau_seq=seq, force_repr=2)
+    np.testing.assert_array_equal(plain, final)  # recording does not change the rollout
+
+
 @pytest.mark.parametrize("fixed_base,max_back", [(True, 1), (False, 1), (False, 3)])
 def test_maximum_size_models(models, fixed_base, max_back):
     """The largest supported model: 64 links, one per lane of a full wave; a serial chain makes the tree

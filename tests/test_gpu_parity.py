@@ -444,6 +444,43 @@ def test_controlled_rollout_equals_the_step_loop_gpu(models, name, kind):
         assert o32.dtype == np.float32 and helpers.rel_err(o32, s32.state_block()) < 2e-4
 
 
+@pytest.mark.parametrize("name,kind,seq", [("icub", "euler", True), ("cartpole", "euler", False), ("chain9f", "rk4", True), ("anymal", "rigid", False), ("icub80", "euler", True), ("icub16", "disabled", True)])
+def test_recorded_rollout_returns_every_step_gpu(models, name, kind, seq):
+    """[round 4] js.model.rollout(..., return_trajectory=True) / jxs_rollout_recorded: the state after every step (the
+    stacked outputs of the reference's jax.lax.scan over step), stored from registers inside the fused launch or copied
+    per step where the steps do not fuse.  Every recorded state against the oracle; the last one is the final state;
+    recording does not change the rollout (bitwise)."""
+    from jaxsim_amd import robots
+
+    K, N = 5, 37
+    if name == "icub80":
+        model = ja.JaxSimModel.build_from_model_description(robots.icub23_urdf(sole_boxes_per_foot=5))
+        d = oracle.random_model_data(model, batch_size=N, seed=3, base_pos_bounds=((-1, -1, 0.56), (1, 1, 0.66)), base_rpy_bounds=((-0.3, -0.3, -3), (0.3, 0.3, 3)))
+    else:
+        model = models(name)
+        d = models.random_data(name, N, seed=23)
+    if kind == "rk4":
+        model = _rk4(model)
+    if kind == "rigid":
+        model = helpers.rigid_model(model, helpers.ANYMAL_FEET_4, K=1e4, D=2e2)
+    if kind == "disabled":
+        model = helpers.enable_points(model, [0, 1, 2, 3, 8, 9, 10, 11])
+    n = model.dofs()
+    tau = np.random.default_rng(13).uniform(-3, 3, size=(K, N, n))
+    if not seq:
+        tau[:] = tau[0]
+    arg = tau if seq else tau[0]
+    final, states = js.model.rollout(model, to_gpu(model, d), K, joint_force_references=arg, return_trajectory=True)
+    assert states.shape == (K,) + final.state_block().shape
+    ref, tol = d, (1e-5 if kind == "rigid" else 1e-9)
+    for k in range(K):
+        ref = oracle.step(model, ref, joint_force_references=tau[k])
+        assert helpers.rel_err(states[k], helpers.odata_to_block(model, ref)) < tol, k
+    np.testing.assert_array_equal(states[-1], final.state_block())
+    plain = js.model.rollout(model, to_gpu(model, d), K, joint_force_references=arg).state_block()
+    np.testing.assert_array_equal(plain, final.state_block())
+
+
 @pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-10), (np.float32, 2e-4)])
 def test_rk4_with_more_points_than_lanes_gpu(models, dtype, tol):
     """[round 4] RungeKutta4 + SoftContacts with 80 collidable points on 32 lanes: three chunks, the stage data of the
