@@ -198,7 +198,8 @@ int jxs_rollout(jxs_model* model, void* state, const void* tau, const void* link
  * (the actuation model is applied to them at every step, like `step`).  `link_forces` stay constant.  Where the
  * steps fuse (semi-implicit Euler, SoftContacts, one chunk of collidable points) this is ONE launch with the state in
  * registers and one torque load per step; otherwise one launch per step, the step's torques gathered by a strided
- * device copy.                                                                                  */
+ * device copy into a scratch block the MODEL owns: unfused controlled rollouts of one model are not re-entrant
+ * across streams (use one model handle per stream, as for every call that carries per-model device state).   */
 int jxs_rollout_controlled(jxs_model* model, void* state, const void* tau_seq, const void* link_forces,
                            int force_repr, int N, int n_steps, void* stream);
 

@@ -197,6 +197,8 @@ def rollout(model: JaxSimModel, data: JaxSimModelData, n_steps: int, *, link_for
     f = _as_device(link_forces, nL * 6, N, data.dtype, (nL, 6), data._state.tile)
     out = data._state.copy()
     seq = None
+    if n == 0:
+        joint_force_references = None  # (no joints: nothing to apply, whatever shape was handed over)
     if joint_force_references is not None and not isinstance(joint_force_references, DeviceArray) and \
             getattr(joint_force_references, "__cuda_array_interface__", None) is None:
         a = np.asarray(joint_force_references, dtype=np.float64)
