@@ -194,7 +194,18 @@ int run_typed(jxs_model* model, int mode, const void* state_in, void* state_out,
   }
   if (mode == jxs::MODE_STEP && mt->pk.P.rigid) mode = jxs::MODE_STEP_RIGID;  // QP contacts + impact, one launch per step
   // (a recorded rollout of a model with disabled collidable points is not fused: their rows are not written by the kernel)
-  if (fuse && mode == jxs::MODE_STEP && repeat > 1 && mt->pk.P.n_chunks <= 1 && (traj == nullptr || mt->pk.n_disabled == 0)) {
+  // [round 4] ... and a plain rollout is fused only while the grid is at most eight waves per SIMD: beyond that the
+  // per-step launches are FASTER (measured, tools/sweep.py --rollout, humanoid: 8.5 against 10.2 us per step at 4096
+  // environments, 32.3 = 32.3 at 16384, 128.7 against 109.2 at 65536 -- the long-lived waves of the fused launch fill
+  // the chip in fewer, coarser rounds and the prologue it saves is hidden by the other waves anyway)
+  static const int n_simds = [] {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return 4 * (cus > 0 ? cus : 256);
+  }();
+  const int blocks = (N + (64 / mt->pk.G) - 1) / (64 / mt->pk.G);
+  const bool worth_fusing = traj != nullptr || blocks <= 8 * n_simds;
+  if (fuse && worth_fusing && mode == jxs::MODE_STEP && repeat > 1 && mt->pk.P.n_chunks <= 1 && (traj == nullptr || mt->pk.n_disabled == 0)) {
     // fused rollout: one launch, the state stays in registers between the steps
     a.n_steps = repeat;
     repeat = 1;
