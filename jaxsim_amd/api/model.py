@@ -210,6 +210,8 @@ def rollout(model: JaxSimModel, data: JaxSimModelData, n_steps: int, *, link_for
             seq = DeviceArray.from_host(np.ascontiguousarray(a.transpose(0, 2, 1).reshape(int(n_steps) * n, N)), tile=data._state.tile, dtype=data.dtype)
     if return_trajectory:
         K, rows = int(n_steps), data._state.shape[0]
+        if K <= 0:
+            return JaxSimModelData(model, out, data.velocity_representation, data._batched), np.zeros((0, rows, N), dtype=data.dtype)
         tau = seq if seq is not None else _as_device(joint_force_references, n, N, data.dtype, (n,), data._state.tile)
         traj = DeviceArray(K * rows, N, data.dtype, tile=data._state.tile)
         _lib.check(
