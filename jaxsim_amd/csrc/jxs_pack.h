@@ -191,6 +191,26 @@ std::string pack_model(const jxs_model_desc& d, Packed<T>& out) {
     }
     bool ok = nl >= 1 && nl <= 2;
     for (int k = 0; k < nl && ok; ++k) ok = d.floating_base || body[k] != 0;
+    if (ok && nl == 2) {
+      // [round 4] B must be DEFINITE for its Cholesky factor: the twelve rows (two link twists) have rank 6 + the number
+      // of joints on the path between the two links, so fewer than six joints between them make B singular -- and an
+      // unpivoted factorisation of a semidefinite matrix in floating point goes wrong in a few per cent of the states
+      // (a small genuine pivot amplifies the rounding noise of the zero pivots behind it; found by
+      // test_link_space_on_random_trees: a 6-% wrong step).  The feet of a humanoid are twelve joints apart; two boxes
+      // on neighbouring links keep the triangles.
+      auto depth = [&](int i) {
+        int k = 0;
+        for (; d.parent[i] >= 0; i = d.parent[i]) ++k;
+        return k;
+      };
+      int a = body[0], b = body[1], joints = 0;
+      while (a != b) {
+        if (depth(a) >= depth(b)) a = d.parent[a];
+        else b = d.parent[b];
+        ++joints;
+      }
+      ok = joints >= 6;
+    }
     if (ok) {
       rl_n = nl;
       for (int k = 0; k < nl; ++k) rl_body[k] = body[k], rl_s0[k] = s0[k], rl_s1[k] = s1[k];

@@ -280,13 +280,16 @@ def anymal12_urdf(points_per_foot_box: bool = True, joint_limit: float = 1.0) ->
     return "".join(out)
 
 
-def chain_urdf(n_links: int = 5, fixed_base: bool = True, seed: int = 0, max_back: int = 3) -> str:
+def chain_urdf(n_links: int = 5, fixed_base: bool = True, seed: int = 0, max_back: int = 3, collision_links=None) -> str:
     """Random serial/branching chain with mixed revolute/prismatic joints, skewed axes and
     rotated joint frames: a stress model for parity tests (cf. the reference's scalable
     "garpez" fixture, ``tests/conftest.py:479-707``).  The parent of link i is one of the ``max_back``
-    previous links (1: a serial chain of depth n_links - 1)."""
+    previous links (1: a serial chain of depth n_links - 1).  ``collision_links``: the links that carry a collision
+    box (default: the first and the last link of a floating chain, none of a fixed one)."""
     rng = np.random.default_rng(seed)
     out = ['<robot name="chain">']
+    if collision_links is None:
+        collision_links = () if fixed_base else (0, n_links - 1)
     if fixed_base:
         out.append('<link name="world"/>')
     for i in range(n_links):
@@ -294,7 +297,7 @@ def chain_urdf(n_links: int = 5, fixed_base: bool = True, seed: int = 0, max_bac
         com = tuple(float(v) for v in rng.uniform(-0.1, 0.1, 3))
         dims = tuple(float(v) for v in rng.uniform(0.05, 0.3, 3))
         rpy = tuple(float(v) for v in rng.uniform(-0.5, 0.5, 3))
-        coll = _box_collision(dims, xyz=com) if (not fixed_base and i in (0, n_links - 1)) else ""
+        coll = _box_collision(dims, xyz=com) if i in collision_links else ""
         out.append(f'<link name="link{i:02d}">' + _inertial(m, com=com, I=_box_inertia(m, *dims), rpy=rpy) + coll + "</link>")
     if fixed_base:
         out.append(_joint("world_to_base", "fixed", "world", "link00", (0.1, -0.2, 0.5), (0, 0, 0)))

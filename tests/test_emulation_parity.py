@@ -431,6 +431,7 @@ RIGID_CASES = {
     "anymal16": ("anymal", helpers.ANYMAL_FEET_16, dict(K=1e4, D=1e2)),
     "anymal4": ("anymal", helpers.ANYMAL_FEET_4, dict()),
     "chain9f6": ("chain9f", [0, 1, 2, 3, 8, 9], dict(K=1e3, mu=0.8)),
+    "serial12f": ("serial12f", list(range(16)), dict(K=1e3, mu=0.8)),  # two links eleven joints apart: link space in fp64
     "icub8": ("icub16", [0, 1, 2, 3, 8, 9, 10, 11], dict(K=1e4)),
     # <= 4 points in a 32-lane group: the row-distributed register solver with the general Delassus sweeps
     # (two points per foot: no merged sweep)
@@ -530,6 +531,7 @@ RELAXED_CASES = {
     "anymal16": ("anymal", helpers.ANYMAL_FEET_16, dict(mu=0.5)),
     "anymal4": ("anymal", helpers.ANYMAL_FEET_4, dict(time_constant=0.01, damping_coefficient=0.7, power=1.5)),
     "chain9f6": ("chain9f", [0, 1, 2, 3, 8, 9], dict(mu=0.8, d_min=0.5, d_max=0.99, width=5e-3, midpoint=0.3)),
+    "serial12f": ("serial12f", list(range(16)), dict(mu=0.8, d_min=0.5, d_max=0.99, width=5e-3, midpoint=0.3)),
     "icub16": ("icub16", list(range(16)), dict(mu=0.5)),
     # the reference's DEFAULT parameters (mu = 0.005: the regulariser is five orders below the Delassus entries) on two links
     "icub16d": ("icub16", list(range(16)), dict()),
@@ -784,9 +786,9 @@ def test_rigid_unsupported_configurations_are_rejected(models, monkeypatch):
 
 
 @pytest.mark.parametrize("kind,key,dtype,tol", [
-    ("relaxed", "icub16", np.float64, 1e-11), ("relaxed", "icub16", np.float32, 2e-4), ("relaxed", "chain9f6", np.float64, 1e-11),
+    ("relaxed", "icub16", np.float64, 1e-11), ("relaxed", "icub16", np.float32, 2e-4), ("relaxed", "serial12f", np.float64, 1e-11),
     ("relaxed", "icub16d", np.float64, 1e-9),  # [r4] default parameters: link space in fp64 only
-    ("relaxed", "chain9f6", np.float32, 1e-4), ("rigid", "icub8", np.float64, 1e-7), ("rigid", "chain9f6", np.float64, 1e-7),
+    ("relaxed", "serial12f", np.float32, 2e-3), ("rigid", "icub8", np.float64, 1e-7), ("rigid", "serial12f", np.float64, 1e-7),
 ])  # fmt: skip
 def test_link_space_solve_agrees_with_the_dense_path(models, reduced_qp, kind, key, dtype, tol, monkeypatch):
     """[round 4] Contact problems whose points sit on at most two links are solved in link space (jxs_rigid.inc ls_*:
@@ -911,6 +913,45 @@ def test_recorded_rollout_returns_every_step(models, name, kind, seq):
     np.testing.assert_array_equal(states[-1], final)
     plain = eb.run(model, eb.MODE_STEP, blk, tau=arg, n_steps=K, tau_seq=seq, force_repr=2)
     np.testing.assert_array_equal(plain, final)  # recording does not change the rollout
+
+
+def test_link_space_on_random_trees():
+    """[round 4] Which contact problems take link space, and that they are right: random floating trees (8 to 24 links)
+    with the two collision boxes on random links.  The 12 x 12 inverse operational-space inertia of two links has
+    rank 6 + (joints between them): the packer takes link space only for six or more joints in between (a singular B
+    cannot be Cholesky-factorised reliably in floating point: the first version took every pair and one state in
+    forty came out 6 % wrong -- this test found it), merges the sweeps when the links hang below different children of
+    the base, and every case -- link space or triangles -- agrees with the oracle in fp64 and, where the regulariser
+    allows link space, in fp32."""
+    import jaxsim_amd as ja
+    from jaxsim_amd import robots, specialize
+
+    rng = np.random.default_rng(7)
+    seen = {"dense": 0, "linkspace": 0, "merged": 0}
+    worst32 = 0.0
+    for trial in range(24):
+        n_links = int(rng.integers(8, 25))
+        seed = 100 + trial
+        max_back = 1 if trial % 3 == 0 else int(rng.integers(1, 4))  # every third tree a serial chain: far-apart links
+        a, b = sorted(int(v) for v in rng.choice(np.arange(0, n_links), size=2, replace=False))
+        base = ja.JaxSimModel.build_from_model_description(robots.chain_urdf(n_links, fixed_base=False, seed=seed, max_back=max_back, collision_links=(a, b)))
+        model = helpers.relaxed_model(base, list(range(16)), mu=0.5)
+        apart = helpers.contact_link_separation(model)
+        text = specialize.spec(model, np.float64, specialize.MODE_STEP_RIGID)
+        assert ("P.rl_n=2" in text) == (apart >= 6), (trial, a, b, apart)
+        merged = "P.rl_merge=1" in text
+        seen["merged" if merged else "linkspace" if apart >= 6 else "dense"] += 1
+        d = oracle.random_model_data(model, batch_size=6, seed=seed, base_pos_bounds=((-1, -1, 0.0), (1, 1, 0.3)), base_rpy_bounds=((-0.4, -0.4, -3), (0.4, 0.4, 3)))
+        truth = helpers.odata_to_block(model, oracle.step(model, d))
+        out = eb.run(model, eb.MODE_STEP, helpers.odata_to_block(model, d))
+        assert helpers.rel_err(out, truth) < 1e-9, (trial, a, b, apart, merged)
+        d32 = helpers.block_to_odata(model, helpers.odata_to_block(model, d).astype(np.float32), d.velocity_representation)
+        out32 = eb.run(model, eb.MODE_STEP, helpers.odata_to_block(model, d32))
+        e32 = helpers.rel_err(out32, helpers.odata_to_block(model, oracle.step(model, helpers.upcast(d32))))
+        worst32 = max(worst32, e32)
+        assert e32 < 2e-3, (trial, a, b, apart, merged, e32)
+    assert min(seen.values()) > 0, seen
+    helpers.note("linkspace_random_trees_fp32_worst", worst32)
 
 
 @pytest.mark.parametrize("fixed_base,max_back", [(True, 1), (False, 1), (False, 3)])

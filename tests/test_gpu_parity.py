@@ -540,6 +540,7 @@ RIGID_CASES = {
     "anymal16": ("anymal", helpers.ANYMAL_FEET_16, dict(K=1e4, D=1e2)),
     "anymal4": ("anymal", helpers.ANYMAL_FEET_4, dict()),
     "chain9f6": ("chain9f", [0, 1, 2, 3, 8, 9], dict(K=1e3, mu=0.8)),
+    "serial12f": ("serial12f", list(range(16)), dict(K=1e3, mu=0.8)),  # two contact links eleven joints apart: link space in fp64
     "icub8": ("icub16", [0, 1, 2, 3, 8, 9, 10, 11], dict(K=1e4)),
     # <= 4 points in a 32-lane group: the row-distributed register solver with the general Delassus sweeps
     # (two points per foot: no merged sweep)
@@ -829,17 +830,21 @@ def test_config5_quadruped_rigid_contacts_with_gravity_compensation(models, redu
     np.testing.assert_array_equal(out24, out[:, :24])
 
 
-@pytest.mark.parametrize("n_links,seed,max_back", [(7, 31, 2), (12, 32, 3), (20, 33, 2), (5, 34, 1)])
+@pytest.mark.parametrize("n_links,seed,max_back,links", [(7, 31, 1, (0, 6)), (12, 32, 3, (0, 11)), (20, 33, 2, (3, 19)), (14, 34, 1, (2, 11)), (16, 100, 3, (9, 11))])
 @pytest.mark.parametrize("kind", ["relaxed", "rigid"])
-def test_link_space_solve_on_random_trees_gpu(reduced_qp, kind, n_links, seed, max_back):
-    """[round 4] The link-space contact solve (jxs_rigid.inc ls_*) on random floating trees -- serial and branching, 5 to
-    20 links, mixed revolute / prismatic joints -- with both contact boxes (base and last link: two contact links, 16
-    points) enabled: RelaxedRigidContacts and RigidContacts in fp64 against the oracle, and RelaxedRigidContacts in fp32."""
+def test_link_space_solve_on_random_trees_gpu(reduced_qp, kind, n_links, seed, max_back, links):
+    """[round 4] The link-space contact solve (jxs_rigid.inc ls_*) on random floating trees -- serial and branching, 7 to
+    20 links, mixed revolute / prismatic joints -- with the two contact boxes (16 points) on the given links:
+    RelaxedRigidContacts and RigidContacts in fp64 against the oracle, and RelaxedRigidContacts in fp32.  Link space is
+    taken when six or more joints separate the two links (a nearer pair has a SINGULAR 12 x 12 inverse operational-space
+    inertia: the last case is the tree and pair on which the first version of the round went 6 % wrong in one state --
+    it takes the triangles now)."""
     from jaxsim_amd import robots, specialize
 
-    base = ja.JaxSimModel.build_from_model_description(robots.chain_urdf(n_links, fixed_base=False, seed=seed, max_back=max_back))
+    base = ja.JaxSimModel.build_from_model_description(robots.chain_urdf(n_links, fixed_base=False, seed=seed, max_back=max_back, collision_links=links))
     model = (helpers.relaxed_model(base, list(range(16)), mu=0.5) if kind == "relaxed" else helpers.rigid_model(base, list(range(16)), K=1e4, D=1e2))
-    assert "P.rl_n=2" in specialize.spec(model, np.float64, specialize.MODE_STEP_RIGID)
+    apart = helpers.contact_link_separation(model)
+    assert ("P.rl_n=2" in specialize.spec(model, np.float64, specialize.MODE_STEP_RIGID)) == (apart >= 6)
     N = 9
     d = oracle.random_model_data(model, batch_size=N, seed=seed, base_pos_bounds=((-1, -1, 0.0), (1, 1, 0.25)), base_rpy_bounds=((-0.4, -0.4, -3), (0.4, 0.4, 3)))
     ref = helpers.odata_to_block(model, oracle.step(model, d))
@@ -851,7 +856,7 @@ def test_link_space_solve_on_random_trees_gpu(reduced_qp, kind, n_links, seed, m
         out32 = js.model.step(model, to_gpu(model, d32)).state_block()
         err32 = helpers.rel_err(out32, helpers.odata_to_block(model, oracle.step(model, helpers.upcast(d32))))
         helpers.note(f"linkspace_random_fp32/{n_links}", err32)
-        assert err32 < 2e-3
+        assert err32 < 3e-3
 
 
 @pytest.mark.parametrize("kind,dtype", [("rigid", np.float32), ("rigid", np.float64), ("relaxed", np.float32), ("soft", np.float32)])
@@ -891,6 +896,7 @@ RELAXED_CASES = {
     "anymal16": ("anymal", helpers.ANYMAL_FEET_16, dict(mu=0.5)),
     "anymal4": ("anymal", helpers.ANYMAL_FEET_4, dict(time_constant=0.01, damping_coefficient=0.7, power=1.5)),
     "chain9f6": ("chain9f", [0, 1, 2, 3, 8, 9], dict(mu=0.8, d_min=0.5, d_max=0.99, width=5e-3, midpoint=0.3)),
+    "serial12f": ("serial12f", list(range(16)), dict(mu=0.8, d_min=0.5, d_max=0.99, width=5e-3, midpoint=0.3)),
     "icub16": ("icub16", list(range(16)), dict(mu=0.5)),
     # [r4] the reference's DEFAULT parameters (mu = 0.005) on two links: link space in fp64 (jxs_pack.h)
     "icub16d": ("icub16", list(range(16)), dict()),
