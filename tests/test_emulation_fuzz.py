@@ -1,0 +1,22 @@
+"""A small slice of the emulation fuzz campaigns (tools/fuzz/*.py: the kernel sources compiled for the CPU against the
+oracle on random trees) in the CPU suite: the campaigns of the round's end ran hundreds of trees
+(profiles/r04_experiments.md) and found the one real defect of the round -- this keeps a dozen trees of each alive."""
+import os
+import pathlib
+import subprocess
+import sys
+
+import pytest
+
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+
+
+@pytest.mark.parametrize("script,seed,trials", [("fuzz_step.py", 21, 14), ("fuzz_rigid.py", 22, 12), ("fuzz_query.py", 23, 10),
+                                                ("fuzz_rollout.py", 24, 12)])  # fmt: skip
+def test_fuzz_slice(script, seed, trials):
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([str(ROOT), str(ROOT / "tests"), os.environ.get("PYTHONPATH", "")]))
+    p = subprocess.run([sys.executable, str(ROOT / "tools" / "fuzz" / script), str(seed), str(trials)], capture_output=True, text=True,
+                       env=env, timeout=900)  # fmt: skip
+    assert p.returncode == 0, p.stderr[-2000:]
+    last = [ln for ln in p.stdout.splitlines() if ln.startswith("fails")]
+    assert last and last[-1].startswith("fails 0 "), p.stdout[-2000:]
