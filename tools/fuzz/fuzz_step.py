@@ -22,6 +22,10 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 60):
         model = ja.JaxSimModel.build_from_model_description(urdf)
     except Exception as e:
         print('build failed', trial, n_links, fixed, cl, repr(e)[:100]); continue
+    if rng.integers(0, 3) == 0:  # a tilted ground plane (PlaneTerrain)
+        model = helpers.with_params(model, terrain=ja.PlaneTerrain.build(height=float(rng.uniform(-0.05, 0.05)), normal=[float(rng.uniform(-0.3, 0.3)), float(rng.uniform(-0.3, 0.3)), 1.0]))
+    if rng.integers(0, 4) == 0 and model.kin_dyn_parameters.number_of_collidable_points() > 1:  # soft-contact exponents other than 1/2, a different friction
+        model = helpers.with_params(model, contact_params=ja.SoftContactsParams.build(K=5e5, D=1.5e3, mu=0.9, p=0.7, q=0.3))
     integ = int(rng.integers(0, 2))
     if integ:
         model = helpers.with_params(model, integrator=ja.IntegratorType.RungeKutta4, contact_params=ja.SoftContactsParams.build(K=2e4, D=60.0, mu=0.6))
