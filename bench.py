@@ -127,6 +127,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--envs-per-gpu", type=int, default=1024)
+    ap.add_argument("--global-batch", type=int, default=0, help="strong scaling: this many environments in total, split evenly over the GPUs (north_star: batch 8192 over 1 / 2 / 4 / 8 GPUs); overrides --envs-per-gpu and the line says \"scaling\": \"strong\"")
     ap.add_argument("--dtype", default="float32", choices=["float32", "float64"])
     ap.add_argument("--model", default="icub23", choices=["icub23", "icub23_16", "anymal12", "cartpole"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -138,7 +139,14 @@ def parse_args():
     ap.add_argument("--dry-run-bootstrap", action="store_true",
                     help="no GPU work: run only the multi-rank bootstrap of this script (job key, id exchange through the "
                     "rendezvous file, host collective, shard bounds) and print what a rank-0 line would say about it")
-    return ap.parse_args()
+    args = ap.parse_args()
+    args.scaling = "weak"
+    if args.global_batch > 0:
+        if args.global_batch % max(args.gpus, 1) != 0:
+            raise SystemExit(f"--global-batch {args.global_batch} is not a multiple of --gpus {args.gpus}")
+        args.envs_per_gpu = args.global_batch // max(args.gpus, 1)
+        args.scaling = "strong"
+    return args
 
 
 def build_model(name):
@@ -861,7 +869,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32" if dtype == np.float32 else "f64",
             "data": "synthetic",
