@@ -50,3 +50,12 @@ def test_bench_two_ranks_from_one_command_gpu():
     assert d["comm"]["kind"] in ("FileCollective", "Communicator")
     if d["comm"]["kind"] == "FileCollective":
         assert "ncclCommInitRank" in d["comm"]["error"]
+
+
+@pytest.mark.gpu
+def test_bench_global_batch_is_strong_scaling_gpu():
+    """`--global-batch B` splits a fixed batch over the GPUs (north_star: batch 8192 over 1 / 2 / 4 / 8 GPUs) and the
+    line says so."""
+    d = run_bench("--gpus", "1", "--global-batch", "2048", *FAST, "--no-cpu-baseline")
+    assert d["scaling"] == "strong" and d["config"]["global_batch"] == 2048 and d["config"]["envs_per_gpu"] == 2048
+    assert abs(d["value"] - 2048 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
