@@ -11,8 +11,8 @@ import pytest
 ROOT = pathlib.Path(__file__).resolve().parent.parent
 
 
-@pytest.mark.parametrize("script,seed,trials", [("fuzz_step.py", 21, 14), ("fuzz_rigid.py", 22, 12), ("fuzz_query.py", 23, 10),
-                                                ("fuzz_rollout.py", 24, 12)])  # fmt: skip
+@pytest.mark.parametrize("script,seed,trials", [("fuzz_step.py", 21, 40), ("fuzz_rigid.py", 22, 30), ("fuzz_query.py", 23, 25),
+                                                ("fuzz_rollout.py", 24, 30)])  # fmt: skip
 def test_fuzz_slice(script, seed, trials):
     env = dict(os.environ, PYTHONPATH=os.pathsep.join([str(ROOT), str(ROOT / "tests"), os.environ.get("PYTHONPATH", "")]))
     p = subprocess.run([sys.executable, str(ROOT / "tools" / "fuzz" / script), str(seed), str(trials)], capture_output=True, text=True,
