@@ -978,9 +978,9 @@ struct Core {
           } else {
             V fpt[3];
             if (P.rigid == 2)
-              relaxed_contact_forces(lane, level, parent, child, tf, ps0, rp, a6, mass, fpt);
+              relaxed_contact_forces(lane, level, parent, child, tf, ps0, rp, a6, mass, cw, Ic, fpt);
             else
-              rigid_contact_forces(lane, level, parent, child, tf, ps0, rp, a6, fpt);
+              rigid_contact_forces(lane, level, parent, child, tf, ps0, rp, a6, mass, cw, Ic, fpt);
             V w6[6];
   #pragma unroll
             for (int k = 0; k < 3; ++k) w6[k] = fpt[k];
@@ -1004,7 +1004,7 @@ struct Core {
         } else {
           // velocity reset at impacts: nu+ = nu - M^-1 J^T lambda on the new configuration
           V dv0[6], dsd;
-          rigid_impact(lane, level, parent, child, tf, ps0, rp, dv0, dsd);
+          rigid_impact(lane, level, parent, child, tf, ps0, rp, mass, cw, Ic, dv0, dsd);
           sd = sd + vsel(is_joint, dsd, V(T(0)));
           V t[3];
           cross(dv0 + 3, pB, t);  // inertial-fixed linear velocity: v_W = v_C - w x p_B

@@ -182,22 +182,9 @@ constexpr int kRgMergeRec = 40;  // [0, 18) wrench handed to the base per unit f
 JXS_HD constexpr int rigid_lds_merge_off(int n_cp, int rigid = 1) {
   return ((rigid == 2 ? 1 : 2) * ((3 * n_cp * (3 * n_cp + 1)) / 2) + 3 * n_cp + 8 + (n_cp <= 4 ? 16 : 0) + 3) / 4 * 4;
 }
-// [round 4] contact problems solved in link space (jxs_rigid.inc ls_*): the 12 x 12 inverse
-// operational-space inertia of the contact links (rows of 16 words), one 12-word record per point, 16 words of exchange
-constexpr int kRlRowStride = 16, kRlPtRec = 12;
-JXS_HD constexpr int rl_lds_pt_off() { return 12 * kRlRowStride; }
-JXS_HD constexpr int rl_lds_vec_off(int n_cp) { return rl_lds_pt_off() + kRlPtRec * n_cp; }
-JXS_HD constexpr int rl_lds_sink_off(int n_cp) { return rl_lds_vec_off(n_cp) + 16; }  // 8 words nobody reads (lds_write*_sel)
-// merged sweeps (KParams::rl_merge): per contact link six wrenches handed to the base and six base accelerations, rows of 8 words
-constexpr int kRlMergeRec = 96;
-JXS_HD constexpr int rl_lds_merge_off(int n_cp) { return rl_lds_sink_off(n_cp) + 8; }
-JXS_HD constexpr int rl_lds_words(int n_cp) { return rl_lds_merge_off(n_cp) + 2 * kRlMergeRec; }
-// the model's contact problem is solved in link space (rl_n: contact links found eligible by the packer); RigidContacts
-// with <= 4 points keeps the row-distributed register solver (config 5)
-JXS_HD constexpr bool rl_linkspace(int rl_n, int n_cp, int rigid) { return rl_n > 0 && (rigid == 2 || (rigid == 1 && n_cp > 4)); }
-JXS_HD constexpr int rigid_lds_words_per_env(int n_cp, int rigid = 1, int rl_n = 0) {
-  return rl_linkspace(rl_n, n_cp, rigid) ? rl_lds_words(n_cp)  // no triangle at all
-                                         : rigid_lds_merge_off(n_cp, rigid) + (n_cp <= 4 ? 4 * kRgMergeRec : 0);
+JXS_HD constexpr int rigid_lds_words_per_env(int n_cp, int rigid = 1, int ct_tree = 0) {
+  return ct_tree ? 16  // [round 5] solved in the tree (jxs_rigid.inc ta_*): shuffles only, no triangle in the LDS
+                 : rigid_lds_merge_off(n_cp, rigid) + (n_cp <= 4 ? 4 * kRgMergeRec : 0);
 }
 constexpr int kQpMaxIter = 30;    // interior-point iterations (oracle/refrigid.py QP_MAX_ITER)
 constexpr int kRigidMaxPoints = 64;  // one lane per point: a full wave ([round 3]: 32 -> 64; the point masks are 64 bits wide)
@@ -287,11 +274,11 @@ struct KParams {
   T rr_rcoef;                    // 2 mu^2 (1 + mu^2)
   T rr_tiny;                     // smallest positive normal number (guards pow of a non-positive base)
   int rr_refine;                 // refinement steps against the operator applied through the tree
-  // [round 4] contact problems solved in LINK space (jxs_rigid.inc ls_*): all points of a link move with the
-  // link's twist, J M^-1 J^T = P B P^T with B the inverse operational-space inertia of the contact links.  rl_n: number
-  // of contact links (1 or 2; 0: the dense Delassus path), their lanes, and the slots [s0, s1) of their points.
-  int rl_n, rl_lane[2], rl_s0[2], rl_s1[2];
-  int rl_merge;                  // the two contact links sit in different subtrees of a floating base: B from TWO merged sweeps (ls_build_B_merged)
+  // [round 5] contact problems solved IN THE TREE (jxs_rigid.inc ta_*): (J M^-1 J^T + D) x = c with D block diagonal per
+  // point is x = D^-1 (c - J a), (M + J^T D^-1 J) a = J^T D^-1 c -- a forward-dynamics solve of the same tree whose contact
+  // links carry the extra 6 x 6 "inertia" W_l = sum_p P_p^T D_p^-1 P_p.  No matrix, no rank decision, any number of contact
+  // links.  1: this model's contact solves run that way (decided by the packer).
+  int ct_tree;
   int jump_pad;                  // 1: pointer-jumping sources beyond the base point at a padding lane that holds the identity
                                  // transform and zero vectors (no selects in the rounds); 0: they are -1 (no padding lane: nL == G)
   // [round 3] The joint rows (and, with one point chunk of <= G collidable points, the deformation rows) of the state are

@@ -301,7 +301,7 @@ def planar_biped_urdf(sole=(0.2, 0.08, 0.04)) -> str:
 
 
 def chain_urdf(n_links: int = 5, fixed_base: bool = True, seed: int = 0, max_back: int = 3, collision_links=None,
-               parallel_axes: str | None = None) -> str:
+               parallel_axes: str | None = None, base_offset=(0.1, -0.2, 0.5)) -> str:
     """Random serial/branching chain with mixed revolute/prismatic joints, skewed axes and
     rotated joint frames: a stress model for parity tests (cf. the reference's scalable
     "garpez" fixture, ``tests/conftest.py:479-707``).  The parent of link i is one of the ``max_back``
@@ -309,7 +309,9 @@ def chain_urdf(n_links: int = 5, fixed_base: bool = True, seed: int = 0, max_bac
     box (default: the first and the last link of a floating chain, none of a fixed one).
     ``parallel_axes``: ``"all"`` -- every joint revolute about x with unrotated joint frames (a planar mechanism: the
     relative twist of any two links spans 3 dimensions); ``"aligned"`` -- revolute joints about one of the coordinate
-    axes, unrotated frames (runs of parallel axes, as in real robots); ``None`` -- axes in general position."""
+    axes, unrotated frames (runs of parallel axes, as in real robots); ``None`` -- axes in general position.
+    ``base_offset``: where the fixed joint places the base link of a fixed-base chain in the world (the rigid contact
+    models refuse a base-link offset: their fuzz campaigns pass zeros)."""
     rng = np.random.default_rng(seed)
     out = ['<robot name="chain">']
     if collision_links is None:
@@ -324,7 +326,7 @@ def chain_urdf(n_links: int = 5, fixed_base: bool = True, seed: int = 0, max_bac
         coll = _box_collision(dims, xyz=com) if i in collision_links else ""
         out.append(f'<link name="link{i:02d}">' + _inertial(m, com=com, I=_box_inertia(m, *dims), rpy=rpy) + coll + "</link>")
     if fixed_base:
-        out.append(_joint("world_to_base", "fixed", "world", "link00", (0.1, -0.2, 0.5), (0, 0, 0)))
+        out.append(_joint("world_to_base", "fixed", "world", "link00", tuple(base_offset), (0, 0, 0)))
     for i in range(1, n_links):
         parent = int(rng.integers(max(0, i - max_back), i))
         jt = "prismatic" if rng.uniform() < 0.25 else "revolute"

@@ -14,11 +14,24 @@
 #include "../../jaxsim_amd/csrc/jxs_core.h"
 #include "../../jaxsim_amd/csrc/jxs_pack.h"
 
-namespace {
+// The emulation is built as several translation units in parallel (tests/emul_binding.py): one per (dtype, lanes per
+// environment) -- compiled with -DJXS_EMUL_UNIT_T=<float|double> -DJXS_EMUL_UNIT_G=<4..64>, each holds the explicit
+// instantiation of run_group for that pair (the kernel core in all its modes) -- and the main unit (no macro) with the
+// packer, the dispatch and the C entry points.  One g++ run over everything took 3.5 minutes.
+namespace jxs_emul {
 
+#ifdef JXS_EMUL_UNIT_G
+extern thread_local std::string g_err;
+extern void* g_dbg_ptr;
+#else
 thread_local std::string g_err;
 void* g_dbg_ptr = nullptr;
+#endif
 
+template <typename T, int G>
+void run_group(const jxs::Packed<T>& pk, jxs::KArgs<T> a, int mode);
+
+#ifdef JXS_EMUL_UNIT_G
 template <typename T, int G>
 void run_group(const jxs::Packed<T>& pk, jxs::KArgs<T> a, int mode) {
   a.ltf = pk.ltf.data();
@@ -51,6 +64,9 @@ void run_group(const jxs::Packed<T>& pk, jxs::KArgs<T> a, int mode) {
     }
   }
 }
+template void run_group<JXS_EMUL_UNIT_T, JXS_EMUL_UNIT_G>(const jxs::Packed<JXS_EMUL_UNIT_T>&, jxs::KArgs<JXS_EMUL_UNIT_T>, int);
+}  // namespace jxs_emul
+#else
 
 template <typename T>
 int run_typed(const jxs_model_desc* d, int mode, const void* state_in, void* state_out, const void* tau,
@@ -150,7 +166,8 @@ int run_typed(const jxs_model_desc* d, int mode, const void* state_in, void* sta
   return JXS_OK;
 }
 
-}  // namespace
+}  // namespace jxs_emul
+using namespace jxs_emul;
 
 template <typename T>
 static int layout_typed(const jxs_model_desc* d, jxs_layout* out) {
@@ -184,3 +201,4 @@ int jxs_emul_run(const jxs_model_desc* d, int mode, const void* state_in, void* 
   return run_typed<float>(d, mode, state_in, state_out, tau, link_f, force_repr, in_a, out_a, out_H, out_V, N, n_steps);
 }
 }
+#endif  // main unit

@@ -25,13 +25,30 @@ MODE_STEP_DUO = MODE_STEP | 0x100  # the two-wave workgroup variant of the step 
 
 
 def build(force: bool = False) -> pathlib.Path:
+    """One g++ run per (dtype, lanes per environment) unit of tests/emul/jxs_emul.cpp and one for its main unit, in
+    parallel, then the link (~1 min on 8 cores instead of 3.5 min for a single translation unit)."""
     deps = [_SRC, _HERE / "emul" / "jxs_lanes_host.h"] + sorted((_ROOT / "jaxsim_amd" / "csrc").glob("*.h")) + sorted((_ROOT / "jaxsim_amd" / "csrc").glob("*.inc"))
     deps.append(_ROOT / "include" / "jaxsim_amd.h")
     if force or not _SO.exists() or any(d.stat().st_mtime > _SO.stat().st_mtime for d in deps):
-        cmd = ["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas",
-               f"-I{_ROOT / 'jaxsim_amd' / 'csrc'}", f"-I{_HERE / 'emul'}", str(_SRC), "-o", str(_SO)]  # fmt: skip
-        cmd[1:1] = os.environ.get("JXS_EMUL_CXXFLAGS", "").split()  # developer aid, e.g. -DJXS_RIGID_DEBUG
-        subprocess.run(cmd, check=True)
+        from concurrent.futures import ThreadPoolExecutor
+
+        objdir = _HERE / "emul" / "build"
+        objdir.mkdir(exist_ok=True)
+        base = ["g++", "-O1", "-std=c++17", "-fPIC", "-Wno-unknown-pragmas", f"-I{_ROOT / 'jaxsim_amd' / 'csrc'}", f"-I{_HERE / 'emul'}"]  # fmt: skip
+        base[1:1] = os.environ.get("JXS_EMUL_CXXFLAGS", "").split()  # developer aid, e.g. -DJXS_RIGID_DEBUG
+        units = [("main", [])] + [(f"{t}_{g}", [f"-DJXS_EMUL_UNIT_T={t}", f"-DJXS_EMUL_UNIT_G={g}"]) for g in (64, 32, 16, 8, 4) for t in ("double", "float")]
+
+        def one(unit):
+            name, defs = unit
+            obj = objdir / f"{name}.o"
+            subprocess.run(base + defs + ["-c", str(_SRC), "-o", str(obj)], check=True)
+            return str(obj)
+
+        with ThreadPoolExecutor(os.cpu_count() or 4) as ex:
+            objs = list(ex.map(one, units))
+        tmp = _SO.with_suffix(f".tmp{os.getpid()}.so")
+        subprocess.run(["g++", "-shared", "-o", str(tmp)] + objs, check=True)
+        os.replace(tmp, _SO)
     return _SO
 
 

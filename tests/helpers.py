@@ -66,14 +66,19 @@ class ModelZoo:
         "cartpole": lambda: robots.cartpole_urdf(),
         "chain5": lambda: robots.chain_urdf(5, fixed_base=True, seed=1),
         "chain9f": lambda: robots.chain_urdf(9, fixed_base=False, seed=2),
-        # a serial floating chain: its two collision boxes (first and last link) are eleven joints apart -- link space (jxs_pack.h)
+        # a serial floating chain: its two collision boxes (first and last link) are eleven joints apart
         "serial12f": lambda: robots.chain_urdf(12, fixed_base=False, seed=4, max_back=1),
+        # [round 5] every joint axis parallel: the relative twist of any two links spans three dimensions, whatever the number
+        # of joints between them (a Walker2d-style planar biped with a floating base; a planar serial chain)
+        "planar_biped": lambda: robots.planar_biped_urdf(),
+        "planar10f": lambda: robots.chain_urdf(10, fixed_base=False, seed=6, max_back=1, parallel_axes="all"),
         "anymal": lambda: robots.anymal12_urdf(),
         "icub": lambda: robots.icub23_urdf(),
         "icub16": lambda: robots.icub23_urdf(sole_boxes_per_foot=1),
     }
     # base height range putting some collidable points in contact
     contact_z = {"box": (0.0, 0.1), "sphere": (0.09, 0.12), "chain9f": (0.0, 0.3), "serial12f": (0.0, 0.3), "anymal": (0.58, 0.70),
+                 "planar_biped": (0.78, 0.95), "planar10f": (0.0, 0.3),
                  "icub": (0.56, 0.68), "icub16": (0.56, 0.68)}  # fmt: skip
 
     def __init__(self):
@@ -243,28 +248,6 @@ def rigid_model(model, idx, *, build=None, **params):
     ``tests/test_simulations.py:245-270``)."""
     cm = ja.RigidContacts.build(**(build or {}))
     return enable_points(with_params(model, contact_model=cm, contact_params=ja.RigidContactsParams(**params)), idx)
-
-
-def contact_link_separation(model) -> int | None:
-    """Joints on the tree path between the two links that carry the ENABLED collidable points (None unless there are
-    exactly two such links): the link-space contact solve needs six or more (csrc/jxs_pack.h: the 12 x 12 inverse
-    operational-space inertia of two links fewer joints apart is singular)."""
-    kdp = model.kin_dyn_parameters
-    bodies = sorted({int(b) for b, e in zip(np.asarray(kdp.contact_body), np.asarray(kdp.contact_enabled)) if e})
-    if len(bodies) != 2:
-        return None
-    parent = np.asarray(model.kin_dyn_parameters.parent_array)
-
-    def chain(i):
-        out = [i]
-        while parent[i] >= 0:
-            i = int(parent[i])
-            out.append(i)
-        return out
-
-    ca, cb = chain(bodies[0]), chain(bodies[1])
-    common = next(x for x in ca if x in cb)
-    return ca.index(common) + cb.index(common)
 
 
 def relaxed_model(model, idx, *, build=None, **params):
