@@ -69,8 +69,9 @@ def _check_quaternion(model, data: JaxSimModelData, *, normalized: bool) -> None
 
 
 def solver_fault_counts(model: JaxSimModel, dtype=np.float64, *, reset: bool = False) -> tuple[int, int]:
-    """RigidContacts: environments whose contact-force QP / impact solve was discarded (non-finite result) by
-    the steps of this model since the last reset -- ``(contact_force_solves, impact_solves)``.  The reference
+    """RigidContacts / RelaxedRigidContacts: environments whose contact-force solve / impact solve was discarded
+    (non-finite result) by the steps of this model since the last reset -- ``(contact_force_solves, impact_solves)``
+    (the relaxed model has no impact: its second count stays 0).  The reference
     would carry the NaN into the state (``rbda/contacts/rigid.py:331-379``); here the environment takes that
     step without contact forces, and the event is counted instead of being silent."""
     dm = runtime.device_model(model, np.dtype(dtype))
@@ -81,11 +82,11 @@ def solver_fault_counts(model: JaxSimModel, dtype=np.float64, *, reset: bool = F
 
 def _check_solver_faults(model, data: JaxSimModelData) -> None:
     """With ``JAXSIM_ENABLE_EXCEPTIONS`` a discarded solve raises like the reference's NaN checks would."""
-    if not _exceptions_enabled() or type(model.contact_model).__name__ != "RigidContacts":
+    if not _exceptions_enabled() or type(model.contact_model).__name__ not in ("RigidContacts", "RelaxedRigidContacts"):
         return
     qp, imp = solver_fault_counts(model, data.dtype, reset=True)
     if qp or imp:
-        raise ValueError(f"RigidContacts: {qp} contact-force solve(s) and {imp} impact solve(s) were not finite and were discarded")
+        raise ValueError(f"{type(model.contact_model).__name__}: {qp} contact-force solve(s) and {imp} impact solve(s) were not finite and were discarded")
 
 
 def _ptr(d: DeviceArray | None):

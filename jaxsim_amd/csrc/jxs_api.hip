@@ -100,8 +100,6 @@ struct ModelT {
   SpecLaunch spec_launch[16] = {};
   void* spec_handle[16] = {};
   int* faults = nullptr;  // [2] discarded contact-force / impact solves since the last reset (rigid contact models)
-  void* tau_scratch = nullptr;  // jxs_rollout_controlled, one launch per step: the torques of the current step, [n][N]
-  size_t tau_scratch_bytes = 0;
 
   ~ModelT() {
     // The specialised-kernel objects are NOT unloaded (attach_typed): launches of this model may still be in
@@ -110,7 +108,6 @@ struct ModelT {
     // which also keeps them visible in /proc/self/maps to whoever audits which native code ran.
     (void)hipFree(mblk);
     (void)hipFree(faults);
-    if (tau_scratch != nullptr) (void)hipFree(tau_scratch);
   }
 
   hipError_t upload_all() {
@@ -213,6 +210,14 @@ int run_typed(jxs_model* model, int mode, const void* state_in, void* state_out,
     if (traj != nullptr) a.out_a = static_cast<T*>(traj);  // recorded: the kernel stores the state after every step (jxs_core.h)
   }
   const bool tau_seq = (extra_flags & 4) != 0 && a.tau != nullptr;
+  struct Scratch {  // the torques of the current step, [n][N]: released behind the last launch on every way out
+    void* p = nullptr;
+    hipStream_t s;
+    ~Scratch() {
+      if (p != nullptr) (void)hipFreeAsync(p, s);
+    }
+  } scratch;
+  scratch.s = s;
   const T* const tau_all = a.tau;
   const int seq_steps = a.n_steps > 1 ? a.n_steps : repeat;
   if (tau_seq && mode != jxs::MODE_ROLLOUT) {
@@ -222,20 +227,22 @@ int run_typed(jxs_model* model, int mode, const void* state_in, void* state_out,
     a.flags &= ~4;
     const int tile = 64 / mt->pk.G;
     const size_t need = sizeof(T) * (size_t)((N + tile - 1) / tile) * tile * mt->pk.P.n;
-    if (mt->tau_scratch_bytes < need) {
-      if (mt->tau_scratch != nullptr) (void)hipFree(mt->tau_scratch);
-      mt->tau_scratch = nullptr, mt->tau_scratch_bytes = 0;
-      JXS_HIP(hipMalloc(&mt->tau_scratch, need));
-      mt->tau_scratch_bytes = need;
-    }
+    // [ADVICE r4] the gather block belongs to THIS call and to its stream (hipMallocAsync / hipFreeAsync: stream-ordered,
+    // no device-wide synchronisation on the launch path, nothing shared between two streams or threads that roll out
+    // the same model -- round 4 kept one block per model and re-allocated it with hipFree + hipMalloc when N grew).
+    // An allocation cannot be part of a stream capture: refused there.
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+      return fail(JXS_EINVAL, "a rollout with a torque sequence that runs one launch per step allocates its gather block: not inside a stream capture");
+    JXS_HIP(hipMallocAsync(&scratch.p, need, s));
   }
   for (int it = 0; it < repeat; ++it) {
     if (tau_seq && mode != jxs::MODE_ROLLOUT) {
       const int tile = 64 / mt->pk.G, n = mt->pk.P.n;
       const size_t row_bytes = sizeof(T) * (size_t)tile;
-      JXS_HIP(hipMemcpy2DAsync(mt->tau_scratch, row_bytes * n, reinterpret_cast<const char*>(tau_all) + row_bytes * n * it,
+      JXS_HIP(hipMemcpy2DAsync(scratch.p, row_bytes * n, reinterpret_cast<const char*>(tau_all) + row_bytes * n * it,
                                row_bytes * n * seq_steps, row_bytes * n, (size_t)((N + tile - 1) / tile), hipMemcpyDeviceToDevice, s));
-      a.tau = static_cast<const T*>(mt->tau_scratch);
+      a.tau = static_cast<const T*>(scratch.p);
     }
     hipError_t e = (mode >= 0 && mode < 16 && mt->spec_launch[mode] != nullptr)
                        ? static_cast<hipError_t>(mt->spec_launch[mode](&mt->pk.P, mt->mblk, &a, s))
@@ -707,22 +714,36 @@ int jxs_step_repeat_timed(jxs_model* model, void* state, const void* tau, const 
   // stream writes behind the last launch (hipStreamWriteValue32) and this thread polls -- no runtime call inside the
   // wait (JXS_TIMED_WAIT_QUERY=1: poll hipStreamQuery instead, the round-3 bracket; developer knob, A/B)
   static const bool by_query = std::getenv("JXS_TIMED_WAIT_QUERY") != nullptr;
-  static thread_local volatile uint32_t* flag = nullptr;
-  static thread_local uint32_t seq = 0;
-  if (!by_query && flag == nullptr) {
+  // [ADVICE r4] ONE pinned line per process (64 words: a word per calling thread, handed out once and never freed while
+  // the library is loaded -- round 4 allocated a line per thread and leaked it), and a poll that cannot hang: a faulted
+  // launch or a stream error never writes the word, so every 4096 spins the stream is asked (hipStreamQuery returns the
+  // error, or success when the word was missed for another reason) and its status is read once after the word is seen.
+  static volatile uint32_t* line = [] {
     void* p = nullptr;
-    if (hipHostMalloc(&p, 64, hipHostMallocDefault) == hipSuccess) {
-      flag = static_cast<volatile uint32_t*>(p);
-      *flag = 0;
-    }
-  }
+    if (hipHostMalloc(&p, 64 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) return static_cast<volatile uint32_t*>(nullptr);
+    std::memset(p, 0, 64 * sizeof(uint32_t));
+    return static_cast<volatile uint32_t*>(p);
+  }();
+  static std::atomic<int> next_word{0};
+  static thread_local int my_word = -1;
+  static thread_local uint32_t seq = 0;
+  if (my_word < 0) my_word = next_word.fetch_add(1);
+  volatile uint32_t* flag = (line != nullptr && my_word < 64) ? line + my_word : nullptr;
   bool polled = false;
   if (!by_query && flag != nullptr && stream != nullptr) {
     const uint32_t want = ++seq;
-    if (hipStreamWriteValue32(static_cast<hipStream_t>(stream), const_cast<uint32_t*>(flag), want, 0) == hipSuccess) {
-      while (*flag != want) {
-      }
+    hipStream_t hs = static_cast<hipStream_t>(stream);
+    if (hipStreamWriteValue32(hs, const_cast<uint32_t*>(flag), want, 0) == hipSuccess) {
       polled = true;
+      for (unsigned spins = 0; *flag != want; ++spins) {
+        if ((spins & 4095u) == 4095u) {
+          const hipError_t q = hipStreamQuery(hs);
+          if (q == hipSuccess) break;                                      // the stream drained: the word is (or is about to be) there
+          if (q != hipErrorNotReady) return hip_fail(q, "hipStreamQuery");  // a faulted launch: report it instead of spinning for ever
+        }
+      }
+      const hipError_t q = hipStreamQuery(hs);
+      if (q != hipSuccess && q != hipErrorNotReady) return hip_fail(q, "hipStreamQuery");
     } else {
       (void)hipGetLastError();
     }

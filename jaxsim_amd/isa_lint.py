@@ -31,7 +31,22 @@ import subprocess
 import sys
 import tempfile
 
-OBJDUMP = os.environ.get("LLVM_OBJDUMP", "/opt/rocm/lib/llvm/bin/llvm-objdump")
+def _default_objdump() -> str:
+    """llvm-objdump of the ROCm installation whose hipcc builds the kernels (``HIPCC``, default /opt/rocm/bin/hipcc)."""
+    hipcc = os.path.realpath(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"))
+    for root in (os.path.dirname(os.path.dirname(hipcc)), "/opt/rocm"):
+        cand = os.path.join(root, "lib", "llvm", "bin", "llvm-objdump")
+        if os.path.isfile(cand):
+            return cand
+    return "/opt/rocm/lib/llvm/bin/llvm-objdump"
+
+
+OBJDUMP = os.environ.get("LLVM_OBJDUMP") or _default_objdump()
+
+
+def available() -> bool:
+    """The disassembler the lint needs is there (jaxsim_amd/specialize.py asks before it promises to build)."""
+    return os.path.isfile(OBJDUMP) and os.access(OBJDUMP, os.X_OK)
 
 # wait states a DPP instruction needs behind a SCALAR write of EXEC (0 = the hardware interlocks; see the module text)
 SALU_EXEC_DPP_STATES = int(os.environ.get("JXS_LINT_SALU_EXEC_STATES", "0"))
@@ -295,8 +310,15 @@ def _describe(n: str, h: dict) -> str:
 
 
 def check(path: str) -> None:
-    """Raise ``RuntimeError`` naming the first sites when ``path`` carries a wait-state hazard."""
-    _counts, hits = lint_file(path)
+    """Raise ``RuntimeError`` naming the first sites when ``path`` carries a wait-state hazard -- and when the lint could
+    not look at all: no disassembler, a disassembler that fails, or an object in which it finds no kernel (e.g. a
+    compressed offload bundle): a vacuous pass is not a pass.  [ADVICE r4]"""
+    try:
+        counts, hits = lint_file(path)
+    except (OSError, subprocess.SubprocessError) as exc:
+        raise RuntimeError(f"{path}: the ISA lint could not run ({OBJDUMP}: {exc!r})") from exc
+    if not counts:
+        raise RuntimeError(f"{path}: the ISA lint found no device kernel in the object (compressed or foreign offload bundle?)")
     if hits:
         lines = [_describe(n, h) for n, h in hits[:12]]
         raise RuntimeError(f"{path}: {len(hits)} hazard(s) in the device code (jaxsim_amd/isa_lint.py):\n" + "\n".join(lines))

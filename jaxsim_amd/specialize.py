@@ -133,13 +133,22 @@ def compile_text(text: str, *, force: bool = False) -> pathlib.Path:
     # queue on its lock file; whoever gets it second finds the object built and returns it
     import fcntl
 
-    with open(out.with_suffix(".lock"), "w") as lock:
+    lock_path = out.with_suffix(".lock")
+    with open(lock_path, "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:
             if out.exists() and not force:
                 return out
             return _compile_locked(text, fields, assign, out)
         finally:
+            # [round 5] the lock file goes when its build ends (round 4 left 2528 of them in the cache, and they travelled
+            # to every GPU box).  A process still queued on the unlinked file gets its lock, finds the object and returns;
+            # one that arrives later makes a new file -- at worst two builders, each renaming a complete object into place.
+            if out.exists():
+                try:
+                    lock_path.unlink()
+                except OSError:
+                    pass
             fcntl.flock(lock, fcntl.LOCK_UN)
 
 
@@ -159,9 +168,11 @@ def _compile_locked(text: str, fields: dict, assign: str, out: pathlib.Path) -> 
         from . import isa_lint
 
         isa_lint.check(str(tmp))
-    except RuntimeError:
-        tmp.unlink(missing_ok=True)
-        raise
+    except Exception as exc:  # [ADVICE r4] whatever the lint dies of, the temporary object goes and the caller sees ONE
+        tmp.unlink(missing_ok=True)  # exception type it already handles (attach / ensure_mode fall back to the library's kernel)
+        if isinstance(exc, RuntimeError):
+            raise
+        raise RuntimeError(f"ISA lint of the specialised kernel failed to run: {exc!r}") from exc
     os.replace(tmp, out)  # atomic: concurrent ranks may build the same object
     return out
 
@@ -248,7 +259,10 @@ def modes(dm) -> list[int]:
 
 
 def hipcc_available() -> bool:
-    return os.path.isfile(_HIPCC) and os.access(_HIPCC, os.X_OK)
+    """The compiler AND the disassembler of the ISA lint are there: a build that cannot be linted is not attempted."""
+    from . import isa_lint
+
+    return os.path.isfile(_HIPCC) and os.access(_HIPCC, os.X_OK) and isa_lint.available()
 
 
 def policy() -> str:

@@ -20,10 +20,10 @@ from test_gpu_parity import RELAXED_CASES, RIGID_CASES, _rk4, to_gpu
 
 pytestmark = pytest.mark.gpu
 
-ZOO = ["box", "sphere", "pendulum", "double_pendulum", "cartpole", "chain5", "chain9f", "anymal", "icub", "icub16"]
+ZOO = ["box", "sphere", "pendulum", "double_pendulum", "cartpole", "chain5", "chain9f", "anymal", "icub", "icub16", "planar_biped"]
 RK4_SOFT = ["box", "sphere", "cartpole", "chain9f", "anymal", "icub16", "icub"]  # (the models test_rk4_step_matches_oracle_gpu steps)
 RK4_RIGID = ["box4", "anymal4", "icub8"]
-RK4_RELAXED = ["box8", "anymal16", "chain9f6", "icub16"]
+RK4_RELAXED = ["box8", "anymal16", "chain9f6", "icub16", "planar_biped"]
 
 
 def _cases():

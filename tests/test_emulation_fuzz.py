@@ -12,7 +12,7 @@ ROOT = pathlib.Path(__file__).resolve().parent.parent
 
 
 @pytest.mark.parametrize("script,seed,trials", [("fuzz_step.py", 21, 40), ("fuzz_rigid.py", 22, 30), ("fuzz_query.py", 23, 25),
-                                                ("fuzz_rollout.py", 24, 30)])  # fmt: skip
+                                                ("fuzz_rollout.py", 24, 30), ("fuzz_contact_tree.py", 25, 30)])  # fmt: skip
 def test_fuzz_slice(script, seed, trials):
     env = dict(os.environ, PYTHONPATH=os.pathsep.join([str(ROOT), str(ROOT / "tests"), os.environ.get("PYTHONPATH", "")]))
     p = subprocess.run([sys.executable, str(ROOT / "tools" / "fuzz" / script), str(seed), str(trials)], capture_output=True, text=True,
@@ -20,3 +20,9 @@ def test_fuzz_slice(script, seed, trials):
     assert p.returncode == 0, p.stderr[-2000:]
     last = [ln for ln in p.stdout.splitlines() if ln.startswith("fails")]
     assert last and last[-1].startswith("fails 0 "), p.stdout[-2000:]
+    # [ADVICE r4] a campaign that refuses or skips most of its trials proves little: the ones that count what they
+    # compared must have compared at least three quarters of what they drew
+    words = last[-1].split()
+    if "compared" in words:
+        compared, refused, failed = (int(words[words.index(k) + 1]) for k in ("compared", "refused", "oracle_failed"))
+        assert compared >= 0.75 * (compared + refused + failed), last[-1]

@@ -565,7 +565,7 @@ def test_relaxed_defaults_in_fp32_stay_finite(models):
     """[round 4] The reference's default RelaxedRigidContacts parameters (mu = 0.005) in fp32 with every sole point of the
     humanoid active (a Delassus matrix of rank 12 in 96 unknowns, the regulariser below its fp32 rounding): pivots at the
     rounding floor are dropped and the refinement is safeguarded (jxs_rigid.inc relaxed_contact_forces) -- finite states
-    a few per cent from fp64, where rounds 1-3 returned NaN; fp64 takes link space and is exact."""
+    a few per cent from fp64, where rounds 1-3 returned NaN; fp64 is solved in the tree and is exact."""
     model = helpers.relaxed_model(models("icub"), list(range(32)))
     d32 = helpers.standing_data(model, 12, seed=0, dtype=np.float32, noise=0.003)
     truth = helpers.odata_to_block(model, oracle.step(model, helpers.upcast(d32)))

@@ -9,13 +9,14 @@ import emul_binding as eb, helpers, oracle
 import jaxsim_amd as ja
 from jaxsim_amd import robots
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 5)
-nfail = 0; worst = {}
+nfail = 0; worst = {}; compared = refused = oracle_failed = 0
 for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
     n_links = int(rng.integers(1, 25)); seed = 5000 + trial; fixed = bool(rng.integers(0, 4) == 0) and n_links > 1
     mb = int(rng.integers(1, 4))
     ncl = int(rng.integers(1, 4))
     cl = tuple(sorted(set(int(v) for v in rng.integers(0, n_links, size=ncl))))
-    base = ja.JaxSimModel.build_from_model_description(robots.chain_urdf(n_links, fixed_base=fixed, seed=seed, max_back=mb, collision_links=cl))
+    base = ja.JaxSimModel.build_from_model_description(robots.chain_urdf(n_links, fixed_base=fixed, seed=seed, max_back=mb, collision_links=cl,
+                                                                         base_offset=(0.0, 0.0, 0.0) if trial % 4 else (0.1, -0.2, 0.5)))  # (a base-link offset is refused by the rigid models: one fixed tree in four keeps it, to cover the refusal)
     npts = 8 * len(cl)
     k = int(rng.integers(1, npts + 1))
     idx = sorted(int(v) for v in rng.choice(npts, size=k, replace=False))
@@ -31,13 +32,14 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
         ref = oracle.step(model, d)
         out = eb.run(model, eb.MODE_STEP, blk)
     except RuntimeError as ex:
-        print('refused', trial, n_links, fixed, cl, len(idx), kind, str(ex)[:80]); continue
+        refused += 1; print('refused', trial, n_links, fixed, cl, len(idx), kind, str(ex)[:80]); continue
     except np.linalg.LinAlgError as ex:
-        print('oracle failed', trial, kind); continue
+        oracle_failed += 1; print('oracle failed', trial, kind); continue
+    compared += 1
     e = helpers.rel_err(out, helpers.odata_to_block(model, ref))
     key = (kind, 'rk4' if integ else 'euler')
     worst[key] = max(worst.get(key, 0), e)
     tol = 1e-8 if kind == 'relaxed' else 1e-5
     if not (e < tol):
         nfail += 1; print('FAIL', trial, 'nL', n_links, 'fixed', fixed, 'mb', mb, 'coll', cl, 'points', idx, key, '%.2e'%e)
-print('fails', nfail, worst)
+print('fails', nfail, 'compared', compared, 'refused', refused, 'oracle_failed', oracle_failed, worst)
