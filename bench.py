@@ -132,6 +132,10 @@ def parse_args():
     ap.add_argument("--model", default="icub23", choices=["icub23", "icub23_16", "anymal12", "cartpole"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="developer: run the multi-rank code path even with WORLD_SIZE=1")
+    ap.add_argument("--require-rccl", action="store_true", default=os.environ.get("JAXSIM_AMD_REQUIRE_RCCL", "") not in ("", "0"),
+                    help="multi-rank runs: a rank whose communicator is not RCCL (ncclCommInitRank failed and the host-side file collective "
+                    "would take over) exits non-zero instead -- a scaling record cannot be a file collective by accident "
+                    "(also JAXSIM_AMD_REQUIRE_RCCL=1)")
     ap.add_argument("--share-device", action="store_true", help="developer: ranks take device LOCAL_RANK %% device_count -- the N > 1 path on a box with fewer GPUs than ranks (RCCL refuses two ranks on one device: the host-side file collective takes over, `comm.kind` says so); the figure is not a scaling measurement")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=10.0)
     ap.add_argument("--saturated-envs", type=int, default=65536, help="secondary figure: batch that saturates one GPU (0 = skip)")
@@ -567,13 +571,16 @@ def dry_run_bootstrap(args, rank, world, result_out):
     his = fc.all_gather_scalars(float(hi))
     ids = fc.all_gather_scalars(float(int.from_bytes(uid[:6], "little")))
     t = [float(fc.all_gather_scalars(0.001 * (r + 1)).max()) for r in range(3)]  # the max-over-ranks reduction
+    # the device each rank would select (main(): LOCAL_RANK, or LOCAL_RANK % device_count with --share-device)
+    devs = [int(v) for v in fc.all_gather_scalars(float(int(os.environ.get("LOCAL_RANK", "0"))))]
     ok = (los[0] == 0 and his[-1] == n_total and all(his[r] == los[r + 1] for r in range(world - 1))
           and all(his[r] - los[r] == args.envs_per_gpu for r in range(world)) and len(set(ids.tolist())) == 1)  # fmt: skip
     fc.barrier()
     if rank == 0:
         print(json.dumps({"dry_run_bootstrap": True, "ok": bool(ok), "n_gpus": world, "global_batch": n_total,
                           "shards": [[int(a), int(b)] for a, b in zip(los, his)], "same_id_on_all_ranks": len(set(ids.tolist())) == 1,
-                          "max_over_ranks": t, "job_key": key}), file=result_out, flush=True)  # fmt: skip
+                          "max_over_ranks": t, "job_key": key, "device_of_rank": devs, "distinct_devices": len(set(devs)) == world,
+                          "require_rccl": bool(args.require_rccl)}), file=result_out, flush=True)  # fmt: skip
     if not ok:
         raise SystemExit(f"rank {rank}: bootstrap dry run failed: {los} {his} {ids}")
 
@@ -663,6 +670,10 @@ def main():
             comm = distributed.communicator_from_env()
         except Exception as e:  # keep the bench line: fall back to a host-side file collective
             comm_error = repr(e)
+            if args.require_rccl:
+                # [round 5] asked to be fatal: the launcher (torch.distributed.run or bench.py itself) takes the other ranks down
+                print(f"bench.py: rank {rank}: --require-rccl and the RCCL communicator could not be created: {comm_error}", file=sys.stderr, flush=True)
+                raise SystemExit(3)
             comm = distributed.FileCollective(rank, world, distributed.job_key())
     dtype = np.dtype(args.dtype)
     model = build_model(args.model)
@@ -802,6 +813,38 @@ def main():
         controlled_us = controlled_us if controlled_us is not None else repr(e)
         recorded_us = repr(e)
 
+    # [round 5] What a USER of the reference gets: the literal loop `for _ in range(K): data = js.model.step(model, data)`
+    # (README.md:80-83, tests/test_simulations.py:170-191) -- one Python call, one ctypes call, one plain launch per step,
+    # a fresh data object per step (functional, like the reference's pytrees) or the same buffer (`inplace=True`, an
+    # extension).  `value` above is the same launches enqueued from C (`jxs_step_repeat`); this is the interpreter's share.
+    python_loop = None
+    if rank == 0:
+        try:
+            import time as _time
+
+            K_py = 2000
+            python_loop = {"steps": K_py, "idiom": "for _ in range(K): data = js.model.step(model, data)"}
+            for label, kw in (("functional", {}), ("inplace", {"inplace": True})):
+                d_py = js.data.JaxSimModelData.from_state_block(model, initial_block.astype(dtype), data.velocity_representation)
+                for _ in range(50):
+                    d_py = js.model.step(model, d_py, **kw)
+                runtime.synchronize(stream)
+                best = None
+                for _rep in range(3):
+                    t0 = _time.perf_counter()
+                    for _ in range(K_py):
+                        d_py = js.model.step(model, d_py, **kw)
+                    t_enq = _time.perf_counter() - t0  # the interpreter is done enqueueing
+                    runtime.synchronize(stream)
+                    t_all = _time.perf_counter() - t0
+                    if best is None or t_all < best[1]:
+                        best = (t_enq, t_all)
+                python_loop[label] = {"us_per_call": best[1] / K_py * 1e6, "host_enqueue_us_per_call": best[0] / K_py * 1e6,
+                                      "env_steps_per_s": n_local * K_py / best[1]}
+                del d_py
+        except Exception as e:  # secondary: never lose the headline for it
+            python_loop = {"error": repr(e)}
+
     # secondary figure: the same kernel with the chip saturated (64 Ki environments on this GPU) -- what
     # the step costs once enough waves hide each other's latencies.  Not the headline configuration.
     saturated = None
@@ -849,6 +892,29 @@ def main():
         except Exception as e:  # the gather is outside the timed region: report, do not lose the line
             allgather_error = repr(e)
     nonfinite_envs = int((~np.isfinite(final).all(axis=0)).sum())
+    # [round 5] what the communicator was: library version, and the device every rank ran on (PCI bus ids, gathered as
+    # integers domain << 16 | bus << 8 | device << 3 | function through the communicator itself)
+    import ctypes as _C
+
+    nccl_version, pci_ids = None, None
+    try:
+        buf = _C.create_string_buffer(32)
+        _lib.check(lib.jxs_device_pci_bus_id(buf, 32), "jxs_device_pci_bus_id")
+        my_pci = buf.value.decode()
+        dom, bus, devfn = my_pci.split(":")
+        dev_, fn_ = devfn.split(".")
+        code = (int(dom, 16) << 16) | (int(bus, 16) << 8) | (int(dev_, 16) << 3) | int(fn_, 16)
+        if comm is not None:
+            codes = [int(c) for c in comm.all_gather_scalars(float(code))]
+            pci_ids = [f"{c >> 16:04x}:{(c >> 8) & 0xff:02x}:{(c >> 3) & 0x1f:02x}.{c & 7:x}" for c in codes]
+        else:
+            pci_ids = [my_pci]
+        if comm is not None and comm_error is None:
+            v = _C.c_int(0)
+            _lib.check(lib.jxs_comm_version(_C.byref(v)), "jxs_comm_version")
+            nccl_version = int(v.value)
+    except Exception as e:  # reporting only
+        pci_ids = pci_ids if pci_ids is not None else repr(e)
 
     if rank == 0:
         lay = dm.layout
@@ -920,9 +986,13 @@ def main():
                               "that trajectory, DESIGN.md section 7",
             "allgather_ms": allgather_ms,
             "allgather_error": allgather_error,
-            "comm": None if comm is None else {"kind": type(comm).__name__, "ranks": comm_ranks, "error": comm_error,
+            "comm": None if comm is None else {"kind": "rccl" if comm_error is None else "file_collective", "class": type(comm).__name__, "ranks": comm_ranks,
+                                               "error": comm_error, "nccl_version": nccl_version, "require_rccl": bool(args.require_rccl),
+                                               "distinct_devices": (len(set(pci_ids)) == len(pci_ids)) if isinstance(pci_ids, list) else None,
                                                "ms_per_step_per_rank": per_rank_ms},
+            "device_pci_bus_ids": pci_ids,
             "steady_state": steady,
+            "python_step_loop": python_loop,
             "generic_kernel": generic,
             "fused_rollout": {"us_per_step": rollout_ms_per_step * 1e3, "env_steps_per_s_rank0": n_local / (rollout_ms_per_step * 1e-3),
                               "controlled_us_per_step": controlled_us,

@@ -299,6 +299,12 @@ int jxs_refresh_kinematics(jxs_model* model, const void* state, void* out_link_t
 int jxs_comm_unique_id(char id[128]);
 int jxs_comm_init(void** comm, const char id[128], int rank, int world_size);
 int jxs_comm_destroy(void* comm);
+/* [round 5] what a scaling record must be able to say about its communicator: the version of the RCCL library the
+ * ranks talk through (ncclGetVersion: e.g. 22107) and the PCI bus id of the device a rank runs on ("0000:05:00.0";
+ * buf of at least 16 bytes) -- bench.py puts both into its line and refuses a run whose communicator is not RCCL
+ * when asked to (--require-rccl).  */
+int jxs_comm_version(int* version);
+int jxs_device_pci_bus_id(char* buf, int len);
 /* recv[world][rows][n_local]  <-  send[rows][n_local] of every rank */
 int jxs_allgather(void* comm, const void* send, void* recv, uint64_t count, int dtype,
                   void* stream);

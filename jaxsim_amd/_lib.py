@@ -229,6 +229,8 @@ def _declare(lib):
         "jxs_jacobian_full": [vp, vp, vp, vp, C.c_int, vp],
         "jxs_mass_matrix_inverse": [vp, vp, vp, C.c_int, vp],
         "jxs_comm_unique_id": [C.c_char * 128],
+        "jxs_comm_version": [C.POINTER(C.c_int)],
+        "jxs_device_pci_bus_id": [C.c_char_p, C.c_int],
         "jxs_comm_init": [C.POINTER(vp), C.c_char * 128, C.c_int, C.c_int],
         "jxs_comm_destroy": [vp],
         "jxs_allgather": [vp, vp, vp, C.c_uint64, C.c_int, vp],

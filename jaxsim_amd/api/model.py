@@ -45,11 +45,31 @@ def _as_device(x, rows: int, N: int, dtype, trailing_shape, tile: int) -> Device
     return DeviceArray.from_host(np.ascontiguousarray(a.reshape(N, rows).T), tile=tile, dtype=dtype)
 
 
+_environ = __import__("os").environ
+
+
 def _exceptions_enabled() -> bool:
     """``JAXSIM_ENABLE_EXCEPTIONS`` (``src/jaxsim/exceptions.py:26-29``), same variable, same default."""
-    import os
+    v = _environ.get("JAXSIM_ENABLE_EXCEPTIONS")
+    return v is not None and v.lower() in ("1", "true", "on", "yes")
 
-    return os.environ.get("JAXSIM_ENABLE_EXCEPTIONS", "0").lower() in ("1", "true", "on", "yes")
+
+def _device_model_fast(model, dtype):
+    """``runtime.device_model`` without recomputing the model signature on every call of the hot loop.
+
+    A `JaxSimModel` drops its cached device copies whenever one of its fields is assigned (``model.__setattr__``,
+    ``editable()``), its sub-objects are frozen dataclasses, and the kernel policy is an environment variable: so the
+    record ``(policy value, device model)`` kept NEXT to the device copies is valid while it is there and the variable
+    has the value it was made under -- two dictionary look-ups instead of a 25-field tuple compare per step."""
+    dev = model.__dict__.get("_device")
+    key = ("fast", dtype.str)
+    if dev is not None:
+        rec = dev.get(key)
+        if rec is not None and rec[0] == _environ.get("JAXSIM_AMD_SPECIALIZE"):
+            return rec[1]
+    dm = runtime.device_model(model, dtype)
+    model.__dict__.setdefault("_device", {})[key] = (_environ.get("JAXSIM_AMD_SPECIALIZE"), dm)
+    return dm
 
 
 def _check_quaternion(model, data: JaxSimModelData, *, normalized: bool) -> None:
@@ -153,30 +173,46 @@ def step(
     Returns a new data object (functional); ``inplace=True`` (extension) updates ``data``'s
     buffer instead and returns a data object sharing it.
     """
-    dm = runtime.device_model(model, data.dtype)
-    _check_quaternion(model, data, normalized=False)  # ABA receives data.base_orientation (normalised)
-    N, nL, n = data.batch_size, model.number_of_links(), model.dofs()
-    f = _as_device(link_forces, nL * 6, N, data.dtype, (nL, 6), data._state.tile)
-    tau = _as_device(joint_force_references, n, N, data.dtype, (n,), data._state.tile)
-    out = data._state if inplace else DeviceArray(data._state.rows, N, data.dtype, tile=data._state.tile)
-    fn = _lib.load().jxs_step
-    if gravity_compensation:
-        from .. import specialize as _sp
+    st = data._state
+    dtype, N = st.dtype, st.cols
+    dm = _device_model_fast(model, dtype)
+    checks = _exceptions_enabled()  # (the reference's value checks are compiled in only with JAXSIM_ENABLE_EXCEPTIONS)
+    if checks:
+        _check_quaternion(model, data, normalized=False)  # ABA receives data.base_orientation (normalised)
+    lib = _lib.load()
+    stream = runtime._sp()
+    if link_forces is None and joint_force_references is None and not gravity_compensation:
+        # the reference's idiom `data = js.model.step(model, data)` (README.md:80-83, tests/test_simulations.py:170-191): no
+        # inputs to convert -- pointers as plain integers (the C-ABI declares void*), the output block from the pool
+        out = st if inplace else DeviceArray(st.rows, N, dtype, tile=st.tile)
+        rc = lib.jxs_step(dm.handle, st.ptr, out.ptr, None, None, int(data.velocity_representation), N, stream)
+        if rc != 0:
+            _lib.check(rc, "jxs_step")
+    else:
+        nL, n = model.number_of_links(), model.dofs()
+        f = _as_device(link_forces, nL * 6, N, dtype, (nL, 6), st.tile)
+        tau = _as_device(joint_force_references, n, N, dtype, (n,), st.tile)
+        out = st if inplace else DeviceArray(st.rows, N, dtype, tile=st.tile)
+        fn = lib.jxs_step
+        if gravity_compensation:
+            from .. import specialize as _sp
 
-        if _sp.mode_of(model) in (_sp.MODE_STEP_RIGID, _sp.MODE_STEP_RK4_RIGID):
-            fn = _lib.load().jxs_step_gravity_compensated
-        else:  # soft contacts: g(q) through the host (no fused kernel for this mode), the user's references added to it
-            g = np.asarray(free_floating_gravity_forces(model, data))[..., 6:]
-            tau_np = g if joint_force_references is None else g + np.asarray(joint_force_references, dtype=g.dtype)
-            tau = _as_device(tau_np, n, N, data.dtype, (n,), data._state.tile)
-    _lib.check(
-        fn(
-            dm.handle, C.c_void_p(data._state.ptr), C.c_void_p(out.ptr), _ptr(tau), _ptr(f),
-            int(data.velocity_representation), N, runtime._sp(),
-        ),
-        "jxs_step",
-    )  # fmt: skip
-    _check_solver_faults(model, data)
+            if _sp.mode_of(model) in (_sp.MODE_STEP_RIGID, _sp.MODE_STEP_RK4_RIGID):
+                fn = lib.jxs_step_gravity_compensated
+            else:
+                # soft contacts: g(q) through the host (no fused kernel for this mode), the user's references added to it
+                # [ADVICE r4] -- whatever form they came in: a DeviceArray ([n][N]) and a device array of another
+                # framework are downloaded, not handed to np.asarray
+                g = np.asarray(free_floating_gravity_forces(model, data))[..., 6:]
+                g = g.reshape(N, n) if g.ndim == 1 else g
+                tau_np = g if tau is None else g + tau.to_host().T.astype(g.dtype)
+                tau = _as_device(tau_np, n, N, dtype, (n,), st.tile)
+        _lib.check(
+            fn(dm.handle, C.c_void_p(st.ptr), C.c_void_p(out.ptr), _ptr(tau), _ptr(f), int(data.velocity_representation), N, stream),
+            "jxs_step",
+        )  # fmt: skip
+    if checks:
+        _check_solver_faults(model, data)
     if inplace:
         # the buffer of `data` now holds the new state: its lazily downloaded fields and cached
         # kinematics describe the old one
@@ -195,6 +231,9 @@ def rollout(model: JaxSimModel, data: JaxSimModelData, n_steps: int, *, link_for
     stacked outputs of the reference's ``scan``; ``JaxSimModelData.from_state_block(model, states[k])`` rebuilds step k)."""
     dm = runtime.device_model(model, data.dtype)
     N, nL, n = data.batch_size, model.number_of_links(), model.dofs()
+    if int(n_steps) <= 0:  # [ADVICE r4] nothing to do -- whatever shape the references have
+        same = JaxSimModelData(model, data._state.copy(), data.velocity_representation, data._batched)
+        return (same, np.zeros((0, data._state.rows, N), dtype=data.dtype)) if return_trajectory else same
     f = _as_device(link_forces, nL * 6, N, data.dtype, (nL, 6), data._state.tile)
     out = data._state.copy()
     seq = None

@@ -16,6 +16,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -100,6 +101,9 @@ struct ModelT {
   SpecLaunch spec_launch[16] = {};
   void* spec_handle[16] = {};
   int* faults = nullptr;  // [2] discarded contact-force / impact solves since the last reset (rigid contact models)
+  // jxs_rollout_controlled, one launch per step: the torques of the current step, [n][N] -- one block per stream
+  std::mutex scratch_mu;
+  std::map<hipStream_t, std::pair<void*, size_t>> tau_scratch;
 
   ~ModelT() {
     // The specialised-kernel objects are NOT unloaded (attach_typed): launches of this model may still be in
@@ -108,6 +112,8 @@ struct ModelT {
     // which also keeps them visible in /proc/self/maps to whoever audits which native code ran.
     (void)hipFree(mblk);
     (void)hipFree(faults);
+    for (auto& kv : tau_scratch)
+      if (kv.second.first != nullptr) (void)hipFree(kv.second.first);
   }
 
   hipError_t upload_all() {
@@ -210,14 +216,7 @@ int run_typed(jxs_model* model, int mode, const void* state_in, void* state_out,
     if (traj != nullptr) a.out_a = static_cast<T*>(traj);  // recorded: the kernel stores the state after every step (jxs_core.h)
   }
   const bool tau_seq = (extra_flags & 4) != 0 && a.tau != nullptr;
-  struct Scratch {  // the torques of the current step, [n][N]: released behind the last launch on every way out
-    void* p = nullptr;
-    hipStream_t s;
-    ~Scratch() {
-      if (p != nullptr) (void)hipFreeAsync(p, s);
-    }
-  } scratch;
-  scratch.s = s;
+  void* scratch = nullptr;  // the torques of the current step, [n][N] (one launch per step)
   const T* const tau_all = a.tau;
   const int seq_steps = a.n_steps > 1 ? a.n_steps : repeat;
   if (tau_seq && mode != jxs::MODE_ROLLOUT) {
@@ -227,22 +226,33 @@ int run_typed(jxs_model* model, int mode, const void* state_in, void* state_out,
     a.flags &= ~4;
     const int tile = 64 / mt->pk.G;
     const size_t need = sizeof(T) * (size_t)((N + tile - 1) / tile) * tile * mt->pk.P.n;
-    // [ADVICE r4] the gather block belongs to THIS call and to its stream (hipMallocAsync / hipFreeAsync: stream-ordered,
-    // no device-wide synchronisation on the launch path, nothing shared between two streams or threads that roll out
-    // the same model -- round 4 kept one block per model and re-allocated it with hipFree + hipMalloc when N grew).
-    // An allocation cannot be part of a stream capture: refused there.
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
-      return fail(JXS_EINVAL, "a rollout with a torque sequence that runs one launch per step allocates its gather block: not inside a stream capture");
-    JXS_HIP(hipMallocAsync(&scratch.p, need, s));
+    // [ADVICE r4] one gather block per (model, STREAM), under a mutex: two streams or threads that roll out the same model
+    // never share a block (round 4 kept one per model), and the launch path allocates only when a stream's block has to
+    // grow -- which a stream capture cannot contain: refused there.  (hipMallocAsync / hipFreeAsync per call was tried
+    // first and returned wrong rollouts on ROCm 7.2: the strided device copy into pool memory did not land.)
+    std::lock_guard<std::mutex> lk(mt->scratch_mu);
+    auto& blk = mt->tau_scratch[s];
+    if (blk.second < need) {
+      hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+      if (hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+        return fail(JXS_EINVAL, "a rollout with a torque sequence that runs one launch per step has to (re)allocate its gather block: not inside a stream capture");
+      if (blk.first != nullptr) {
+        JXS_HIP(hipStreamSynchronize(s));  // the last launches of this stream may still read the old block
+        (void)hipFree(blk.first);
+        blk = {nullptr, 0};
+      }
+      JXS_HIP(hipMalloc(&blk.first, need));
+      blk.second = need;
+    }
+    scratch = blk.first;
   }
   for (int it = 0; it < repeat; ++it) {
     if (tau_seq && mode != jxs::MODE_ROLLOUT) {
       const int tile = 64 / mt->pk.G, n = mt->pk.P.n;
       const size_t row_bytes = sizeof(T) * (size_t)tile;
-      JXS_HIP(hipMemcpy2DAsync(scratch.p, row_bytes * n, reinterpret_cast<const char*>(tau_all) + row_bytes * n * it,
+      JXS_HIP(hipMemcpy2DAsync(scratch, row_bytes * n, reinterpret_cast<const char*>(tau_all) + row_bytes * n * it,
                                row_bytes * n * seq_steps, row_bytes * n, (size_t)((N + tile - 1) / tile), hipMemcpyDeviceToDevice, s));
-      a.tau = static_cast<const T*>(scratch.p);
+      a.tau = static_cast<const T*>(scratch);
     }
     hipError_t e = (mode >= 0 && mode < 16 && mt->spec_launch[mode] != nullptr)
                        ? static_cast<hipError_t>(mt->spec_launch[mode](&mt->pk.P, mt->mblk, &a, s))
@@ -279,6 +289,7 @@ int run_any(jxs_model* model, int mode, const void* state_in, void* state_out, c
 struct Rccl {
   void* h = nullptr;
   ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*GetVersion)(int*) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
@@ -294,6 +305,7 @@ int rccl_load() {
   Rccl r;
   r.h = h;
   r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+  r.GetVersion = reinterpret_cast<decltype(r.GetVersion)>(dlsym(h, "ncclGetVersion"));  // (optional)
   r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
   r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
   r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(h, "ncclAllGather"));
@@ -836,6 +848,22 @@ int jxs_comm_unique_id(char id[128]) {
   if (r != ncclSuccess) return rccl_fail(r, "ncclGetUniqueId");
   static_assert(sizeof(u.internal) == 128, "unexpected ncclUniqueId size");
   std::memcpy(id, u.internal, 128);
+  return JXS_OK;
+}
+int jxs_comm_version(int* version) {
+  if (version == nullptr) return fail(JXS_EINVAL, "null version");
+  int rc = rccl_load();
+  if (rc != JXS_OK) return rc;
+  if (g_rccl.GetVersion == nullptr) return fail(JXS_ECOMM, "librccl has no ncclGetVersion");
+  ncclResult_t r = g_rccl.GetVersion(version);
+  if (r != ncclSuccess) return rccl_fail(r, "ncclGetVersion");
+  return JXS_OK;
+}
+int jxs_device_pci_bus_id(char* buf, int len) {
+  if (buf == nullptr || len < 16) return fail(JXS_EINVAL, "buffer of at least 16 bytes expected");
+  int dev = 0;
+  JXS_HIP(hipGetDevice(&dev));
+  JXS_HIP(hipDeviceGetPCIBusId(buf, len, dev));
   return JXS_OK;
 }
 int jxs_comm_init(void** comm, const char id[128], int rank, int world_size) {

@@ -975,6 +975,9 @@ struct Core {
             cross(dp, xcfl, t);
   #pragma unroll
             for (int k = 0; k < 3; ++k) cfl[k] = xcfl[k], cfa[k] = xcfa[k] + t[k];
+          } else if (P.rigid == 2 && P.n_chunks > 1) {
+            // [round 5] more collidable points than lanes: chunks of G points, solved in the tree (jxs_rigid.inc)
+            relaxed_contact_forces_chunked(lane, level, parent, child, tf, R, r, vl, va, pB, vBc, om, a6, mass, cw, Ic, cfl, cfa);
           } else {
             V fpt[3];
             if (P.rigid == 2)
@@ -986,6 +989,9 @@ struct Core {
             for (int k = 0; k < 3; ++k) w6[k] = fpt[k];
             cross(rp.rc, w6, w6 + 3);
             scatter_point_wrenches(lane, ps0, w6, cfl, cfa);
+#ifdef JXS_RIGID_DEBUG
+            for (int i = 0; i < G; ++i) if (cfl[2].v[i] != 0) std::fprintf(stderr, "single: link lane %d f=(%g %g %g) n=(%g %g %g)\n", i, (double)cfl[0].v[i], (double)cfl[1].v[i], (double)cfl[2].v[i], (double)cfa[0].v[i], (double)cfa[1].v[i], (double)cfa[2].v[i]);
+#endif
             if (kRK4) {
   #pragma unroll
               for (int k = 0; k < 3; ++k) xcfl[k] = cfl[k], xcfa[k] = cfa[k];

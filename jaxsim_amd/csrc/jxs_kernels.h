@@ -94,7 +94,7 @@ __global__ __launch_bounds__(64, VARIANT == KV_OCC2 ? 2 : JXS_MIN_WAVES) void jx
   A.has_lds = (kFlagsKnown && P.row_mode && (MODE == jxs::MODE_STEP || MODE == jxs::MODE_ROLLOUT || MODE == jxs::MODE_FD || MODE == jxs::MODE_STEP_RK4)) ? 1 : 0;
   extern __shared__ __align__(16) unsigned char jxs_smem[];
   const jxs::DeviceLanes<T, G> ln(A.N, reinterpret_cast<T*>(jxs_smem),
-                                  (MODE == jxs::MODE_STEP_RIGID || MODE == jxs::MODE_STEP_RK4_RIGID) ? jxs::rigid_lds_words_per_env(P.n_cp, P.rigid, P.ct_tree)
+                                  (MODE == jxs::MODE_STEP_RIGID || MODE == jxs::MODE_STEP_RK4_RIGID) ? jxs::rigid_lds_words_per_env(P.n_cp, P.rigid, P.ct_tree, P.n_chunks, G)
                                   : MODE == jxs::MODE_STEP_RK4 ? jxs::rk4_lds_words_per_env(G, P.n_chunks)
                                                                : jxs::lds_words_per_env(G));
   jxs::Core<jxs::DeviceLanes<T, G>> core(P, A, ln);
@@ -161,7 +161,7 @@ hipError_t launch_one(const jxs::KParams<T>& P, const unsigned char* mblk, const
   const KTail<T> tail{A.in_a, A.out_a, A.out_H, A.out_V, A.out_tau, A.id_zero_vel, A.dbg, A.faults,
                       A.flags | ((A.knobs & jxs::KNOB_NO_MFMA) ? 1 : 0)};  // KNOB_NO_MFMA: A/B of the vector path of the contact solvers' Cholesky
   if (MODE == jxs::MODE_STEP_RIGID || MODE == jxs::MODE_STEP_RK4_RIGID) {
-    lds_bytes = sizeof(T) * (size_t)envs_per_wave * jxs::rigid_lds_words_per_env(P.n_cp, P.rigid, P.ct_tree);
+    lds_bytes = sizeof(T) * (size_t)envs_per_wave * jxs::rigid_lds_words_per_env(P.n_cp, P.rigid, P.ct_tree, P.n_chunks, G);
     if (lds_bytes > 64 * 1024) {  // beyond the default dynamic-LDS window (gfx950 has 160 KiB per CU)
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&jxs_kernel<T, G, MODE>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);

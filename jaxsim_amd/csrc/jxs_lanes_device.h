@@ -107,6 +107,9 @@ struct DeviceLanes {
   // Measured on the step kernel:
   // the 3x3 products alone 9.92 -> 9.84 us (round 2).  Each helper returns false where the packed form does
   // not exist (fp64, host emulation) and the caller runs the scalar loop.
+  // small integers (lane and slot indices) kept in the LDS next to real numbers: exact both ways
+  static __device__ __forceinline__ V to_real(VI i) { return (V)i; }
+  static __device__ __forceinline__ VI to_int(V x) { return (VI)x; }
   typedef float f2 __attribute__((ext_vector_type(2)));
   static __device__ __forceinline__ bool mat3mul_packed(const float* a, const float* b, float* o) {
     const f2 b0 = {b[0], b[1]}, b1 = {b[3], b[4]}, b2 = {b[6], b[7]};

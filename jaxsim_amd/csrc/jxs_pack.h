@@ -128,6 +128,10 @@ std::string pack_model(const jxs_model_desc& d, Packed<T>& out) {
   if (d.integrator != JXS_INTEGRATOR_SEMI_IMPLICIT_EULER && n_en > 32 && n_en <= 64) G = 64;
   // the rigid contact models solve for all enabled points at once: one lane each
   if (d.contact_model != JXS_CONTACT_SOFT && n_en > 32 && n_en <= 64) G = 64;
+  if (const char* e = std::getenv("JXS_CT_CHUNK_LANES")) {  // developer knob (tests): RelaxedRigidContacts in a smaller lane group, i.e. in more point chunks
+    const int g = std::atoi(e);
+    if (d.contact_model == JXS_CONTACT_RELAXED_RIGID && (g == 8 || g == 16 || g == 32) && g >= pow2ceil(nL)) G = std::min(G, g);
+  }
   if (const char* e = std::getenv("JXS_MIN_LANES")) {  // developer knob: at least this many lanes per environment (A/B of the lane-group size)
     const int g = std::atoi(e);
     if (g == 8 || g == 16 || g == 32 || g == 64) G = std::max(G, g);
@@ -177,24 +181,32 @@ std::string pack_model(const jxs_model_desc& d, Packed<T>& out) {
   //    environments left the iteration with a poor iterate on the device where the dense path reaches 5e-10), and for
   //    more than four points -- config 5 keeps its row-distributed register solver.  fp64 is the reference's default
   //    precision and the one whose triangles do not fit the LDS beyond 47 points.
+  //  * [round 5] RelaxedRigidContacts in the tree takes MORE POINTS THAN LANES (semi-implicit Euler): the points go through
+  //    in chunks of G, what a point carries between the passes sits in the LDS (jxs_rigid.inc
+  //    relaxed_contact_forces_chunked) -- the real ANYmal's four foot spheres are 200 points (parsers/rod/utils.py:200-204).
   int ct_tree = 0;
-  if (P.rigid && n_en >= 1 && (n_en + G - 1) / G == 1 && std::getenv("JXS_DISABLE_CT_TREE") == nullptr) {  // (developer knob: A/B against the triangles)
+  if (P.rigid && n_en >= 1 && std::getenv("JXS_DISABLE_CT_TREE") == nullptr) {  // (developer knob: A/B against the triangles)
     if (P.rigid == 2)
-      ct_tree = (sizeof(T) == 8 || 2.0 * d.mu * d.mu * (1.0 + d.mu * d.mu) >= 0.02 || std::getenv("JXS_CT_TREE_ANY_MU") != nullptr) ? 1 : 0;  // (knob: the fp32 experiment at small mu)
+      ct_tree = ((sizeof(T) == 8 || 2.0 * d.mu * d.mu * (1.0 + d.mu * d.mu) >= 0.02 || std::getenv("JXS_CT_TREE_ANY_MU") != nullptr) &&  // (knob: the fp32 experiment at small mu)
+                 (n_chunks == 1 || d.integrator == JXS_INTEGRATOR_SEMI_IMPLICIT_EULER)) ? 1 : 0;
     else
-      ct_tree = (n_en > 4 && ((sizeof(T) == 8 && d.solver_tol >= 1e-7) || std::getenv("JXS_CT_TREE_FP32") != nullptr)) ? 1 : 0;  // (knob: the fp32 experiment)
+      ct_tree = (n_chunks == 1 && n_en > 4 && ((sizeof(T) == 8 && d.solver_tol >= 1e-7) || std::getenv("JXS_CT_TREE_FP32") != nullptr)) ? 1 : 0;  // (knob: the fp32 experiment)
   }
   if (P.rigid) {
+    const bool chunked = ct_tree && P.rigid == 2 && n_chunks > 1;
     // one point per lane, three rows of the QP per point, both matrices in LDS (jxs_rigid.inc)
-    if (n_en > kRigidMaxPoints) return "RigidContacts / RelaxedRigidContacts: at most 64 enabled collidable points are supported";
+    if (n_en > kRigidMaxPoints && !chunked)
+      return "RigidContacts, and RelaxedRigidContacts outside the tree solve (fp32 with a negligible regulariser, Runge-Kutta): at most 64 enabled "
+             "collidable points are supported";
     {
-      // the Delassus matrix (and the working factor of RigidContacts) of one environment must fit the LDS of a CU
-      const size_t bytes = sizeof(T) * (size_t)(64 / G) * (size_t)rigid_lds_words_per_env(n_en, d.contact_model == JXS_CONTACT_RELAXED_RIGID ? 2 : 1, ct_tree);
+      // the Delassus matrix (and the working factor of RigidContacts) of one environment -- or the point records of the
+      // chunked tree solve -- must fit the LDS of a CU
+      const size_t bytes = sizeof(T) * (size_t)(64 / G) * (size_t)rigid_lds_words_per_env(n_en, d.contact_model == JXS_CONTACT_RELAXED_RIGID ? 2 : 1, ct_tree, n_chunks, G);
       if (bytes > (size_t)160 * 1024 && std::getenv("JXS_IGNORE_LDS_BUDGET") == nullptr)  // (the knob: host emulation of the tests only)
         return "RigidContacts / RelaxedRigidContacts: the contact problem of this many enabled points does not fit the 160 KB of LDS of a CU "
                "in this precision (64 points: fp32, or RelaxedRigidContacts in fp64)";
     }
-    if (n_chunks > 1) return "RigidContacts needs every enabled collidable point in one lane group";
+    if (n_chunks > 1 && !chunked) return "RigidContacts needs every enabled collidable point in one lane group";
     if (P.rigid == 1 && (!(d.regularization_delassus >= 0.0) || !(d.solver_tol > 0.0))) return "invalid RigidContacts options";
     if (P.rigid == 2) {
       // RelaxedRigidContactsParams.valid (relaxed_rigid.py:184-200); a zero time constant or width, or a

@@ -182,8 +182,11 @@ constexpr int kRgMergeRec = 40;  // [0, 18) wrench handed to the base per unit f
 JXS_HD constexpr int rigid_lds_merge_off(int n_cp, int rigid = 1) {
   return ((rigid == 2 ? 1 : 2) * ((3 * n_cp * (3 * n_cp + 1)) / 2) + 3 * n_cp + 8 + (n_cp <= 4 ? 16 : 0) + 3) / 4 * 4;
 }
-JXS_HD constexpr int rigid_lds_words_per_env(int n_cp, int rigid = 1, int ct_tree = 0) {
-  return ct_tree ? 16  // [round 5] solved in the tree (jxs_rigid.inc ta_*): shuffles only, no triangle in the LDS
+// [round 5] RelaxedRigidContacts with more points than lanes (jxs_rigid.inc relaxed_contact_forces_chunked): one record of
+// kCtRec words per point slot, read and written by the slot's own lane only
+constexpr int kCtRec = 24;
+JXS_HD constexpr int rigid_lds_words_per_env(int n_cp, int rigid = 1, int ct_tree = 0, int n_chunks = 1, int G = 0) {
+  return ct_tree ? (n_chunks > 1 ? n_chunks * G * kCtRec : 16)  // [round 5] solved in the tree (jxs_rigid.inc ta_*): no triangle in the LDS
                  : rigid_lds_merge_off(n_cp, rigid) + (n_cp <= 4 ? 4 * kRgMergeRec : 0);
 }
 constexpr int kQpMaxIter = 30;    // interior-point iterations (oracle/refrigid.py QP_MAX_ITER)

@@ -62,7 +62,7 @@ class JaxSimModelData:
     def __init__(self, model, state: runtime.DeviceArray, velocity_representation: VelRepr, batched: bool):
         self._model_ref = model
         self._state = state
-        self.velocity_representation = VelRepr(velocity_representation)
+        self.velocity_representation = velocity_representation if type(velocity_representation) is VelRepr else VelRepr(velocity_representation)
         self._batched = bool(batched)
         self._host = None  # lazily downloaded dict of [N,...] arrays
         self._kin = None  # lazily computed (link_transforms, link_velocities)

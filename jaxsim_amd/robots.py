@@ -263,13 +263,17 @@ def icub23_urdf(sole_boxes_per_foot: int = 2, joint_limit: float = 1.0, joint_da
     return "".join(out)
 
 
-def anymal12_urdf(points_per_foot_box: bool = True, joint_limit: float = 1.0) -> str:
-    """Synthetic 13-link / 12-DoF quadruped (4 x HAA-x / HFE-y / KFE-y), ~50 kg."""
+def anymal12_urdf(points_per_foot_box: bool = True, joint_limit: float = 1.0, foot_shape: str = "box") -> str:
+    """Synthetic 13-link / 12-DoF quadruped (4 x HAA-x / HFE-y / KFE-y), ~50 kg.  ``foot_shape="sphere"``: a sphere
+    collision shape of radius 3 cm at every shank tip instead of the box -- 50 Fibonacci points each
+    (``parsers/rod/utils.py:200-204``), 200 collidable points like the real robot's URDF."""
     out = ['<robot name="anymal12_synthetic">']
     out.append('<link name="base">' + _inertial(30.0, I=_box_inertia(30.0, 0.6, 0.3, 0.2)) + "</link>")
     jl = joint_limit
     for leg, sx, sy in (("LF", 1, 1), ("RF", 1, -1), ("LH", -1, 1), ("RH", -1, -1)):
         foot = _box_collision((0.04, 0.04, 0.04), xyz=(0, 0, -0.3)) if points_per_foot_box else ""
+        if points_per_foot_box and foot_shape == "sphere":
+            foot = '<collision><origin xyz="0 0 -0.3" rpy="0 0 0"/><geometry><sphere radius="0.03"/></geometry></collision>'
         out.append(f'<link name="{leg}_HIP">' + _inertial(1.5, com=(0, 0.02 * sy, 0), I=_box_inertia(1.5, 0.1, 0.1, 0.1)) + "</link>")
         out.append(f'<link name="{leg}_THIGH">' + _inertial(2.0, com=(0, 0, -0.14), I=_box_inertia(2.0, 0.06, 0.06, 0.3)) + "</link>")
         out.append(f'<link name="{leg}_SHANK">' + _inertial(1.5, com=(0, 0, -0.14), I=_box_inertia(1.5, 0.05, 0.05, 0.3)) + foot + "</link>")

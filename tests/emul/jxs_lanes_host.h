@@ -135,6 +135,17 @@ struct HostLanes {
   using VM = Vec<bool, G_>;
   static constexpr int G = G_;
 
+  // small integers (lane and slot indices) kept in the LDS next to real numbers: exact both ways
+  static V to_real(const VI& i) {
+    V r;
+    for (int k = 0; k < G_; ++k) r.v[k] = (T_)i.v[k];
+    return r;
+  }
+  static VI to_int(const V& x) {
+    VI r;
+    for (int k = 0; k < G_; ++k) r.v[k] = (int)x.v[k];
+    return r;
+  }
   static bool mat3mul_packed(const V*, const V*, V*) { return false; }
   template <typename... Args>
   static bool axpy6_packed(Args...) { return false; }

@@ -47,9 +47,23 @@ def test_bench_two_ranks_from_one_command_gpu():
     assert d["ms_per_step"] >= max(d["comm"]["ms_per_step_per_rank"]) - 1e-9
     assert abs(d["value"] - 2 * 1024 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     # two ranks on one device: RCCL says no and the line says which collective ran instead
-    assert d["comm"]["kind"] in ("FileCollective", "Communicator")
-    if d["comm"]["kind"] == "FileCollective":
-        assert "ncclCommInitRank" in d["comm"]["error"]
+    assert d["comm"]["kind"] in ("file_collective", "rccl") and d["comm"]["class"] in ("FileCollective", "Communicator")
+    if d["comm"]["kind"] == "file_collective":
+        assert "ncclCommInitRank" in d["comm"]["error"] and d["comm"]["nccl_version"] is None
+    # [round 5] the line names the device of every rank; here both ranks share the box's one GPU, and it says so
+    assert isinstance(d["device_pci_bus_ids"], list) and len(d["device_pci_bus_ids"]) == 2 and d["comm"]["distinct_devices"] is False
+
+
+@pytest.mark.gpu
+def test_bench_require_rccl_is_fatal_without_rccl_gpu():
+    """[round 5] `--require-rccl`: a rank whose communicator is not RCCL exits non-zero -- two ranks on ONE device is the
+    case a 1-GPU box can produce (ncclCommInitRank refuses it) -- so a scaling record cannot be a file collective by accident."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR", "JAXSIM_AMD_LIB")}
+    res = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--share-device", "--require-rccl", *FAST, "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=600, env=env)  # fmt: skip
+    assert res.returncode != 0
+    assert not [ln for ln in res.stdout.splitlines() if ln.startswith("{")], res.stdout
+    assert "--require-rccl" in res.stderr
 
 
 @pytest.mark.gpu

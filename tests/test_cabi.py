@@ -32,7 +32,7 @@ def declared_symbols():
 def test_header_declares_the_expected_entry_points():
     names = declared_symbols()
     for must in ("jxs_model_create", "jxs_step", "jxs_rollout", "jxs_rollout_controlled", "jxs_rollout_recorded", "jxs_forward_dynamics_aba", "jxs_inverse_dynamics",
-                 "jxs_refresh_kinematics", "jxs_allgather", "jxs_comm_init", "jxs_last_error"):  # fmt: skip
+                 "jxs_refresh_kinematics", "jxs_allgather", "jxs_comm_init", "jxs_comm_version", "jxs_device_pci_bus_id", "jxs_last_error"):  # fmt: skip
         assert must in names
 
 

@@ -113,6 +113,8 @@ def test_bench_is_its_own_launcher(world):
     out = json.loads(lines[0])
     assert out["ok"] and out["n_gpus"] == world and out["global_batch"] == 1024 * world and out["same_id_on_all_ranks"]
     assert out["shards"][-1] == [1024 * (world - 1), 1024 * world]
+    # [round 5] the self-launcher gives every rank its own LOCAL_RANK, i.e. its own device of the node
+    assert out["device_of_rank"] == list(range(world)) and out["distinct_devices"]
 
 
 def test_bench_launcher_propagates_a_failing_rank():

@@ -918,6 +918,75 @@ def test_recorded_rollout_returns_every_step(models, name, kind, seq):
     np.testing.assert_array_equal(plain, final)  # recording does not change the rollout
 
 
+def _quadruped_200():
+    """The quadruped with a 50-point sphere at every shank tip: 200 collidable points, like the real robot's URDF
+    (parsers/rod/utils.py:200-204 turns a sphere collision shape into 50 Fibonacci points)."""
+    import jaxsim_amd as ja
+    from jaxsim_amd import robots
+
+    return ja.JaxSimModel.build_from_model_description(robots.anymal12_urdf(foot_shape="sphere"))
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-9), (np.float32, 3e-3)])
+def test_relaxed_contacts_with_more_points_than_lanes(dtype, tol):
+    """[round 5] RelaxedRigidContacts beyond 64 enabled points (missing #3): 200 points on four links in chunks of
+    32 lanes, solved in the tree (jxs_rigid.inc relaxed_contact_forces_chunked) -- random states with a few points down
+    and standing states, against the oracle; ten in-place steps stay on the oracle's trajectory."""
+    model = helpers.relaxed_model(_quadruped_200(), range(200), mu=0.5)
+    assert eb.layout(model, dtype).group == 32
+    worst = 0.0
+    for d in (oracle.random_model_data(model, batch_size=12, seed=1, dtype=dtype, base_pos_bounds=((-1, -1, 0.55), (1, 1, 0.68)), base_rpy_bounds=((-0.3, -0.3, -3), (0.3, 0.3, 3))),
+              helpers.standing_data(model, 12, seed=1, dtype=dtype, noise=0.05)):  # fmt: skip
+        p, _ = oracle.collidable_points_pos_vel(model, link_transforms=d.link_transforms, link_velocities=d.link_velocities)
+        assert (p[..., 2] < 0).any()
+        truth = helpers.odata_to_block(model, oracle.step(model, helpers.upcast(d, model) if dtype == np.float32 else d))
+        out = eb.run(model, eb.MODE_STEP, helpers.odata_to_block(model, d))
+        worst = max(worst, helpers.rel_err(out, truth))
+    helpers.note(f"relaxed_200_points/{np.dtype(dtype).name}", worst)
+    assert worst < tol
+    if dtype == np.float64:
+        d = helpers.standing_data(model, 3, seed=2, noise=0.05)
+        ref, blk = d, helpers.odata_to_block(model, d)
+        for _ in range(10):
+            ref = oracle.step(model, ref)
+            blk = eb.run(model, eb.MODE_STEP, blk)
+        assert helpers.rel_err(blk, helpers.odata_to_block(model, ref)) < 1e-8
+
+
+@pytest.mark.parametrize("n_points,lanes", [(40, 32), (65, 32), (100, 16), (32, 16)])
+def test_chunked_relaxed_solve_equals_the_one_chunk_form(models, n_points, lanes, monkeypatch):
+    """[round 5] The chunked form against the one-lane-per-point form of the SAME problem (a developer knob caps the lane
+    group, so that up to 64 points run both ways) and against the oracle: full and partly filled last chunks, a link's
+    points split over chunk borders."""
+    base = _quadruped_200() if n_points > 32 else models("anymal")
+    model = helpers.relaxed_model(base, range(n_points), mu=0.5)
+    d = helpers.standing_data(model, 8, seed=1, noise=0.05)
+    blk = helpers.odata_to_block(model, d)
+    truth = helpers.odata_to_block(model, oracle.step(model, d))
+    one = eb.run(model, eb.MODE_STEP, blk) if n_points <= 64 else None
+    monkeypatch.setenv("JXS_CT_CHUNK_LANES", str(lanes))
+    assert eb.layout(model).group == lanes
+    chunked = eb.run(model, eb.MODE_STEP, blk)
+    assert helpers.rel_err(chunked, truth) < 1e-10
+    if one is not None:
+        assert helpers.rel_err(chunked, one) < 1e-11
+
+
+def test_more_points_than_lanes_outside_the_tree_solve_is_refused():
+    """What still needs one lane per point says so: RigidContacts, RelaxedRigidContacts in fp32 with the bare default
+    regulariser (the dense path), Runge-Kutta with a rigid contact model."""
+    import jaxsim_amd as ja
+
+    base = _quadruped_200()
+    with pytest.raises(RuntimeError, match="at most 64"):
+        eb.layout(helpers.rigid_model(base, range(200)), np.float64)
+    with pytest.raises(RuntimeError, match="at most 64"):
+        eb.layout(helpers.relaxed_model(base, range(200)), np.float32)  # mu = 0.005: no tree solve in fp32
+    assert eb.layout(helpers.relaxed_model(base, range(200)), np.float64).group == 32  # fp64: in the tree
+    with pytest.raises(RuntimeError, match="RungeKutta4"):
+        eb.layout(helpers.with_params(helpers.relaxed_model(base, range(200), mu=0.5), integrator=ja.IntegratorType.RungeKutta4), np.float64)
+
+
 def test_contact_tree_solve_on_random_trees():
     """[round 5] Random floating trees (8 to 24 links) with the two collision boxes on random links -- neighbours, far
     apart, on the base; every third tree with all joint axes parallel, every third with axis-aligned joints: every pair

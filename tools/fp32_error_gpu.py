@@ -15,7 +15,7 @@ import oracle  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 zoo = helpers.ModelZoo()
-for name in ["box", "sphere", "pendulum", "double_pendulum", "cartpole", "chain5", "chain9f", "anymal", "icub", "icub16"]:
+for name in ["box", "sphere", "pendulum", "double_pendulum", "cartpole", "chain5", "chain9f", "anymal", "icub", "icub16", "planar_biped", "planar10f"]:
     model = zoo(name)
     for seed in (4, 5):
         d = zoo.random_data(name, N, seed=seed, dtype=np.float32)
@@ -28,3 +28,20 @@ for name in ["box", "sphere", "pendulum", "double_pendulum", "cartpole", "chain5
         r = np.max(np.abs(ref32.astype(np.float64) - truth) / np.maximum(1.0, np.abs(truth)), axis=0)
         print(f"{name:16s} seed {seed}: GPU median {np.median(e):.1e} p99 {np.percentile(e, 99):.1e} worst {e.max():.1e} | "
               f"reference formulation in fp32: median {np.median(r):.1e} p99 {np.percentile(r, 99):.1e} worst {r.max():.1e}", flush=True)
+
+# [round 5] the rigid contact models in fp32 (the cases of tests/test_gpu_parity.py), same truth: the fp64 oracle on the same state
+from test_gpu_parity import RELAXED_CASES, RIGID_CASES  # noqa: E402
+
+for kind, table, make in (("relaxed", RELAXED_CASES, helpers.relaxed_model), ("rigid", RIGID_CASES, helpers.rigid_model)):
+    for key, (name, idx, params) in table.items():
+        model = make(zoo(name), idx, **params)
+        for seed in (4, 5):
+            d = zoo.random_data(name, N, seed=seed, dtype=np.float32)
+            try:
+                truth = helpers.odata_to_block(model, oracle.step(model, helpers.upcast(d, model)))
+                out = js.model.step(model, js.data.JaxSimModelData.from_state_block(model, helpers.odata_to_block(model, d))).state_block()
+            except Exception as exc:  # (a singular oracle state, a refused model)
+                print(f"{kind}/{key:14s} seed {seed}: skipped ({exc!r})"[:160], flush=True)
+                continue
+            e = np.max(np.abs(out.astype(np.float64) - truth) / np.maximum(1.0, np.abs(truth)), axis=0)
+            print(f"{kind}/{key:14s} seed {seed}: GPU median {np.median(e):.1e} p99 {np.percentile(e, 99):.1e} worst {e.max():.1e}", flush=True)
