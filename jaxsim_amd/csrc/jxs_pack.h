@@ -179,8 +179,9 @@ std::string pack_model(const jxs_model_desc& d, Packed<T>& out) {
   //    barrier weights that go to zero on the inactive faces, D^-1 up to 1e6 against Delassus entries of O(1): fp64 only
   //    (no correct digit in fp32, measured in round 4 for the same algebra), for solver_tol >= 1e-7 (at 1e-10 single
   //    environments left the iteration with a poor iterate on the device where the dense path reaches 5e-10), and for
-  //    more than four points -- config 5 keeps its row-distributed register solver.  fp64 is the reference's default
-  //    precision and the one whose triangles do not fit the LDS beyond 47 points.
+  //    more than four points -- config 5 keeps its row-distributed register solver -- AND only where the dense path cannot
+  //    run at all (below).  fp64 is the reference's default precision and the one whose triangles do not fit the LDS
+  //    beyond 47 points.
   //  * [round 5] RelaxedRigidContacts in the tree takes MORE POINTS THAN LANES (semi-implicit Euler): the points go through
   //    in chunks of G, what a point carries between the passes sits in the LDS (jxs_rigid.inc
   //    relaxed_contact_forces_chunked) -- the real ANYmal's four foot spheres are 200 points (parsers/rod/utils.py:200-204).
@@ -189,8 +190,17 @@ std::string pack_model(const jxs_model_desc& d, Packed<T>& out) {
     if (P.rigid == 2)
       ct_tree = ((sizeof(T) == 8 || 2.0 * d.mu * d.mu * (1.0 + d.mu * d.mu) >= 0.02 || std::getenv("JXS_CT_TREE_ANY_MU") != nullptr) &&  // (knob: the fp32 experiment at small mu)
                  (n_chunks == 1 || d.integrator == JXS_INTEGRATOR_SEMI_IMPLICIT_EULER)) ? 1 : 0;
-    else
-      ct_tree = (n_chunks == 1 && n_en > 4 && ((sizeof(T) == 8 && d.solver_tol >= 1e-7) || std::getenv("JXS_CT_TREE_FP32") != nullptr)) ? 1 : 0;  // (knob: the fp32 experiment)
+    else {
+      // RigidContacts: ONLY where the triangles of the dense path do not fit the LDS of a CU (fp64 beyond 47 points: the
+      // reference's 50-point sphere).  The tree form of the interior-point iteration was measured to be fragile: its Newton
+      // directions lose their digits when the barrier weights become extreme (the last iterations; tools/fuzz found a tree
+      // whose residual went 1e-6 -> 5e3 in one iteration even with five refinement steps against the exact operator), the
+      // dense Cholesky is backward stable there.  Where it has to run, the iteration keeps its best iterate (rigid_qp_impl).
+      const size_t dense_bytes = sizeof(T) * (size_t)(64 / G) * (size_t)rigid_lds_words_per_env(n_en, 1, 0);
+      const bool fits = dense_bytes <= (size_t)160 * 1024;
+      ct_tree = (n_chunks == 1 && n_en > 4 && (!fits || std::getenv("JXS_CT_TREE_RIGID") != nullptr) &&  // (knob: the tree wherever it applies, A/B and tests)
+                 ((sizeof(T) == 8 && d.solver_tol >= 1e-7) || std::getenv("JXS_CT_TREE_FP32") != nullptr)) ? 1 : 0;  // (knob: the fp32 experiment)
+    }
   }
   if (P.rigid) {
     const bool chunked = ct_tree && P.rigid == 2 && n_chunks > 1;

@@ -284,6 +284,28 @@ def anymal12_urdf(points_per_foot_box: bool = True, joint_limit: float = 1.0, fo
     return "".join(out)
 
 
+def four_bar_opened_urdf() -> str:
+    """The reference's third shipped test asset, ``tests/assets/4_bar_opened.urdf`` (numeric values only, emitted by our
+    own code): a planar four-bar linkage cut open at C -- AB (root, floating) -> BC1 (joint B) and AB -> DA (joint A) ->
+    CD (joint D) -> BC2 (joint C), every joint revolute about z and turned by 1.57 rad, two massless frame links at the
+    cut (``BC1_frame``, ``BC2_frame``: the reference closes the loop there with kinematic constraints, out of scope
+    here), one collision box on CD."""
+    def bar(name, m, ly, com_y, I, coll=False):
+        c = _box_collision((0.1, ly, 0.1), xyz=(0, com_y, 0)) if coll else ""
+        return f'<link name="{name}">' + _inertial(m, com=(0, com_y, 0), I=I) + c + "</link>"
+
+    long_I, short_I = (0.02167, 0.00167, 0.02167), (0.010835, 0.000835, 0.010835)
+    out = ['<robot name="4_bar_opened">', bar("AB", 1.0, 0.5, 0.0, long_I), bar("BC1", 0.5, 0.25, 0.125, short_I), '<link name="BC1_frame"/>',
+           _joint("BC1_frame_joint", "fixed", "BC1", "BC1_frame", (0, 0.25, 0), (0, 0, 0)),
+           bar("BC2", 0.5, 0.25, 0.125, short_I), '<link name="BC2_frame"/>',
+           _joint("BC2_frame_joint", "fixed", "BC2", "BC2_frame", (0, 0.25, 0), (0, 0, 0), rpy=(0, 0, 3.1416)),
+           bar("CD", 1.0, 0.5, 0.25, long_I, coll=True), bar("DA", 1.0, 0.5, 0.25, long_I)]  # fmt: skip
+    for name, parent, child, y in (("B", "AB", "BC1", -0.25), ("C", "CD", "BC2", 0.5), ("D", "DA", "CD", 0.5), ("A", "AB", "DA", 0.25)):
+        out.append(_joint(name, "revolute", parent, child, (0, y, 0), (0, 0, 1), rpy=(0, 0, 1.57), lower=-1.57, upper=1.57))
+    out.append("</robot>")
+    return "".join(out)
+
+
 def planar_biped_urdf(sole=(0.2, 0.08, 0.04)) -> str:
     """Walker2d-style planar biped with a floating base: torso (10 kg) + 2 x (thigh, shank, foot), all six joints
     revolute about y (hip, knee, ankle), a sole box on each foot.  Every joint axis between the two feet is PARALLEL:

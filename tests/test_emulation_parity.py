@@ -814,6 +814,11 @@ def test_tree_solve_agrees_with_the_dense_path(models, reduced_qp, kind, key, dt
     d = models.random_data(name, 16, seed=5, dtype=dtype)
     truth = helpers.odata_to_block(model, oracle.step(model, helpers.upcast(d) if dtype == np.float32 else d))
     blk = helpers.odata_to_block(model, d)
+    if kind == "rigid":
+        # RigidContacts takes the tree only where the triangles do not fit the LDS (jxs_pack.h: its Newton directions are
+        # fragile near convergence); the developer knob runs it wherever it applies
+        assert "P.ct_tree=0" in specialize.spec(model, dtype, specialize.MODE_STEP_RIGID)
+        monkeypatch.setenv("JXS_CT_TREE_RIGID", "1")
     assert "P.ct_tree=1" in specialize.spec(model, dtype, specialize.MODE_STEP_RIGID)
     tree = eb.run(model, eb.MODE_STEP, blk)
     monkeypatch.setenv("JXS_DISABLE_CT_TREE", "1")

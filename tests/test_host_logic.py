@@ -40,6 +40,43 @@ def test_cartpole_tables(models):
     assert kdp.number_of_collidable_points() == 0  # cylinders are skipped, config C2 has no boxes
 
 
+def test_four_bar_opened_tables():
+    """[round 5] Row T on the reference's third shipped asset (``tests/assets/4_bar_opened.urdf``, re-typed as
+    ``robots.four_bar_opened_urdf``), expectations stated by hand from the rules of SURVEY 8(a) row T: root = the link
+    that is nobody's child, BFS indices with children sorted by NAME, joint index = child link index, massless
+    fixed-joint children become frames of their parent, a box is eight corner points (bottom first)."""
+    from jaxsim_amd import robots
+
+    m = ja.JaxSimModel.build_from_model_description(robots.four_bar_opened_urdf())
+    kdp = m.kin_dyn_parameters
+    assert m.floating_base()
+    assert kdp.link_names == ("AB", "BC1", "DA", "CD", "BC2")  # AB; its children BC1 < DA; then DA's CD; then CD's BC2
+    assert list(kdp.parent_array) == [-1, 0, 0, 2, 3]
+    assert kdp.joint_names == ("B", "A", "D", "C")  # joint i drives link i + 1
+    assert set(kdp.frame_names) == {"BC1_frame", "BC2_frame"}
+    frames = dict(zip(kdp.frame_names, kdp.frame_body))
+    assert frames["BC1_frame"] == 1 and frames["BC2_frame"] == 4
+    np.testing.assert_allclose(kdp.frame_transform[kdp.frame_names.index("BC1_frame")][:3, 3], [0, 0.25, 0])
+    Rz = kdp.frame_transform[kdp.frame_names.index("BC2_frame")][:3, :3]
+    np.testing.assert_allclose(Rz, [[np.cos(3.1416), -np.sin(3.1416), 0], [np.sin(3.1416), np.cos(3.1416), 0], [0, 0, 1]], atol=1e-12)
+    assert list(kdp.joint_types) == [1, 1, 1, 1]
+    for i in range(1, 5):
+        np.testing.assert_allclose(kdp.motion_subspaces[i], [0, 0, 0, 0, 0, 1])
+    np.testing.assert_allclose(kdp.lambda_H_pre[1][:3, 3], [0, -0.25, 0])  # joint B
+    np.testing.assert_allclose(kdp.lambda_H_pre[2][:3, 3], [0, 0.25, 0])   # joint A
+    np.testing.assert_allclose(kdp.lambda_H_pre[3][:3, 3], [0, 0.5, 0])    # joint D
+    np.testing.assert_allclose(kdp.lambda_H_pre[3][:3, :3], [[np.cos(1.57), -np.sin(1.57), 0], [np.sin(1.57), np.cos(1.57), 0], [0, 0, 1]], atol=1e-12)
+    np.testing.assert_allclose(kdp.link_mass, [1.0, 0.5, 1.0, 1.0, 0.5])
+    np.testing.assert_allclose(m.total_mass(), 4.0)
+    np.testing.assert_allclose(kdp.position_limits_min, -1.57)
+    np.testing.assert_allclose(kdp.position_limits_max, 1.57)
+    assert kdp.number_of_collidable_points() == 8 and set(np.asarray(kdp.contact_body)) == {3}  # the box on CD
+    pts = np.asarray(kdp.contact_point)
+    np.testing.assert_allclose(pts[:4, 2], -0.05)
+    np.testing.assert_allclose(sorted(set(np.round(pts[:, 1], 6))), [0.0, 0.5])  # the box is centred 0.25 m along CD
+    assert kdp.tree_depths().max() == 3
+
+
 def test_fixed_joint_lumping_conserves_mass_and_inertia():
     # child rigidly attached 0.5 m above the parent: lumped inertia = parallel-axis sum
     u = (

@@ -24,7 +24,7 @@ sys.path.insert(0, str(ROOT / "tests"))
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--points", type=int, default=4, choices=[4, 16, 32])
+    ap.add_argument("--points", type=int, default=4, choices=[4, 16, 32, 200], help="200: the quadruped with a 50-point sphere on every foot (RelaxedRigidContacts only: more points than lanes)")
     ap.add_argument("--standing", action="store_true", help="standing states: every sole point in contact")
     ap.add_argument("--envs", type=int, default=4096)
     ap.add_argument("--steps", type=int, default=200)
@@ -42,11 +42,17 @@ def main():
     zoo = helpers.ModelZoo()
     # --points 32: the 24-link humanoid of config 3 with all its 32 collidable points enabled
     robot = "icub" if args.points == 32 else "anymal"
-    idx = helpers.ANYMAL_FEET_4 if args.points == 4 else helpers.ANYMAL_FEET_16 if args.points == 16 else list(range(32))
+    idx = helpers.ANYMAL_FEET_4 if args.points == 4 else helpers.ANYMAL_FEET_16 if args.points == 16 else list(range(args.points))
+    base = zoo(robot)
+    if args.points == 200:
+        import jaxsim_amd as ja
+        from jaxsim_amd import robots
+
+        base = ja.JaxSimModel.build_from_model_description(robots.anymal12_urdf(foot_shape="sphere"))
     if args.contact == "rigid":
-        model = helpers.rigid_model(zoo(robot), idx, K=1e4, D=2e2)
+        model = helpers.rigid_model(base, idx, K=1e4, D=2e2)
     else:
-        model = helpers.relaxed_model(zoo(robot), idx)
+        model = helpers.relaxed_model(base, idx)
         if not args.default_params:
             model = helpers.with_params(model, contact_params=js.contact.estimate_good_contact_parameters(model))
     dtype = np.dtype(args.dtype)
@@ -54,6 +60,10 @@ def main():
         d = helpers.standing_data(model, args.envs, seed=0, dtype=dtype, noise=0.003)
     else:
         d = zoo.random_data(robot, args.envs, seed=0, dtype=dtype)
+        if args.points == 200:  # (the states of the zoo's quadruped, whose caches belong to its point set: rebuilt for this one)
+            import oracle
+
+            d = oracle.random_model_data(model, batch_size=args.envs, seed=0, dtype=dtype, base_pos_bounds=((-1, -1, 0.58), (1, 1, 0.70)), base_rpy_bounds=((-0.3, -0.3, -3), (0.3, 0.3, 3)))
     data = js.data.JaxSimModelData.from_state_block(model, helpers.odata_to_block(model, d), 2)
     dm = runtime.device_model(model, dtype)
     from jaxsim_amd import specialize

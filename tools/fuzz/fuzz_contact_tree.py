@@ -29,6 +29,11 @@ for trial in range(trials):
     idx = list(range(8 * len(cl)))
     for kind, dtype, tol in (("relaxed", np.float64, 1e-9), ("relaxed", np.float32, 2e-3), ("rigid", np.float64, 5e-5)):
         key = (kind, np.dtype(dtype).name)
+        # (RigidContacts takes the tree by default only where the triangles do not fit the LDS; the campaign runs it everywhere)
+        if kind == "rigid" and os.environ.get("JXS_DISABLE_CT_TREE") is None:
+            os.environ["JXS_CT_TREE_RIGID"] = "1"
+        else:
+            os.environ.pop("JXS_CT_TREE_RIGID", None)
         try:
             model = helpers.relaxed_model(base, idx, mu=0.5) if kind == "relaxed" else helpers.rigid_model(base, idx, K=1e4, D=1e2)
             assert ("P.ct_tree=1" in specialize.spec(model, dtype, specialize.MODE_STEP_RIGID)) == (os.environ.get("JXS_DISABLE_CT_TREE") is None), (trial, key)

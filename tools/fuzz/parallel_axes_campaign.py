@@ -17,6 +17,11 @@ tot = {}
 for name, base, bounds in models:
     for kind, dtype in (("relaxed", np.float32), ("relaxed", np.float64), ("rigid", np.float64)):
         model = helpers.relaxed_model(base, range(16), mu=0.5) if kind == "relaxed" else helpers.rigid_model(base, range(16), K=1e4, D=1e2)
+        # (RigidContacts takes the tree by default only where the triangles do not fit the LDS; the campaign runs it everywhere)
+        if kind == "rigid" and os.environ.get("JXS_DISABLE_CT_TREE") is None:
+            os.environ["JXS_CT_TREE_RIGID"] = "1"
+        else:
+            os.environ.pop("JXS_CT_TREE_RIGID", None)
         errs = []
         for part, seed in (("random", 0), ("standing", 1)):
             N = per_model // 2
