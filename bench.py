@@ -51,7 +51,7 @@ def kernel_source_sha():
 
 def profiled_traffic(model_name, n_envs, dtype_name):
     """(bytes per launch | None, note) for the configuration that was profiled."""
-    for tag in ("r04", "r03", "r02", "r01"):
+    for tag in ("r05", "r04", "r03", "r02", "r01"):
         try:
             with open(os.path.join(ROOT, "profiles", f"{tag}_pmc.json")) as f:
                 prof = json.load(f)
@@ -70,7 +70,7 @@ def profiled_traffic(model_name, n_envs, dtype_name):
 def profiled_config5_traffic():
     """HBM-side bytes per launch of the config-5 step kernel (tools/profile_round.sh c5_pmc_* passes), or None when the
     committed profile was taken on other kernel sources."""
-    for tag in ("r04", "r03"):
+    for tag in ("r05", "r04", "r03"):
         try:
             with open(os.path.join(ROOT, "profiles", f"{tag}_pmc.json")) as f:
                 prof = json.load(f)

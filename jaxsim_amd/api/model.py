@@ -46,12 +46,25 @@ def _as_device(x, rows: int, N: int, dtype, trailing_shape, tile: int) -> Device
 
 
 _environ = __import__("os").environ
+# os.environ.get() encodes its key and decodes the value on every call (1.1 us each -- a sixth of a step at 1024
+# environments); the mapping underneath holds both as bytes and is what os.environ[...] = ... / monkeypatch.setenv write
+_env_raw = getattr(_environ, "_data", None)
+_K_EXC, _K_SPEC = (_environ.encodekey("JAXSIM_ENABLE_EXCEPTIONS"), _environ.encodekey("JAXSIM_AMD_SPECIALIZE")) if _env_raw is not None else (None, None)
+_TRUE = (b"1", b"true", b"on", b"yes")
 
 
 def _exceptions_enabled() -> bool:
     """``JAXSIM_ENABLE_EXCEPTIONS`` (``src/jaxsim/exceptions.py:26-29``), same variable, same default."""
+    if _env_raw is not None:
+        v = _env_raw.get(_K_EXC)
+        return v is not None and v.lower() in _TRUE
     v = _environ.get("JAXSIM_ENABLE_EXCEPTIONS")
     return v is not None and v.lower() in ("1", "true", "on", "yes")
+
+
+def _policy_token():
+    """The raw value of JAXSIM_AMD_SPECIALIZE (the kernel policy is part of what a cached device model was made under)."""
+    return _env_raw.get(_K_SPEC) if _env_raw is not None else _environ.get("JAXSIM_AMD_SPECIALIZE")
 
 
 def _device_model_fast(model, dtype):
@@ -65,10 +78,10 @@ def _device_model_fast(model, dtype):
     key = ("fast", dtype.str)
     if dev is not None:
         rec = dev.get(key)
-        if rec is not None and rec[0] == _environ.get("JAXSIM_AMD_SPECIALIZE"):
+        if rec is not None and rec[0] == _policy_token():
             return rec[1]
     dm = runtime.device_model(model, dtype)
-    model.__dict__.setdefault("_device", {})[key] = (_environ.get("JAXSIM_AMD_SPECIALIZE"), dm)
+    model.__dict__.setdefault("_device", {})[key] = (_policy_token(), dm)
     return dm
 
 
@@ -184,7 +197,7 @@ def step(
     if link_forces is None and joint_force_references is None and not gravity_compensation:
         # the reference's idiom `data = js.model.step(model, data)` (README.md:80-83, tests/test_simulations.py:170-191): no
         # inputs to convert -- pointers as plain integers (the C-ABI declares void*), the output block from the pool
-        out = st if inplace else DeviceArray(st.rows, N, dtype, tile=st.tile)
+        out = st if inplace else DeviceArray.like(st)
         rc = lib.jxs_step(dm.handle, st.ptr, out.ptr, None, None, int(data.velocity_representation), N, stream)
         if rc != 0:
             _lib.check(rc, "jxs_step")

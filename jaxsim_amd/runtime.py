@@ -131,6 +131,35 @@ class DeviceArray:
         if zero:
             _lib.check(lib.jxs_memset(C.c_void_p(self.ptr), 0, self.nbytes, _sp()), "jxs_memset")
 
+    @classmethod
+    def like(cls, other: "DeviceArray") -> "DeviceArray":
+        """A new (uninitialised) array with the shape, dtype and tiling of ``other`` -- the output block of a functional
+        ``step``: the metadata is copied, the buffer comes from the free list of that size (the block the previous
+        ``data`` object just gave back, in the reference's loop ``data = js.model.step(model, data)``)."""
+        self = cls.__new__(cls)
+        self.rows, self.cols, self.tile, self.dtype = other.rows, other.cols, other.tile, other.dtype
+        self.n_tiles, self.nbytes, self._bucket = other.n_tiles, other.nbytes, other._bucket
+        cur = _current_stream if _current_stream is not None else _NULL
+        ptr = None
+        free = _pool.get(self._bucket)
+        if free:
+            try:
+                ptr, last = free.pop()  # (list.pop is atomic under the GIL)
+            except IndexError:
+                ptr = None
+        if ptr is None:
+            p = C.c_void_p()
+            _lib.check(_lib.load().jxs_malloc(C.byref(p), self._bucket), "jxs_malloc")
+            ptr = p.value
+        elif last is not cur:  # recycled from another stream: its last kernels may still be reading the buffer
+            if last is _NULL:
+                _lib.check(_lib.load().jxs_device_synchronize(), "jxs_device_synchronize")
+            else:
+                last.synchronize()
+        self._ptr = ptr
+        self._streams = {cur}
+        return self
+
     @property
     def ptr(self):
         """Raw device pointer.  Every consumer passes it to work on the CURRENT stream, so reading it
@@ -148,6 +177,14 @@ class DeviceArray:
             return
         self._ptr = None
         try:
+            if len(self._streams) == 1:  # the usual case: one stream ever touched the buffer -- it goes back tagged with it
+                (tag,) = self._streams
+                free = _pool.get(self._bucket)
+                if free is None:
+                    with _pool_lock:
+                        free = _pool.setdefault(self._bucket, [])
+                free.append((ptr, tag))  # (list.append is atomic under the GIL)
+                return
             streams = list(self._streams)
             # the buffer goes back to the pool tagged with ONE stream; work still in flight on any other
             # stream that touched it is waited for here (rare: set_stream() between uses)

@@ -51,8 +51,10 @@ if kind == "relaxed":
     tot = o[:, 10] - o[:, 0]
     print(f"points={pts} N={N} relaxed{' standing' if standing else ''}: {blocks} waves, {has.sum()} with contacts")
     print("  total                 %9.0f (max %d)" % (tot.mean(), tot.max()))
-    print("  delassus              %9.0f" % (o[:, 12] - o[:, 11]).mean())
-    print("  regulariser+H+cholesky%9.0f" % (o[:, 14] - o[:, 12]).mean())
+    # [round 5] solved in the tree: no Delassus matrix; the second figure is the points' terms, W into the link lanes and
+    # the articulated-inertia recursion of the augmented tree (ta_factor)
+    print("  delassus (dense path) %9.0f" % (o[:, 12] - o[:, 11]).mean())
+    print("  terms + W + tree factor / H + cholesky %9.0f" % (o[:, 14] - o[:, 12]).mean())
     print("  first solve           %9.0f" % (o[:, 15] - o[:, 14]).mean())
     print("  refinement            %9.0f" % (o[:, 13] - o[:, 15]).mean())
     print("  everything else       %9.0f" % (tot - (o[:, 13] - o[:, 11])).mean())
