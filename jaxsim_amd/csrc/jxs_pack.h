@@ -128,6 +128,10 @@ std::string pack_model(const jxs_model_desc& d, Packed<T>& out) {
   if (d.integrator != JXS_INTEGRATOR_SEMI_IMPLICIT_EULER && n_en > 32 && n_en <= 64) G = 64;
   // the rigid contact models solve for all enabled points at once: one lane each
   if (d.contact_model != JXS_CONTACT_SOFT && n_en > 32 && n_en <= 64) G = 64;
+  // [round 5] RelaxedRigidContacts with more points than lanes goes through in chunks (jxs_rigid.inc
+  // relaxed_contact_forces_chunked): a full wave per environment halves the number of passes over the chunks
+  // (measured, quadruped with 200 points, N = 4096: 131 us in 64-lane groups against 156 us in 32-lane groups)
+  if (d.contact_model == JXS_CONTACT_RELAXED_RIGID && n_en > 64) G = 64;
   if (const char* e = std::getenv("JXS_CT_CHUNK_LANES")) {  // developer knob (tests): RelaxedRigidContacts in a smaller lane group, i.e. in more point chunks
     const int g = std::atoi(e);
     if (d.contact_model == JXS_CONTACT_RELAXED_RIGID && (g == 8 || g == 16 || g == 32) && g >= pow2ceil(nL)) G = std::min(G, g);

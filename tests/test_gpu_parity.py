@@ -888,7 +888,7 @@ def test_parallel_axis_models_gpu(models, name, kind, dtype, tol):
 @pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-9), (np.float32, 3e-3)])
 def test_relaxed_contacts_with_200_points_gpu(dtype, tol):
     """[round 5] The quadruped with a 50-point sphere on every foot -- 200 collidable points, the real robot's URDF shape
-    (parsers/rod/utils.py:200-204) -- with RelaxedRigidContacts: more points than lanes, chunks of 32 solved in the tree
+    (parsers/rod/utils.py:200-204) -- with RelaxedRigidContacts: more points than lanes, chunks of 64 solved in the tree
     (jxs_rigid.inc relaxed_contact_forces_chunked).  VERDICT r4's done-criterion: fp32 <= 3e-3, fp64 <= 1e-9 against the
     oracle on the GPU; no solve discarded; the batch result does not depend on the batch."""
     from jaxsim_amd import robots
