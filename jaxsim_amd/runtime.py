@@ -276,10 +276,17 @@ def trim_pool() -> None:
     """Return every pooled buffer to the driver."""
     lib = _lib.load()
     with _pool_lock:
-        for ptrs in _pool.values():
-            for p, _ in ptrs:
-                lib.jxs_free(C.c_void_p(p))
+        lists = list(_pool.values())
         _pool.clear()
+    # (drained by pop: `DeviceArray.like` and `__del__` take and give buffers without the lock -- list.pop / append are
+    # atomic -- so no buffer can be both handed out and freed)
+    for ptrs in lists:
+        while ptrs:
+            try:
+                p, _ = ptrs.pop()
+            except IndexError:
+                break
+            lib.jxs_free(C.c_void_p(p))
 
 
 class DeviceModel:

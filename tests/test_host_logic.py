@@ -448,3 +448,31 @@ def test_references_apply_frame_forces(rep):
         refs.apply_frame_forces(np.zeros((N, 2, 6)), model=model, data=data, frame_names=("rail_frame",))
     with pytest.raises(ValueError, match="unknown frame"):
         refs.apply_frame_forces(f, model=model, data=data, frame_names=("nope",))
+
+
+def test_step_host_path_caches_follow_the_environment(models, monkeypatch):
+    """[round 5] The host path of `js.model.step` keeps two things out of the per-call cost -- the value checks of
+    `JAXSIM_ENABLE_EXCEPTIONS` (read from the raw environment mapping) and the device copy of the model (a record kept next
+    to the device copies, valid while no model field was assigned and the kernel policy is the one it was made under).
+    Both must follow a change immediately: `monkeypatch.setenv` / `os.environ[...] = ...`, `model.<field> = ...`."""
+    from jaxsim_amd.api import model as M
+
+    monkeypatch.delenv("JAXSIM_ENABLE_EXCEPTIONS", raising=False)
+    assert not M._exceptions_enabled()
+    for v, want in (("True", True), ("1", True), ("on", True), ("0", False), ("no", False)):
+        monkeypatch.setenv("JAXSIM_ENABLE_EXCEPTIONS", v)
+        assert M._exceptions_enabled() is want
+    calls = []
+    monkeypatch.setattr(M.runtime, "device_model", lambda model, dtype: calls.append(1) or object())
+    with models("cartpole").editable(validate=False) as m:
+        pass
+    dt = np.dtype(np.float32)
+    monkeypatch.setenv("JAXSIM_AMD_SPECIALIZE", "cached")
+    a = M._device_model_fast(m, dt)
+    assert M._device_model_fast(m, dt) is a and len(calls) == 1          # the hot loop: two dictionary look-ups
+    assert M._device_model_fast(m, np.dtype(np.float64)) is not a and len(calls) == 2  # per precision
+    monkeypatch.setenv("JAXSIM_AMD_SPECIALIZE", "0")                       # another kernel policy: resolved again
+    assert M._device_model_fast(m, dt) is not a and len(calls) == 3
+    m.time_step = 2e-3                                                     # a model constant changed: the device copies are dropped
+    M._device_model_fast(m, dt)
+    assert len(calls) == 4
