@@ -140,6 +140,8 @@ def parse_args():
     ap.add_argument("--cpu-baseline-seconds", type=float, default=10.0)
     ap.add_argument("--saturated-envs", type=int, default=65536, help="secondary figure: batch that saturates one GPU (0 = skip)")
     ap.add_argument("--no-other-contact-models", action="store_true", help="skip the secondary RigidContacts / RelaxedRigidContacts figures")
+    ap.add_argument("--no-python-loop", action="store_true", help="skip the secondary `python_step_loop` figure (the rocprofv3 passes of tools/profile_round.sh: "
+                    "its 12 000 plain launches would be averaged into the per-dispatch statistics of the step kernel)")
     ap.add_argument("--dry-run-bootstrap", action="store_true",
                     help="no GPU work: run only the multi-rank bootstrap of this script (job key, id exchange through the "
                     "rendezvous file, host collective, shard bounds) and print what a rank-0 line would say about it")
@@ -818,7 +820,7 @@ def main():
     # a fresh data object per step (functional, like the reference's pytrees) or the same buffer (`inplace=True`, an
     # extension).  `value` above is the same launches enqueued from C (`jxs_step_repeat`); this is the interpreter's share.
     python_loop = None
-    if rank == 0:
+    if rank == 0 and not args.no_python_loop:
         try:
             import time as _time
 

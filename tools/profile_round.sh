@@ -8,7 +8,7 @@ R=$PWD
 OUT=$R/gpurun_out/$1
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-B="python $R/bench.py --steps 500 --warmup 20 --no-cpu-baseline --saturated-envs 0 --no-other-contact-models"
+B="python $R/bench.py --steps 500 --warmup 20 --no-cpu-baseline --saturated-envs 0 --no-other-contact-models --no-python-loop"
 rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/stats" -- $B > "$OUT/bench.log" 2>&1
 rocprofv3 --output-format csv --kernel-trace --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -- $B > "$OUT/pmc_fetch.log" 2>&1
 rocprofv3 --output-format csv --kernel-trace --pmc WRITE_SIZE -d "$OUT/pmc_write" -- $B > "$OUT/pmc_write.log" 2>&1

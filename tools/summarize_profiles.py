@@ -16,7 +16,7 @@ lines = [f"# rocprofv3 summary {tag} (source: {run})", ""]
 ks = glob.glob(str(run / "stats" / "*" / "*_kernel_stats.csv"))
 if ks:
     shutil.copy(ks[0], out / f"{tag}_kernel_stats.csv")
-    lines += ["## `rocprofv3 --kernel-trace --stats -- python bench.py --steps 500 --warmup 20 --no-cpu-baseline --saturated-envs 0 --no-other-contact-models`", "",
+    lines += ["## `rocprofv3 --kernel-trace --stats -- python bench.py --steps 500 --warmup 20 --no-cpu-baseline --saturated-envs 0 --no-other-contact-models --no-python-loop`", "",
               "| kernel | calls | total ns | avg ns | % |", "|---|---|---|---|---|"]
     for r in csv.DictReader(open(ks[0])):
         lines.append(f"| `{r['Name'][:90]}` | {r['Calls']} | {r['TotalDurationNs']} | {float(r['AverageNs']):.0f} | {float(r['Percentage']):.2f} |")
