@@ -67,7 +67,7 @@ std::string kernel_spec_string(const Packed<T>& pk, int mode) {
   add("flat", P.flat), add("enable_friction", P.enable_friction), add("pq_half", P.pq_half), add("anchored", P.anchored);
   add("rigid", P.rigid), add("n_cp", P.n_cp), add("rg_merge", P.rg_merge), add("rr_refine", P.rr_refine), add("rk4fast", P.rk4fast);
   add("jump_pad", P.jump_pad), add("jrow_seq", P.jrow_seq), add("prow_seq", P.prow_seq);
-  add("ct_tree", P.ct_tree);
+  add("ct_tree", P.ct_tree), add("qp_warm", P.qp_warm);
   s.pop_back();
   return s;
 }
@@ -482,6 +482,22 @@ std::string pack_model(const jxs_model_desc& d, Packed<T>& out) {
     }
   }
   P.ct_tree = ct_tree;
+  // [round 5] the warm start of the interior-point iteration (jxs_rigid.inc rigid_qp_warm_start): RigidContacts with every
+  // point alone in its own subtree of a floating base, at most four of them -- the same structural condition as the merged
+  // sweeps above, but not subject to their developer knob (oracle/refrigid.py points_alone_in_base_subtrees mirrors it)
+  P.qp_warm = 0;
+  if (P.rigid == 1 && d.floating_base && n_en >= 1 && n_en <= 4 && n_chunks == 1 && std::getenv("JXS_DISABLE_QP_WARM") == nullptr) {  // (developer knob: A/B)
+    bool ok = true;
+    std::vector<int> l1(n_en, -1);
+    for (int s2 = 0; s2 < n_en && ok; ++s2) {
+      int a = d.point_body[en[s2]];
+      if (level[a] < 1) ok = false;
+      while (ok && level[a] > 1) a = d.parent[a];
+      l1[s2] = a;
+      for (int t = 0; t < s2; ++t) ok = ok && l1[t] != a;
+    }
+    P.qp_warm = ok ? 1 : 0;
+  }
   // RelaxedRigidContacts in the tree: two refinement steps in fp32, one in fp64 reach the accuracy of the dense path
   // (the regulariser is never at the rounding level here, eligibility above), so the steps that pay for mu = 0.005 in
   // fp32 are not needed

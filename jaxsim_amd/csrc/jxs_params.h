@@ -282,6 +282,12 @@ struct KParams {
   // links carry the extra 6 x 6 "inertia" W_l = sum_p P_p^T D_p^-1 P_p.  No matrix, no rank decision, any number of contact
   // links.  1: this model's contact solves run that way (decided by the packer).
   int ct_tree;
+  // [round 5] RigidContacts: the interior-point iteration starts from the UNCONSTRAINED minimiser x = -Q^-1 q instead of
+  // CVXGEN's penalised one, and an environment in which that x is feasible is done without an iteration (jxs_rigid.inc).
+  // 1 for models whose points sit alone in their own subtrees of a floating base (a legged robot with one point per foot:
+  // config 5), where the Delassus matrix is well conditioned; with several points on one rigid body it is singular up to
+  // the 1e-6 regularisation and its unconstrained minimiser is far from anything.
+  int qp_warm;
   int jump_pad;                  // 1: pointer-jumping sources beyond the base point at a padding lane that holds the identity
                                  // transform and zero vectors (no selects in the rounds); 0: they are -1 (no padding lane: nL == G)
   // [round 3] The joint rows (and, with one point chunk of <= G collidable points, the deformation rows) of the state are

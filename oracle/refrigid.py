@@ -285,9 +285,34 @@ def _step_to_boundary(v, dv):
     return float(np.min(r)) if r.size else np.inf
 
 
-def solve_qp_pdip(Q, q, G, h, solver_tol=1e-3, max_iter=QP_MAX_ITER, stall_guard=False):
+def points_alone_in_base_subtrees(model) -> bool:
+    """The structural condition under which the HIP kernel warm-starts its interior-point iteration (csrc/jxs_pack.h
+    ``KParams::qp_warm``): a floating base, one to four enabled collidable points, each on a link below a DIFFERENT child
+    of the base (a legged robot with one point per foot) -- the Delassus matrix is then well conditioned."""
+    kdp = model.kin_dyn_parameters
+    if not model.floating_base():
+        return False
+    parent = np.asarray(kdp.parent_array)
+    bodies = [int(b) for b, e in zip(np.asarray(kdp.contact_body), np.asarray(kdp.contact_enabled)) if e]
+    if not 1 <= len(bodies) <= 4:
+        return False
+    tops = []
+    for b in bodies:
+        if b == 0:
+            return False
+        while parent[b] != 0:
+            b = int(parent[b])
+        tops.append(b)
+    return len(set(tops)) == len(tops)
+
+
+def solve_qp_pdip(Q, q, G, h, solver_tol=1e-3, max_iter=QP_MAX_ITER, stall_guard=False, warm_start=False):
     """min 1/2 x'Qx + q'x  s.t.  Gx <= h  (no equality constraints on this path,
     rigid.py:347-349).  Returns ``(x, s, z, iterations, converged)``.
+
+    ``warm_start`` (the HIP kernel's certificate for well-conditioned problems, not part of CVXGEN): if the unconstrained
+    minimiser ``-Q^-1 q`` is feasible (``G x <= h``) it is the minimiser and is returned with 0 iterations; otherwise the
+    iteration starts from CVXGEN's point as always.
 
     ``stall_guard`` (the HIP kernel's termination rule, not part of CVXGEN): also stop when the
     complementarity gap is below the tolerance and the residual no longer halves -- in fp32 with
@@ -295,6 +320,11 @@ def solve_qp_pdip(Q, q, G, h, solver_tol=1e-3, max_iter=QP_MAX_ITER, stall_guard
     below the tolerance."""
     Q, q, G, h = (np.asarray(a, dtype=np.result_type(Q, np.float32)) for a in (Q, q, G, h))
     nz = G.shape[0]
+    if warm_start:
+        xu = np.linalg.solve(Q, -q)
+        gu = G @ xu - h
+        if np.max(gu) <= 0:
+            return xu, -gu, np.zeros_like(gu), 0, True  # the unconstrained minimiser is feasible: it is the solution
     # ---- initialisation (CVXGEN 5.2): [Q G'; G -I][x; z] = [-q; h], then shift into the cone
     x = np.linalg.solve(Q + G.T @ G, -q + G.T @ h)
     z = G @ x - h
@@ -412,6 +442,7 @@ def compute_contact_forces(model, data: rs.OracleData, *, link_forces=None, join
     f = np.zeros((N, n_cp, 3), dtype=dtype)
     info = []
     reduced = REDUCED_QP if reduced is None else reduced
+    warm = reduced and points_alone_in_base_subtrees(model)  # (the kernel's initial point; the reference's statement keeps CVXGEN's)
     for e in range(N):
         Q = pb["delassus"][e] + cm.regularization_delassus * np.eye(3 * n_cp, dtype=dtype)
         q = pb["a_free"][e] - pb["baumgarte"][e]
@@ -427,7 +458,7 @@ def compute_contact_forces(model, data: rs.OracleData, *, link_forces=None, join
                 G = ineq_constraint_matrix(np.zeros(act.size, dtype=bool), mu, dtype)
                 G = G[np.arange(6 * act.size) % 6 != 5]  # drop the 0 <= 0 rows
                 x, s, z, it, ok = solve_qp_pdip(Q[np.ix_(rows, rows)], q[rows], G, np.zeros(5 * act.size, dtype=dtype),
-                                                solver_tol=cm.solver_tol, stall_guard=True)  # fmt: skip
+                                                solver_tol=cm.solver_tol, stall_guard=True, warm_start=warm)  # fmt: skip
                 f[e, act] = x.reshape(-1, 3)
         info.append((it, ok))
     # mixed force at the point -> inertial wrench [f; p x f]   (rigid.py:368-387)
