@@ -977,6 +977,31 @@ def test_chunked_relaxed_solve_equals_the_one_chunk_form(models, n_points, lanes
         assert helpers.rel_err(chunked, one) < 1e-11
 
 
+def test_rigid_contacts_fp64_beyond_47_points_on_three_links(reduced_qp):
+    """[round 5] RigidContacts in the reference's default precision with 60 points on THREE links: the two triangles of the
+    dense path (180 x 180 doubles twice: 260 KB) do not fit the LDS of a CU, round 4's link space took two links at most --
+    refused until now.  The interior-point iteration runs in the tree (adaptive refinement of its Newton directions, best
+    iterate kept: jxs_rigid.inc rigid_qp_tree), which is the path such a model takes by default."""
+    from jaxsim_amd import specialize
+
+    idx = list(range(0, 20)) + list(range(50, 70)) + list(range(100, 120))
+    model = helpers.rigid_model(_quadruped_200(), idx, K=1e4, D=2e2)
+    assert "P.ct_tree=1" in specialize.spec(model, np.float64, specialize.MODE_STEP_RIGID) and eb.layout(model, np.float64).group == 64
+    with pytest.raises(RuntimeError, match="does not fit"):
+        import os
+
+        os.environ["JXS_DISABLE_CT_TREE"] = "1"
+        try:
+            eb.layout(model, np.float64)
+        finally:
+            del os.environ["JXS_DISABLE_CT_TREE"]
+    for d in (oracle.random_model_data(model, batch_size=8, seed=2, base_pos_bounds=((-1, -1, 0.56), (1, 1, 0.66)), base_rpy_bounds=((-0.3, -0.3, -3), (0.3, 0.3, 3))),
+              helpers.standing_data(model, 8, seed=2, noise=0.05)):  # fmt: skip
+        truth = helpers.odata_to_block(model, oracle.step(model, d))
+        out = eb.run(model, eb.MODE_STEP, helpers.odata_to_block(model, d))
+        assert helpers.rel_err(out, truth) < 1e-6
+
+
 def test_more_points_than_lanes_outside_the_tree_solve_is_refused():
     """What still needs one lane per point says so: RigidContacts, RelaxedRigidContacts in fp32 with the bare default
     regulariser (the dense path), Runge-Kutta with a rigid contact model."""
