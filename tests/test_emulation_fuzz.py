@@ -12,7 +12,7 @@ ROOT = pathlib.Path(__file__).resolve().parent.parent
 
 
 @pytest.mark.parametrize("script,seed,trials", [("fuzz_step.py", 21, 40), ("fuzz_rigid.py", 22, 30), ("fuzz_query.py", 23, 25),
-                                                ("fuzz_rollout.py", 24, 30), ("fuzz_contact_tree.py", 25, 30)])  # fmt: skip
+                                                ("fuzz_rollout.py", 24, 30), ("fuzz_contact_tree.py", 25, 30), ("fuzz_contact_tree2.py", 26, 40)])  # fmt: skip
 def test_fuzz_slice(script, seed, trials):
     env = dict(os.environ, PYTHONPATH=os.pathsep.join([str(ROOT), str(ROOT / "tests"), os.environ.get("PYTHONPATH", "")]))
     p = subprocess.run([sys.executable, str(ROOT / "tools" / "fuzz" / script), str(seed), str(trials)], capture_output=True, text=True,
