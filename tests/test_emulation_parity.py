@@ -1048,6 +1048,34 @@ def test_contact_tree_solve_on_random_trees():
     helpers.note("contact_tree_random_trees_fp32_worst", worst32)
 
 
+@pytest.mark.parametrize("case", ["one_point", "base_link_of_a_fixed_tree", "64_links", "one_link_one_point"])
+@pytest.mark.parametrize("kind", ["relaxed", "rigid"])
+def test_contact_solve_edge_shapes(reduced_qp, case, kind):
+    """[round 5] The edges of the contact problem's shape: a single enabled point (a 3x3 problem, far from a six-lane
+    group's width), points only on the base link of a FIXED tree (every column of J is null: the forces are whatever the
+    regularisation says and move nothing), a 64-link tree with boxes on its first, middle and last link (one link per
+    lane of a full wave), and a single link with a single point."""
+    import jaxsim_amd as ja
+    from jaxsim_amd import robots
+
+    if case == "one_point":
+        base, idx = ja.JaxSimModel.build_from_model_description(robots.chain_urdf(6, fixed_base=False, seed=5, collision_links=(5,))), [0]
+    elif case == "base_link_of_a_fixed_tree":
+        base, idx = ja.JaxSimModel.build_from_model_description(robots.chain_urdf(5, fixed_base=True, seed=1, collision_links=(0,), base_offset=(0.0, 0.0, 0.0))), list(range(8))
+    elif case == "64_links":
+        base, idx = ja.JaxSimModel.build_from_model_description(robots.chain_urdf(64, fixed_base=False, seed=3, max_back=3, collision_links=(0, 31, 63))), list(range(24))
+    else:
+        base, idx = ja.JaxSimModel.build_from_model_description(robots.box_urdf()), [0]
+    if kind == "rigid" and case == "64_links":
+        idx = idx[::2]  # (12 points: the 24-point dense QP on a 64-lane group is minutes of emulation)
+    model = helpers.relaxed_model(base, idx, mu=0.5) if kind == "relaxed" else helpers.rigid_model(base, idx, K=1e4, D=1e2, build=dict(solver_options={"solver_tol": 1e-6 if case == "64_links" else 1e-9}))
+    # (64 links at solver_tol 1e-9: the ORACLE's own KKT factorisation loses positive definiteness on this tree, as the reference's would)
+    d = oracle.random_model_data(model, batch_size=6, seed=3, base_pos_bounds=((-1, -1, -0.2), (1, 1, 0.1)), base_rpy_bounds=((-0.4, -0.4, -3), (0.4, 0.4, 3)))
+    truth = helpers.odata_to_block(model, oracle.step(model, d))
+    out = eb.run(model, eb.MODE_STEP, helpers.odata_to_block(model, d))
+    assert helpers.rel_err(out, truth) < (1e-9 if kind == "relaxed" else 1e-6), (case, kind)
+
+
 @pytest.mark.parametrize("fixed_base,max_back", [(True, 1), (False, 1), (False, 3)])
 def test_maximum_size_models(models, fixed_base, max_back):
     """The largest supported model: 64 links, one per lane of a full wave; a serial chain makes the tree
