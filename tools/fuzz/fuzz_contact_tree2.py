@@ -13,6 +13,7 @@ from jaxsim_amd import robots
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 17)
 trials = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 worst, count, nfail, refused, oracle_failed = {}, {}, 0, 0, 0
+only = set(int(v) for v in os.environ["FUZZ_ONLY"].split(",")) if os.environ.get("FUZZ_ONLY") else None  # re-run single trials of a campaign (same random stream)
 for trial in range(trials):
     n_links = int(rng.integers(2, 41)); seed = 9000 + trial
     fixed = bool(rng.integers(0, 5) == 0)
@@ -33,8 +34,11 @@ for trial in range(trials):
         os.environ["JXS_CT_CHUNK_LANES"] = cap
     for dtype, tol in ((np.float64, 1e-8), (np.float32, 3e-3)):
         key = ("rk4" if rk4 else "euler", "chunk" + str(cap) if (cap and not rk4) else "one", np.dtype(dtype).name)
+        mu = float(rng.choice([0.3, 0.5, 0.8]))
+        if only is not None and trial not in only:
+            continue
         try:
-            model = helpers.relaxed_model(base, idx, mu=float(rng.choice([0.3, 0.5, 0.8])))
+            model = helpers.relaxed_model(base, idx, mu=mu)
             if rk4:
                 model = helpers.with_params(model, integrator=ja.IntegratorType.RungeKutta4)
             d = oracle.random_model_data(model, batch_size=4, seed=seed, dtype=dtype, base_pos_bounds=((-1, -1, 0.0), (1, 1, 0.3)), base_rpy_bounds=((-0.4, -0.4, -3), (0.4, 0.4, 3)))
