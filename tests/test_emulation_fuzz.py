@@ -26,3 +26,17 @@ def test_fuzz_slice(script, seed, trials):
     if "compared" in words:
         compared, refused, failed = (int(words[words.index(k) + 1]) for k in ("compared", "refused", "oracle_failed"))
         assert compared >= 0.75 * (compared + refused + failed), last[-1]
+
+
+def test_device_campaign_tool_dry_run(tmp_path):
+    """[round 5] tools/fuzz/gpu_campaign.py (the fuzz campaign through the PRODUCT on an MI355X: `-m gpu` runs a slice,
+    tests/test_gpu_parity.py; the full record is profiles/r05_gpu_fuzz_campaign.txt) -- its case generation, gates and
+    table, here with the emulation's result standing in for the device's."""
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([str(ROOT), str(ROOT / "tests"), os.environ.get("PYTHONPATH", "")]), GPU_CAMPAIGN_DRY="1")
+    tool, cases = str(ROOT / "tools" / "fuzz" / "gpu_campaign.py"), str(tmp_path / "cases.pkl")
+    p = subprocess.run([sys.executable, tool, "prepare", cases, "41", "16"], capture_output=True, text=True, env=env, timeout=900)
+    assert p.returncode == 0 and "prepared" in p.stdout, p.stderr[-2000:]
+    prepared = int(p.stdout.split("prepared")[1].split()[0])
+    assert prepared >= 20  # (16 trees, two precisions each except RigidContacts)
+    p = subprocess.run([sys.executable, tool, "run", cases], capture_output=True, text=True, env=env, timeout=900)
+    assert p.returncode == 0 and f"{prepared} cases compared" in p.stdout and "fails 0;" in p.stdout, (p.stdout[-2000:], p.stderr[-2000:])

@@ -866,6 +866,29 @@ def test_contact_tree_solve_on_random_trees_gpu(reduced_qp, kind, n_links, seed,
         assert err32 < 3e-3
 
 
+def test_fuzz_campaign_slice_on_the_device(tmp_path):
+    """[round 5] A slice of tools/fuzz/gpu_campaign.py: 60 random trees (1 to 40 links, SoftContacts / RelaxedRigidContacts
+    -- one chunk and chunked -- / RigidContacts, semi-implicit Euler / RungeKutta4, fp64 and fp32) prepared on the host
+    (oracle truth, the emulation's result, the fp32 sensitivities), then stepped through the product on the device: fp64
+    within the class tolerances of the truth and 1e-9 of the emulation, fp32 within what the case's own measured
+    sensitivity allows.  The full campaign (1500 trees, 2633 cases, 0 fails): profiles/r05_gpu_fuzz_campaign.txt."""
+    import os
+    import pathlib
+    import subprocess
+    import sys
+
+    root = pathlib.Path(__file__).resolve().parent.parent
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([str(root), str(root / "tests"), os.environ.get("PYTHONPATH", "")]))
+    env.pop("GPU_CAMPAIGN_DRY", None)
+    tool, cases = str(root / "tools" / "fuzz" / "gpu_campaign.py"), str(tmp_path / "cases.pkl")
+    p = subprocess.run([sys.executable, tool, "prepare", cases, "43", "60"], capture_output=True, text=True, env=env, timeout=900)
+    assert p.returncode == 0 and "prepared" in p.stdout, p.stderr[-2000:]
+    prepared = int(p.stdout.split("prepared")[1].split()[0])
+    assert prepared >= 80
+    p = subprocess.run([sys.executable, tool, "run", cases], capture_output=True, text=True, env=env, timeout=900)
+    assert p.returncode == 0 and f"{prepared} cases compared" in p.stdout and "fails 0;" in p.stdout, (p.stdout[-3000:], p.stderr[-2000:])
+
+
 @pytest.mark.parametrize("name,kind,dtype,tol", [("planar_biped", "relaxed", np.float32, 3e-4), ("planar_biped", "relaxed", np.float64, 1e-10), ("planar_biped", "rigid", np.float64, 1e-4),
                                                  ("planar10f", "relaxed", np.float32, 3e-3), ("planar10f", "relaxed", np.float64, 1e-10), ("planar_biped", "rigid", np.float32, 3e-3)])  # fmt: skip
 def test_parallel_axis_models_gpu(models, name, kind, dtype, tol):
