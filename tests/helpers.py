@@ -222,7 +222,7 @@ def upcast(d: oracle.OracleData, model=None) -> oracle.OracleData:
     return out
 
 
-def oracle_sensitivity(model, d32: oracle.OracleData, trials: int = 3, seed: int = 0) -> np.ndarray:
+def oracle_sensitivity(model, d32: oracle.OracleData, trials: int = 3, seed: int = 0, **step_kw) -> np.ndarray:
     """Per environment: how far ONE fp64 oracle step moves (the parity metric, max over the state rows) when every
     entry of the fp32 input state is perturbed by one ulp (random signs, `trials` draws).  The contact models are
     discontinuous (a point entering contact, stick / slip, max(0, .)): an environment that sits on such an edge answers
@@ -232,13 +232,13 @@ def oracle_sensitivity(model, d32: oracle.OracleData, trials: int = 3, seed: int
     widening the gate for all."""
     blk32 = odata_to_block(model, d32)
     blk = blk32.astype(np.float64)
-    base = odata_to_block(model, oracle.step(model, block_to_odata(model, blk, d32.velocity_representation)))
+    base = odata_to_block(model, oracle.step(model, block_to_odata(model, blk, d32.velocity_representation), **step_kw))
     rng = np.random.default_rng(seed)
     ulp = np.spacing(np.abs(blk32)).astype(np.float64)
     sens = np.zeros(blk.shape[1])
     for _ in range(trials):
         b2 = blk + rng.choice([-1.0, 1.0], size=blk.shape) * ulp
-        o = odata_to_block(model, oracle.step(model, block_to_odata(model, b2, d32.velocity_representation)))
+        o = odata_to_block(model, oracle.step(model, block_to_odata(model, b2, d32.velocity_representation), **step_kw))
         sens = np.maximum(sens, (np.abs(o - base) / np.maximum(1.0, np.abs(base))).max(axis=0))
     return sens
 
