@@ -350,8 +350,8 @@ def inverse_dynamics(model: JaxSimModel, data: JaxSimModelData, *, joint_acceler
     dm = runtime.device_model(model, data.dtype)
     _check_quaternion(model, data, normalized=True)  # RNEA receives the raw quaternion (api/model.py:1856)
     N, nL, n = data.batch_size, model.number_of_links(), model.dofs()
-    sdd = np.zeros((N, n)) if joint_accelerations is None else np.broadcast_to(
-        np.asarray(joint_accelerations, dtype=np.float64).reshape(-1, n), (N, n))  # fmt: skip
+    sdd = np.zeros((N, n)) if (joint_accelerations is None or n == 0) else np.broadcast_to(
+        np.asarray(joint_accelerations, dtype=np.float64).reshape(-1, n), (N, n))  # fmt: skip  (n == 0: a model without joints takes the empty array the reference takes)
     vd = np.zeros((N, 6)) if base_acceleration is None else np.broadcast_to(
         np.asarray(base_acceleration, dtype=np.float64).reshape(-1, 6), (N, 6))  # fmt: skip
     # active representation -> inertial (api/model.py:1801-1842)

@@ -329,6 +329,8 @@ class JaxSimModelData:
             if new is None:
                 return old
             a = np.asarray(new, dtype=np.float64)
+            if old.size == 0:  # (a model without joints: the empty joint arrays of the reference)
+                return old
             return np.broadcast_to(a.reshape((-1,) + old.shape[1:]), old.shape).copy()
 
         q = pick(base_quaternion, f["base_quaternion"]).astype(np.float64)

@@ -866,6 +866,36 @@ def test_contact_tree_solve_on_random_trees_gpu(reduced_qp, kind, n_links, seed,
         assert err32 < 3e-3
 
 
+def test_queries_of_a_model_without_joints_gpu(models):
+    """[round 5] A single floating link (n = 0): every query takes the EMPTY joint arrays the reference takes
+    (`inverse_dynamics(joint_accelerations=jnp.zeros(0))`) -- found by tools/fuzz/gpu_campaign_queries.py, whose one-link
+    trees raised a ValueError in the host wrapper of `inverse_dynamics` (reshape(-1, 0))."""
+    model = models("box")
+    N = 5
+    d = models.random_data("box", N, seed=3)
+    g = to_gpu(model, d)
+    _, f = helpers.random_inputs(model, N, 4, np.float64)
+    acc = np.random.default_rng(5).uniform(-2, 2, size=(N, 6))
+    for ja_ in (np.zeros((N, 0)), np.zeros(0), None):
+        fB, tau = js.model.inverse_dynamics(model, g, joint_accelerations=ja_, base_acceleration=acc, link_forces=f)
+        rB, rtau = oracle.inverse_dynamics(model, d, joint_accelerations=np.zeros((N, 0)), base_acceleration=acc, link_forces=f)
+        assert tau.shape == (N, 0) and helpers.rel_err(fB, rB) < 1e-10
+    vd, sdd = js.model.forward_dynamics_aba(model, g, joint_forces=np.zeros((N, 0)), link_forces=f)
+    rvd, _ = oracle.forward_dynamics_aba(model, d, joint_forces=np.zeros((N, 0)), link_forces=f)
+    assert sdd.shape == (N, 0) and helpers.rel_err(vd, rvd) < 1e-10
+    assert helpers.rel_err(js.model.free_floating_mass_matrix(model, g), oracle.free_floating_mass_matrix(model, d)) < 1e-12
+    assert helpers.rel_err(js.model.free_floating_bias_forces(model, g), oracle.free_floating_bias_forces(model, d)) < 1e-10
+    assert helpers.rel_err(js.model.free_floating_gravity_forces(model, g), oracle.free_floating_gravity_forces(model, d)) < 1e-10
+    assert helpers.rel_err(js.model.free_floating_mass_matrix_inverse(model, g) @ oracle.free_floating_mass_matrix(model, d), np.broadcast_to(np.eye(6), (N, 6, 6))) < 1e-9
+    J, Jd, _ = js.model.jacobian_full_doubly_left(model, g)
+    assert J.shape[-1] == 6 and Jd.shape[-1] == 6
+    out = js.model.rollout(model, g, 3, joint_force_references=np.zeros((3, N, 0))).state_block()
+    dk = d
+    for _ in range(3):
+        dk = oracle.step(model, dk)
+    assert helpers.rel_err(out, helpers.odata_to_block(model, dk)) < 1e-9
+
+
 def test_fuzz_campaign_slice_on_the_device(tmp_path):
     """[round 5] A slice of tools/fuzz/gpu_campaign.py: 60 random trees (1 to 40 links, SoftContacts / RelaxedRigidContacts
     -- one chunk and chunked -- / RigidContacts, semi-implicit Euler / RungeKutta4, fp64 and fp32) prepared on the host
