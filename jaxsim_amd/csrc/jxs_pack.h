@@ -498,10 +498,14 @@ std::string pack_model(const jxs_model_desc& d, Packed<T>& out) {
     }
     P.qp_warm = ok ? 1 : 0;
   }
-  // RelaxedRigidContacts in the tree: two refinement steps in fp32, one in fp64 reach the accuracy of the dense path
-  // (the regulariser is never at the rounding level here, eligibility above), so the steps that pay for mu = 0.005 in
-  // fp32 are not needed
-  if (ct_tree && P.rigid == 2 && std::getenv("JXS_RR_REFINE") == nullptr) P.rr_refine = sizeof(T) == 8 ? 1 : 2;
+  // RelaxedRigidContacts in the tree: ONE refinement step reaches the accuracy of the dense path (the regulariser is
+  // never at the rounding level here, eligibility above), so the steps that pay for mu = 0.005 in fp32 are not needed.
+  // [round 5, late] fp32 had two until the residual histories were printed (profiles/r05_experiments.md, last sections):
+  // after ONE correction the residual sits at the rounding level of the operator application (humanoid 4491 -> 69.6 ->
+  // 74.5 floors; another state 30241 -> 1.3 -> 33.5: the second, unverified correction made it worse) -- robots: same
+  // worst / p99 error with one step; 500 fuzz trees: two comparisons above 3e-3 instead of one.  An operator application
+  // and a tree solve less per step: humanoid -13 %, quadruped -10 %.
+  if (ct_tree && P.rigid == 2 && std::getenv("JXS_RR_REFINE") == nullptr) P.rr_refine = 1;
   for (int ch = 0; ch < n_chunks; ++ch) {
     int s = ch * G;
     const int end = std::min(n_en, (ch + 1) * G);
