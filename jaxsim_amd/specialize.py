@@ -144,11 +144,11 @@ def compile_text(text: str, *, force: bool = False) -> pathlib.Path:
             # [round 5] the lock file goes when its build ends (round 4 left 2528 of them in the cache, and they travelled
             # to every GPU box).  A process still queued on the unlinked file gets its lock, finds the object and returns;
             # one that arrives later makes a new file -- at worst two builders, each renaming a complete object into place.
-            if out.exists():
-                try:
-                    lock_path.unlink()
-                except OSError:
-                    pass
+            # (whether the build succeeded or not: a failed or interrupted build left its lock behind until now)
+            try:
+                lock_path.unlink()
+            except OSError:
+                pass
             fcntl.flock(lock, fcntl.LOCK_UN)
 
 
