@@ -132,6 +132,20 @@ def prepare(path, seed, trials):
                 for _ in range(6):
                     o = eb.run(model, eb.MODE_STEP, (state + prng.choice([-1.0, 1.0], size=state.shape).astype(np.float32) * ulp).astype(np.float32), **kw_e).astype(np.float64)
                     scatter = np.maximum(scatter, (np.abs(o - base) / np.maximum(1.0, np.abs(base))).max(axis=0))
+            if dtype == np.float64 and trial % 3 == 0:  # fp64 extras: a 3-step rollout (with the state of every step) and the gravity-compensated step
+                try:
+                    dk, traj = d, []
+                    for _ in range(3):
+                        dk = oracle.step(model, dk, **kw_o)
+                        traj.append(helpers.odata_to_block(model, dk))
+                    if np.isfinite(traj[-1]).all() and np.abs(traj[-1]).max() < 1e4:  # (a trajectory the ORACLE loses or that explodes -- the default stiffness on 0.5 kg links -- is no truth)
+                        case["rollout3"] = np.stack(traj)
+                        case["rollout3_emul_err"] = float(helpers.rel_err(eb.run(model, eb.MODE_STEP, state, n_steps=3, **kw_e), traj[-1]))
+                    if not with_inputs and model.dofs() > 0:
+                        g = oracle.free_floating_gravity_forces(model, d)[:, 6:]
+                        case["gravcomp"] = helpers.odata_to_block(model, oracle.step(model, d, joint_force_references=g))
+                except np.linalg.LinAlgError:
+                    pass
             case.update(state=state, truth=truth, emul=emul, rep=str(d.velocity_representation), ref32_err=ref32_err, sens=sens, scatter=scatter,
                         group=int(eb.layout(model, dtype).group), emul_err=float(helpers.rel_err(emul, truth)))
             cases.append(case)
@@ -179,7 +193,7 @@ def run(path, out_path):
 
     with open(path, "rb") as f:
         blob = pickle.load(f)
-    lines, worst, worst_emul, count, nfail, stats, widened, widened64 = [], {}, {}, {}, 0, {}, 0, 0
+    lines, worst, worst_emul, count, nfail, stats, widened, widened64, extras = [], {}, {}, {}, 0, {}, 0, 0, {}
     REP = {oracle.VelRepr.Inertial: ja.VelRepr.Inertial, oracle.VelRepr.Body: ja.VelRepr.Body, oracle.VelRepr.Mixed: ja.VelRepr.Mixed}
     todo = [(c, False) for c in blob["cases"]] + [(blob["cases"][i], True) for i in blob.get("specialised", [])]
     for case, specialised in todo:
@@ -194,6 +208,16 @@ def run(path, out_path):
             data = js.data.JaxSimModelData.from_state_block(model, case["state"], REP[case["rep"]])
             out = js.model.step(model, data, **({} if case.get("tau") is None else dict(link_forces=case["f"], joint_force_references=case["tau"]))).state_block()
         e, ee = float(helpers.rel_err(out, case["truth"])), float(helpers.rel_err(out, case["emul"]))
+        if not os.environ.get("GPU_CAMPAIGN_DRY") and case.get("rollout3") is not None:
+            kw = {} if case.get("tau") is None else dict(link_forces=case["f"], joint_force_references=case["tau"])
+            fin, states = js.model.rollout(model, data, 3, return_trajectory=True, **kw)
+            er = max(float(helpers.rel_err(states[k], case["rollout3"][k])) for k in range(3))
+            er = max(er, float(helpers.rel_err(fin.state_block(), case["rollout3"][2])), float(helpers.rel_err(js.model.rollout(model, data, 3, **kw).state_block(), case["rollout3"][2])))
+            extras.setdefault((case["kind"], "rollout of 3 steps, recorded and not"), []).append((er, case["rollout3_emul_err"]))
+            if case.get("gravcomp") is not None:
+                eg = float(helpers.rel_err(js.model.step(model, data, gravity_compensation=True).state_block(), case["gravcomp"]))
+                eg = max(eg, float(helpers.rel_err(js.model.step(model, data, joint_force_references=js.model.gravity_compensation_torques(model, data)).state_block(), case["gravcomp"])))
+                extras.setdefault((case["kind"], "gravity-compensated step, one launch and two"), []).append((eg, 0.0))
         chunked = case["cap"] is not None and len(case["idx"]) > int(case["cap"])
         key = (case["kind"] + ("/chunked" if chunked else "") + (" [specialised]" if specialised else ""), "rk4" if case["rk4"] else "euler", case["dtype"])
         if specialised and not os.environ.get("GPU_CAMPAIGN_DRY"):
@@ -229,6 +253,16 @@ def run(path, out_path):
             lines.append("FAIL trial %d %s nL %d fixed %s coll %s points %d: device-truth %.2e (emulation-truth %.2e, reference formulation in fp32 %.2e) device-emulation %.2e"
                          % (case["trial"], key, case["tree"]["n_links"], case["tree"]["fixed_base"], case["tree"]["collision_links"], len(case["idx"]), e, case["emul_err"], case["ref32_err"], ee))
     os.environ.pop("JXS_CT_CHUNK_LANES", None)
+    # the fp64 extras: three steps compound the one-step distance (RigidContacts: where the iteration stops, three times)
+    extra_lines = []
+    XTOL = {"soft": 1e-8, "relaxed": 1e-7, "rigid": 1e-4}
+    for key in sorted(extras):
+        v = np.array(extras[key])
+        # (a diverging trajectory amplifies 1e-16 like anything else: such a case is held to three times the emulation's own distance)
+        bad = int(np.sum(v[:, 0] >= np.maximum(XTOL[key[0]], 3.0 * v[:, 1])))
+        nfail += bad
+        extra_lines.append("%-10s %-46s float64 %6d | device vs truth: worst %.2e median %.2e, above %.0e: %d of which beyond 3 x the emulation's distance: %d"
+                           % (key[0], key[1], len(v), v[:, 0].max(), np.median(v[:, 0]), XTOL[key[0]], int(np.sum(v[:, 0] >= XTOL[key[0]])), bad))
     lines.append("campaign seed %d, %d trees: %d cases compared on the device (prepare: %d refused by the model constructor, %d the oracle could not solve); fails %d; "
                  "fp32 cases that pass by their own measured sensitivity only (above the class tolerance and above 3 x the emulation / the reference formulation in fp32): %d; fp64 cases above the class tolerance that pass by 3 x the emulation's own distance to the truth: %d"
                  % (blob["seed"], blob["trials"], sum(count.values()), blob["refused"], blob["oracle_failed"], nfail, widened, widened64))
@@ -240,6 +274,7 @@ def run(path, out_path):
         tol = TOL[(key[0].split("/")[0].split(" ")[0], key[2])]
         col = lambda v: "%.2e %.2e %4d" % (np.nanmax(v), np.nanmedian(v), int(np.sum(v >= tol))) if np.isfinite(v).any() else "-"  # noqa: E731
         lines.append("%-30s %-6s %-8s %6d | %-28s | %-28s | %-28s | %.2e" % (key[0], key[1], key[2], count[key], col(a[:, 0]), col(a[:, 1]), col(a[:, 2]), worst_emul[key]))
+    lines.extend(extra_lines)
     text = "\n".join(lines)
     print(text)
     if out_path:
