@@ -121,6 +121,18 @@ def issue_figures(valu_per_wave, envs_per_wave, n_envs, us_per_step):
             "lane_slot_efficiency": (FLOPS_PER_ENV_STEP / 2) / (valu_per_wave * 64 / envs_per_wave)}
 
 
+def rccl_required(args, device_count: int, world: int) -> bool:
+    """[round 6] Whether a rank whose RCCL communicator cannot be created must exit non-zero.  Asked for explicitly
+    (--require-rccl / JAXSIM_AMD_REQUIRE_RCCL=1), or BY DEFAULT whenever the box has a device per rank: there the file
+    collective can only be an accident, and a scaling record must not be one.  The file collective remains for
+    --share-device (fewer GPUs than ranks, where RCCL refuses two ranks on one device) and --allow-file-collective."""
+    if args.require_rccl:
+        return True
+    if args.share_device or args.allow_file_collective:
+        return False
+    return device_count >= world
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -136,6 +148,8 @@ def parse_args():
                     help="multi-rank runs: a rank whose communicator is not RCCL (ncclCommInitRank failed and the host-side file collective "
                     "would take over) exits non-zero instead -- a scaling record cannot be a file collective by accident "
                     "(also JAXSIM_AMD_REQUIRE_RCCL=1)")
+    ap.add_argument("--allow-file-collective", action="store_true", help="multi-rank runs on a box with a device per rank: let the host-side file collective "
+                    "take over when RCCL fails instead of exiting non-zero (the default there since round 6 is --require-rccl)")
     ap.add_argument("--share-device", action="store_true", help="developer: ranks take device LOCAL_RANK %% device_count -- the N > 1 path on a box with fewer GPUs than ranks (RCCL refuses two ranks on one device: the host-side file collective takes over, `comm.kind` says so); the figure is not a scaling measurement")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=10.0)
     ap.add_argument("--saturated-envs", type=int, default=65536, help="secondary figure: batch that saturates one GPU (0 = skip)")
@@ -659,6 +673,7 @@ def main():
 
     runtime.require_device()
     runtime.set_device(local_rank % runtime.device_count() if args.share_device else local_rank)
+    args.require_rccl = rccl_required(args, runtime.device_count(), world)
     # Multi-rank runs: RANK/LOCAL_RANK/WORLD_SIZE/MASTER_PORT come from torch.distributed.run; the
     # ranks rendezvous through a temp file and talk RCCL through the C-ABI library only.  (torch is
     # NOT imported: its wheel bundles a second ROCm runtime with the same sonames, and two HIP
@@ -899,16 +914,22 @@ def main():
     import ctypes as _C
 
     nccl_version, pci_ids = None, None
+    # [ADVICE r5] the local code is computed OUTSIDE the try block around the gather: a rank that failed to read its
+    # bus id still enters the collective (with code -1) instead of leaving the other ranks waiting in it
+    my_pci, code = None, -1.0
     try:
         buf = _C.create_string_buffer(32)
         _lib.check(lib.jxs_device_pci_bus_id(buf, 32), "jxs_device_pci_bus_id")
         my_pci = buf.value.decode()
         dom, bus, devfn = my_pci.split(":")
         dev_, fn_ = devfn.split(".")
-        code = (int(dom, 16) << 16) | (int(bus, 16) << 8) | (int(dev_, 16) << 3) | int(fn_, 16)
+        code = float((int(dom, 16) << 16) | (int(bus, 16) << 8) | (int(dev_, 16) << 3) | int(fn_, 16))
+    except Exception as e:  # reporting only
+        my_pci = repr(e)
+    try:
         if comm is not None:
-            codes = [int(c) for c in comm.all_gather_scalars(float(code))]
-            pci_ids = [f"{c >> 16:04x}:{(c >> 8) & 0xff:02x}:{(c >> 3) & 0x1f:02x}.{c & 7:x}" for c in codes]
+            codes = [int(c) for c in comm.all_gather_scalars(code)]
+            pci_ids = [f"{c >> 16:04x}:{(c >> 8) & 0xff:02x}:{(c >> 3) & 0x1f:02x}.{c & 7:x}" if c >= 0 else None for c in codes]
         else:
             pci_ids = [my_pci]
         if comm is not None and comm_error is None:

@@ -219,6 +219,29 @@ int jxs_forward_dynamics_aba(jxs_model* model, const void* state, const void* jo
                              const void* link_forces, int force_repr, void* out_acc, int N,
                              void* stream);
 
+/* [round 6] system_dynamics / system_acceleration (src/jaxsim/api/ode.py:16-131,174-225) and link_contact_forces
+ * (src/jaxsim/api/contact.py:514-603) -- what the reference's contact-model benchmarks time
+ * (tests/test_benchmark.py:103-139) -- in ONE launch: contact forces of the model's contact model (SoftContacts,
+ * RigidContacts, RelaxedRigidContacts), summed per link, plus the external `link_forces`, through ABA.  No actuation
+ * model (`joint_torques` are applied as given, api/ode.py:117-122), no integrator, no impact.
+ *   out_xdot  = [n_rows][N], the layout of the state block, every row holding the time derivative of the state row
+ *               it stands for, inertial-fixed like the state: pdot_B = v_W + w x p_B, Qdot (Quaternion.derivative of
+ *               the normalised quaternion with the Baumgarte gain `baumgarte`, api/ode.py:136-169; the reference's
+ *               default is 1.0), sdot, W_vdot_WB (linear, angular), sddot, and the rate of the tangential deformation
+ *               of the enabled points (zero for disabled points and for the rigid contact models).  May be NULL
+ *               when only the link wrenches are wanted (SoftContacts then stops before ABA).
+ *   out_link_contact_forces = [nL * 6][N] or NULL: the 6D contact wrench of every link, inertial representation
+ *               ([f; p_W x f] summed over the link's enabled points, api/contact.py:592-601), rows 6 l .. 6 l + 5.
+ * `link_forces` / `force_repr` as in jxs_step.                                                              */
+int jxs_system_dynamics(jxs_model* model, const void* state, const void* joint_torques, const void* link_forces,
+                        int force_repr, double baumgarte, void* out_xdot, void* out_link_contact_forces, int N,
+                        void* stream);
+/* link_contact_forces alone (api/contact.py:514-555): jxs_system_dynamics with out_xdot = NULL; `out_mdot`
+ * ([3 * n_points][N] or NULL) receives the `m_dot` entry of the reference's aux dictionary for SoftContacts (rows
+ * 3 c .. 3 c + 2 = point c; zeros for disabled points and for the rigid contact models).                        */
+int jxs_link_contact_forces(jxs_model* model, const void* state, const void* joint_torques, const void* link_forces,
+                            int force_repr, void* out_link_contact_forces, void* out_mdot, int N, void* stream);
+
 /* inverse_dynamics / RNEA (src/jaxsim/api/model.py:1746-1894, rbda/rnea.py:12-238) in
  * inertial representation: in_acc = [6+n][N] (base acceleration, joint accelerations) or
  * NULL (zeros => free_floating_bias_forces, :1934-1978); out = [6+n][N] = base wrench then

@@ -116,3 +116,22 @@ def inertia_to_params(M: np.ndarray):
     c = np.array([mC[2, 1], mC[0, 2], mC[1, 0]]) / m
     I = M[3:, 3:] - (mC @ mC.T / m)
     return m, c, I
+
+
+def quaternion_derivative(q: np.ndarray, omega: np.ndarray, K: float = 0.1) -> np.ndarray:
+    """``Quaternion.derivative`` with the angular velocity in the inertial frame (``src/jaxsim/math/quaternion.py:68-132``),
+    batched: ``Qdot = 1/2 Q_inertial(q) [K |w| (1 - |q|); w]``, ``q`` = wxyz."""
+    q = np.asarray(q, dtype=float)
+    w = np.asarray(omega, dtype=float)
+    qw, qx, qy, qz = q[..., 0], q[..., 1], q[..., 2], q[..., 3]
+    h0 = K * np.linalg.norm(w, axis=-1) * (1.0 - np.linalg.norm(q, axis=-1))
+    wx, wy, wz = w[..., 0], w[..., 1], w[..., 2]
+    return 0.5 * np.stack(
+        [
+            qw * h0 - qx * wx - qy * wy - qz * wz,
+            qx * h0 + qw * wx + qz * wy - qy * wz,
+            qy * h0 - qz * wx + qw * wy + qx * wz,
+            qz * h0 + qy * wx - qx * wy + qw * wz,
+        ],
+        axis=-1,
+    )

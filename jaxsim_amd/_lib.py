@@ -216,6 +216,8 @@ def _declare(lib):
         "jxs_rollout_recorded": [vp, vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, vp],
         "jxs_forward_dynamics_aba": [vp, vp, vp, vp, C.c_int, vp, C.c_int, vp],
         "jxs_inverse_dynamics": [vp, vp, vp, vp, C.c_int, vp, C.c_int, vp],
+        "jxs_system_dynamics": [vp, vp, vp, vp, C.c_int, C.c_double, vp, vp, C.c_int, vp],
+        "jxs_link_contact_forces": [vp, vp, vp, vp, C.c_int, vp, vp, C.c_int, vp],
         "jxs_gravity_torques": [vp, vp, vp, C.c_int, vp],
         "jxs_tile_from_env_major": [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp],
         "jxs_tile_to_env_major": [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp],

@@ -1,4 +1,5 @@
-"""``jaxsim.api.contact`` mirror: parameter estimation helper (host, build-time)."""
+"""``jaxsim.api.contact`` mirror: parameter estimation (host, build-time), the read-only queries on the cached
+kinematics, and -- [round 6] -- ``link_contact_forces`` (one launch of ``jxs_system_dynamics``)."""
 
 from __future__ import annotations
 
@@ -188,3 +189,44 @@ def jacobian_derivative(model: JaxSimModel, data, *, output_vel_repr=None):
             O_Xd_W = -O_X_W @ _m._vx_matrix(W_v_W_CW)
     Jd = O_Xd_W @ W_J @ T + O_X_W @ W_Jd @ T + O_X_W @ W_J @ Td
     return data._out(Jd.astype(data.dtype))
+
+
+# ---- contact forces (src/jaxsim/api/contact.py:514-603) ----------------------------------------------------------
+
+
+def link_contact_forces(model: JaxSimModel, data, *, link_forces=None, joint_torques=None):
+    """``link_contact_forces`` (``src/jaxsim/api/contact.py:514-555``): the ``[nL, 6]`` contact wrenches of the links in
+    inertial representation and the contact model's auxiliary dictionary -- ``{"m_dot": ...}`` (rate of the tangential
+    deformation of every collidable point, zero for disabled ones) for SoftContacts, ``{}`` for RigidContacts and
+    RelaxedRigidContacts, whose forces depend on ``link_forces`` (read in the representation of ``data``, like
+    ``rbda/contacts/rigid.py:268-276``) and ``joint_torques``.  One launch; SoftContacts stops before ABA."""
+    from ..state import StateLayout, unpack_state
+    from . import ode as _ode
+
+    N, nL = data.batch_size, model.number_of_links()
+    soft = _ode._is_soft(model)
+    n_cp = model.kin_dyn_parameters.number_of_collidable_points()
+    xdot, W_f = _ode.system_dynamics_device(
+        model, data, link_forces=None if soft else link_forces, joint_torques=None if soft else joint_torques,
+        force_repr=data.velocity_representation, want_derivative=soft and n_cp > 0, want_link_contact_forces=True,
+    )  # fmt: skip
+    W_f_L = W_f.to_host().T.reshape(N, nL, 6)
+    aux = {}
+    if soft:
+        md = unpack_state(StateLayout.of(model), xdot.to_host())["tangential_deformation"] if n_cp > 0 else np.zeros((N, 0, 3), dtype=data.dtype)
+        aux = {"m_dot": data._out(md)}
+    return data._out(W_f_L), aux
+
+
+def link_forces_from_contact_forces(model: JaxSimModel, *, contact_forces):
+    """``link_forces_from_contact_forces`` (``src/jaxsim/api/contact.py:558-603``): the wrenches ``[n_cp, 6]`` of the
+    enabled collidable points (world coordinates) summed per parent link, ``[nL, 6]``; batched input ``[N, n_cp, 6]``
+    gives ``[N, nL, 6]``.  (Host NumPy: the kernels do this sum in registers, ``jxs_core.h link_wrench_sums``; this is the
+    reference's stand-alone helper for forces that come from somewhere else.)"""
+    body, _ = _enabled(model)
+    W_f_C = np.asarray(contact_forces, dtype=float)
+    W_f_C = W_f_C.reshape((-1, 6)) if W_f_C.ndim <= 2 else W_f_C
+    if W_f_C.shape[-2] != len(body):
+        raise ValueError((W_f_C.shape, (len(body), 6)))
+    mask = (body[:, None] == np.arange(model.number_of_links())[None, :]).astype(W_f_C.dtype)
+    return np.einsum("cl,...cj->...lj", mask, W_f_C)

@@ -49,6 +49,8 @@ _environ = __import__("os").environ
 # os.environ.get() encodes its key and decodes the value on every call (1.1 us each -- a sixth of a step at 1024
 # environments); the mapping underneath holds both as bytes and is what os.environ[...] = ... / monkeypatch.setenv write
 _env_raw = getattr(_environ, "_data", None)
+if _env_raw is not None and not (isinstance(_env_raw, dict) and isinstance(_environ.encodekey("X"), bytes) and isinstance(_environ.encodevalue("1"), bytes)):
+    _env_raw = None  # (a platform whose os.environ keeps str underneath: the bytes comparisons below would never match)
 _K_EXC, _K_SPEC = (_environ.encodekey("JAXSIM_ENABLE_EXCEPTIONS"), _environ.encodekey("JAXSIM_AMD_SPECIALIZE")) if _env_raw is not None else (None, None)
 _TRUE = (b"1", b"true", b"on", b"yes")
 

@@ -4,7 +4,7 @@
 #   JXS_EXTRA_FLAGS=-DJXS_PHASE_TIMING JXS_OUT=libjaxsim_amd_timing.so build.sh   (developer profiling build)
 #   JXS_ONLY="float:0 float:6" build.sh   (developer: recompile only these dtype:mode units; the other
 #                                          objects of the build directory are reused)
-# The kernels of one (dtype, mode) pair are one translation unit (jxs_inst.hip); the 24 units and the C-ABI
+# The kernels of one (dtype, mode) pair are one translation unit (jxs_inst.hip); the 28 units and the C-ABI
 # file compile in parallel.
 set -euo pipefail
 cd "$(dirname "$0")"
@@ -16,7 +16,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize -mllvm -amd
 JOBS=${JXS_JOBS:-$(nproc)}
 UNITS=${JXS_ONLY:-}
 if [ -z "$UNITS" ]; then
-  for t in float double; do for m in 0 1 2 3 4 5 6 7 8 9 10 11; do UNITS="$UNITS $t:$m"; done; done
+  for t in float double; do for m in 0 1 2 3 4 5 6 7 8 9 10 11 12 13; do UNITS="$UNITS $t:$m"; done; done
   UNITS="$UNITS api"
 fi
 compile() {
@@ -33,7 +33,7 @@ compile() {
 export -f compile
 export HIPCC FLAGS OBJ
 # the slowest units first (rigid contact modes 6, 7; Runge-Kutta 5)
-ORDERED=$(for u in $UNITS; do case $u in *:7) echo "0 $u";; *:6) echo "1 $u";; *:5) echo "2 $u";; *) echo "3 $u";; esac; done | sort -s -k1,1 | cut -d' ' -f2)
+ORDERED=$(for u in $UNITS; do case $u in *:7) echo "0 $u";; *:6|*:13) echo "1 $u";; *:5) echo "2 $u";; *) echo "3 $u";; esac; done | sort -s -k1,1 | cut -d' ' -f2)
 rm -f "$OBJ/failed" "$OBJ/compile.log"
 set +e
 printf '%s\n' $ORDERED | xargs -P "$JOBS" -I{} bash -c 'compile {}' > "$OBJ/compile.log" 2>&1
@@ -44,7 +44,7 @@ if [ $RC -ne 0 ] || [ -s "$OBJ/failed" ]; then
   echo "build.sh: compilation failed (xargs rc $RC) for units: $(tr '\n' ' ' < "$OBJ/failed" 2>/dev/null)" >&2
   exit 1
 fi
-for t in float double; do for m in 0 1 2 3 4 5 6 7 8 9 10 11; do [ -f "$OBJ/inst_${t}_${m}.o" ] || { echo "missing object inst_${t}_${m}.o" >&2; exit 1; }; done; done
+for t in float double; do for m in 0 1 2 3 4 5 6 7 8 9 10 11 12 13; do [ -f "$OBJ/inst_${t}_${m}.o" ] || { echo "missing object inst_${t}_${m}.o" >&2; exit 1; }; done; done
 [ -f "$OBJ/api.o" ] || { echo "missing object api.o" >&2; exit 1; }
 "$HIPCC" --offload-arch=gfx950 -shared -fPIC "$OBJ"/api.o "$OBJ"/inst_*.o -o "$OUT" -ldl
 # [round 4] wait-state lint of the device code (jaxsim_amd/isa_lint.py): the hazards hipcc cannot pad inside asm blocks

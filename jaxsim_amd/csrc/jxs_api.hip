@@ -87,6 +87,8 @@ hipError_t launch_mode(int mode, int G, const jxs::KParams<T>& P, const unsigned
     case jxs::MODE_JAC: return launch_g<T, jxs::MODE_JAC>(G, P, mblk, A, s);
     case jxs::MODE_MINV: return launch_g<T, jxs::MODE_MINV>(G, P, mblk, A, s);
     case jxs::MODE_GRAV: return launch_g<T, jxs::MODE_GRAV>(G, P, mblk, A, s);
+    case jxs::MODE_DYN: return launch_g<T, jxs::MODE_DYN>(G, P, mblk, A, s);
+    case jxs::MODE_DYN_RIGID: return launch_g<T, jxs::MODE_DYN_RIGID>(G, P, mblk, A, s);
     default: return launch_g<T, jxs::MODE_KIN>(G, P, mblk, A, s);
   }
 }
@@ -165,7 +167,7 @@ int create_typed(const jxs_model_desc* d, std::unique_ptr<ModelT<T>>& slot) {
 template <typename T>
 int run_typed(jxs_model* model, int mode, const void* state_in, void* state_out, const void* tau,
               const void* link_f, int force_repr, const void* in_a, void* out_a, void* out_H, void* out_V, int N,
-              int repeat, void* stream, void* out_tau, bool fuse, int extra_flags, void* traj = nullptr) {
+              int repeat, void* stream, void* out_tau, bool fuse, int extra_flags, void* traj = nullptr, double fparam = 0.0) {
   ModelT<T>* mt = typed<T>(model);
   hipStream_t s = static_cast<hipStream_t>(stream);
   jxs::KArgs<T> a = mt->args(N);
@@ -185,6 +187,23 @@ int run_typed(jxs_model* model, int mode, const void* state_in, void* state_out,
     const int tile = 64 / mt->pk.G;
     const size_t elems = (size_t)((N + tile - 1) / tile) * tile * mt->pk.P.n_rows;
     JXS_HIP(hipMemcpyAsync(state_out, state_in, sizeof(T) * elems, hipMemcpyDeviceToDevice, s));
+  }
+  if (mode == jxs::MODE_DYN) {
+    if (mt->pk.P.rigid) mode = jxs::MODE_DYN_RIGID;
+    a.fparam = static_cast<T>(fparam);
+    // rows the kernel does not write: the deformation rates of disabled points, and of every point of the rigid contact
+    // models (no tangential state: their rows are passengers of the block) -- zero, like the reference's m_dot
+    if (state_out != nullptr && (mt->pk.n_disabled > 0 || (mt->pk.P.rigid && mt->pk.P.n_points > 0))) {
+      const int tile = 64 / mt->pk.G;
+      const size_t elems = (size_t)((N + tile - 1) / tile) * tile * mt->pk.P.n_rows;
+      JXS_HIP(hipMemsetAsync(state_out, 0, sizeof(T) * elems, s));
+    }
+    if (out_H != nullptr && mt->pk.P.n_chunks == 0) {  // no enabled points: the kernel has no contact phase
+      const int tile = 64 / mt->pk.G;
+      JXS_HIP(hipMemsetAsync(out_H, 0, sizeof(T) * (size_t)((N + tile - 1) / tile) * tile * mt->pk.P.nL * 6, s));
+      a.out_H = nullptr;
+      if (state_out == nullptr) return JXS_OK;
+    }
   }
   a.dbg = g_dbg;
   a.flags |= extra_flags;
@@ -272,16 +291,16 @@ int run_typed(jxs_model* model, int mode, const void* state_in, void* state_out,
 
 int run_any(jxs_model* model, int mode, const void* state_in, void* state_out, const void* tau, const void* link_f,
             int force_repr, const void* in_a, void* out_a, void* out_H, void* out_V, int N, int repeat,
-            void* stream, void* out_tau = nullptr, bool fuse = true, int extra_flags = 0, void* traj = nullptr) {
+            void* stream, void* out_tau = nullptr, bool fuse = true, int extra_flags = 0, void* traj = nullptr, double fparam = 0.0) {
   if (model == nullptr) return fail(JXS_EINVAL, "null model");
   if (state_in == nullptr) return fail(JXS_EINVAL, "null state");
   if (N <= 0) return fail(JXS_EINVAL, "N must be positive");
   if (force_repr < 0 || force_repr > 2) return fail(JXS_EINVAL, "invalid force representation");
   if (model->dtype == JXS_F64)
     return run_typed<double>(model, mode, state_in, state_out, tau, link_f, force_repr, in_a, out_a, out_H, out_V, N,
-                             repeat, stream, out_tau, fuse, extra_flags, traj);
+                             repeat, stream, out_tau, fuse, extra_flags, traj, fparam);
   return run_typed<float>(model, mode, state_in, state_out, tau, link_f, force_repr, in_a, out_a, out_H, out_V, N,
-                          repeat, stream, out_tau, fuse, extra_flags, traj);
+                          repeat, stream, out_tau, fuse, extra_flags, traj, fparam);
 }
 
 // ---- RCCL, resolved lazily so that the library loads (and the CPU symbol test passes)
@@ -769,6 +788,44 @@ int jxs_forward_dynamics_aba(jxs_model* model, const void* state, const void* jo
   if (out_acc == nullptr) return fail(JXS_EINVAL, "null out_acc");
   return run_any(model, jxs::MODE_FD, state, nullptr, joint_forces, link_forces, force_repr, nullptr, out_acc, nullptr,
                  nullptr, N, 1, stream);
+}
+int jxs_system_dynamics(jxs_model* model, const void* state, const void* joint_torques, const void* link_forces,
+                        int force_repr, double baumgarte, void* out_xdot, void* out_link_contact_forces, int N, void* stream) {
+  if (out_xdot == nullptr && out_link_contact_forces == nullptr) return fail(JXS_EINVAL, "jxs_system_dynamics: no output asked for");
+  if (out_xdot != nullptr && out_xdot == state) return fail(JXS_EINVAL, "jxs_system_dynamics: out_xdot must not alias the state");
+  return run_any(model, jxs::MODE_DYN, state, out_xdot, joint_torques, link_forces, force_repr, nullptr, nullptr,
+                 out_link_contact_forces, nullptr, N, 1, stream, nullptr, true, 0, nullptr, baumgarte);
+}
+int jxs_link_contact_forces(jxs_model* model, const void* state, const void* joint_torques, const void* link_forces,
+                            int force_repr, void* out_link_contact_forces, void* out_mdot, int N, void* stream) {
+  if (out_link_contact_forces == nullptr) return fail(JXS_EINVAL, "null out_link_contact_forces");
+  if (model == nullptr) return fail(JXS_EINVAL, "null model");
+  if (N <= 0) return fail(JXS_EINVAL, "N must be positive");
+  if (out_mdot == nullptr)
+    return run_any(model, jxs::MODE_DYN, state, nullptr, joint_torques, link_forces, force_repr, nullptr, nullptr,
+                   out_link_contact_forces, nullptr, N, 1, stream, nullptr, true, 0, nullptr, 1.0);
+  // with the deformation rates: the derivative block goes to a scratch block and its rows of m are copied out (one
+  // strided device copy; the rows of the tangential deformation are the last 3 * n_points rows of every tile)
+  jxs_layout lay;
+  jxs_model_layout(model, &lay);
+  const size_t esz = model->dtype == JXS_F64 ? 8 : 4;
+  const size_t tiles = (size_t)((N + lay.tile - 1) / lay.tile);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (lay.n_points == 0) return run_any(model, jxs::MODE_DYN, state, nullptr, joint_torques, link_forces, force_repr, nullptr, nullptr,
+                                        out_link_contact_forces, nullptr, N, 1, stream, nullptr, true, 0, nullptr, 1.0);
+  void* xdot = nullptr;
+  JXS_HIP(hipMalloc(&xdot, tiles * lay.tile * lay.n_rows * esz));
+  int rc = run_any(model, jxs::MODE_DYN, state, xdot, joint_torques, link_forces, force_repr, nullptr, nullptr,
+                   out_link_contact_forces, nullptr, N, 1, stream, nullptr, true, 0, nullptr, 1.0);
+  if (rc == JXS_OK) {
+    const size_t mrows = 3 * (size_t)lay.n_points;
+    const hipError_t e = hipMemcpy2DAsync(out_mdot, esz * lay.tile * mrows, static_cast<const char*>(xdot) + esz * lay.tile * lay.row_m,
+                                          esz * lay.tile * lay.n_rows, esz * lay.tile * mrows, tiles, hipMemcpyDeviceToDevice, s);
+    if (e != hipSuccess) rc = hip_fail(e, "hipMemcpy2DAsync");
+  }
+  (void)hipStreamSynchronize(s);  // the scratch block is freed below
+  (void)hipFree(xdot);
+  return rc;
 }
 int jxs_inverse_dynamics(jxs_model* model, const void* state, const void* in_acc, const void* link_forces,
                          int force_repr, void* out_forces, int N, void* stream) {

@@ -150,8 +150,11 @@ struct Core {
     static_assert(ROLE == ROLE_SOLO || (ROLE == ROLE_MAIN && MODE == MODE_STEP), "two-wave workgroups: single step only");
     constexpr int kArea = (ROLE == ROLE_MAIN) ? duo_main_off(G) : 0;  // LDS area of this wave (words)
     constexpr bool kRK4 = (MODE == MODE_STEP_RK4 || MODE == MODE_STEP_RK4_RIGID);
-    constexpr bool kRigid = (MODE == MODE_STEP_RIGID || MODE == MODE_STEP_RK4_RIGID);
-    constexpr bool kStep = (MODE == MODE_STEP || MODE == MODE_ROLLOUT || kRK4 || kRigid);
+    // [round 6] system_dynamics / link_contact_forces (api/ode.py:16-225, api/contact.py:514-603): the step without the
+    // actuation model and without the integrator; the derivative of the state and the link contact wrenches are the outputs
+    constexpr bool kDyn = (MODE == MODE_DYN || MODE == MODE_DYN_RIGID);
+    constexpr bool kRigid = (MODE == MODE_STEP_RIGID || MODE == MODE_STEP_RK4_RIGID || MODE == MODE_DYN_RIGID);
+    constexpr bool kStep = (MODE == MODE_STEP || MODE == MODE_ROLLOUT || kRK4 || kRigid || kDyn);
     const VI lane = ln.lane();
     ln.stamp(A, 0);
     ln.stamp_hwid(A, 11);
@@ -368,7 +371,7 @@ struct Core {
     // and the articulated inertias at the new state for the impact (rbda/contacts/rigid.py:391-446).
     // RigidContacts appends one more pass over the new state for the impact (kImpactStage).
     constexpr int kImpactStage = kRK4 ? 4 : 1;
-    constexpr int n_stages = kRigid ? kImpactStage + 1 : (kRK4 ? 4 : 1);
+    constexpr int n_stages = kDyn ? 1 : (kRigid ? kImpactStage + 1 : (kRK4 ? 4 : 1));
     V x0s, x0sd, x0q[4], x0p[3], x0v[3], x0w[3], x0m[3];  // stage-0 state (quaternion normalised)
     V ks, ksd, kq[4], kp[3], kv[3], kw[3], km[3];           // weighted sum of the stage derivatives
     V xfl[3], xfa[3];                                       // external link wrench in the stage-0 frame C
@@ -579,6 +582,23 @@ struct Core {
     }
 
     // ---- J,K,L,I: soft contacts ----------------------------------------------------------
+    // MODE_DYN*: the contact wrench of every link is an output (api/contact.py:514-603): summed on its own (about the
+    // link's anchor, in C), then added to the external wrench
+    V dcfl[3] = {V(T(0)), V(T(0)), V(T(0))}, dcfa[3] = {V(T(0)), V(T(0)), V(T(0))};
+    V* const cacc_l = kDyn ? dcfl : fl;
+    V* const cacc_a = kDyn ? dcfa : fa;
+    // inertial wrench [f; mu_C + (ra + p_B) x f] of the link of this lane, rows 6 * link ... of KArgs::out_H
+    auto store_link_contact_wrenches = [&]() {
+      V arm[3] = {ra[0] + pB[0], ra[1] + pB[1], ra[2] + pB[2]}, t[3];
+      cross(arm, dcfl, t);
+      const VM is_link = level >= 0;
+      const VI lrow = vsel(lnk >= 0, lnk, lane * 0) * 6;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        ln.gstore(A.out_H, lrow + k, dcfl[k], is_link, P.nL * 6);
+        ln.gstore(A.out_H, lrow + (3 + k), dcfa[k] + t[k], is_link, P.nL * 6);
+      }
+    };
     if (with_contacts && m_by_lane && !kRK4 && it == 0 && stage == 0) place_m();
     if (with_contacts && with_rows && P.n_chunks == 1) {
       // The kinematics of the parent links reach the point lanes through the LDS scratch of the
@@ -624,9 +644,15 @@ struct Core {
       point_physics(valid, ps0.Lp, m, Rb, rb, vbl, vba, rab, pB, doff, vBc, om, w6, mdl);
 #pragma unroll
       for (int k = 0; k < 3; ++k) ps0.md[k] = mdl[k];
-      link_wrench_sums(lane, ps0.tail, ps0.hd, w6, fl, fa);
+      link_wrench_sums(lane, ps0.tail, ps0.hd, w6, cacc_l, cacc_a);
     } else
-    if (with_contacts) contacts<kRK4>(lane, ps0, R, r, vl, va, ra, pB, doff, vBc, om, fl, fa, stage);  // sets ps0.md
+    if (with_contacts) contacts<kRK4, kDyn>(lane, ps0, R, r, vl, va, ra, pB, doff, vBc, om, cacc_l, cacc_a, stage);  // sets ps0.md
+    if constexpr (kDyn && !kRigid) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) fl[k] = fl[k] + dcfl[k], fa[k] = fa[k] + dcfa[k];
+      if (A.out_H != nullptr) store_link_contact_wrenches();
+      if (A.state_out == nullptr) return;  // js.contact.link_contact_forces alone: the accelerations are not asked for
+    }
     ln.stamp(A, 5);  // contacts
 
     // ---- B: joint torques (api/actuation_model.py:7-126): once per step, from the state the step starts from (stage 0
@@ -645,7 +671,7 @@ struct Core {
         // loop "tau = g(q); step(tau)" of BASELINE config 5 in ONE launch (the kinematics are in registers anyway)
         if (A.flags & 2) tau = tau + vsel(is_joint, gravity_tq(level, child, R, r, cL, mass, Sl, Sa), V(T(0)));
       }
-      if (kStep) {
+      if (kStep && !kDyn) {  // (system_dynamics takes the joint torques as they are: api/ode.py:117-122)
         const V lower = vmin(s - smin, V(T(0)));  // clip(max=0)
         const V upper = vmax(s - smax, V(T(0)));  // clip(min=0)
         V tau_pl = -(klim * (lower + upper));
@@ -997,6 +1023,10 @@ struct Core {
               for (int k = 0; k < 3; ++k) xcfl[k] = cfl[k], xcfa[k] = cfa[k];
             }
           }
+          if constexpr (kDyn) {
+  #pragma unroll
+            for (int k = 0; k < 3; ++k) dcfl[k] = cfl[k], dcfa[k] = cfa[k];
+          }
           V pAr[1][6], ar[1][6], sddr[1];
   #pragma unroll
           for (int k = 0; k < 3; ++k) pAr[0][k] = -cfl[k], pAr[0][3 + k] = -cfa[k];
@@ -1038,7 +1068,29 @@ struct Core {
       return;
     }
 
-    if (kRigid && stage == kImpactStage) {
+    if constexpr (kDyn) {
+      // ---- the outputs of system_dynamics (api/ode.py:174-225), inertial-fixed: position derivatives of
+      // system_position_dynamics (:134-171: pdot_B = v_W + w x p_B, Qdot with the caller's Baumgarte gain, sdot) and the
+      // accelerations above, written in the layout of the state block (row of x -> d x / dt) -------------------------------
+      if (kRigid && A.out_H != nullptr) store_link_contact_wrenches();  // (the rigid models refer their wrenches to the origin of C: ra = 0)
+      if (A.state_out != nullptr) {
+        V dq[4], t[3];
+        quat_derivative(q, om, A.fparam, dq);
+        cross(aca, pB, t);
+        s = sd, sd = sdd;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) q[k] = dq[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          pB[k] = vBc[k];
+          vW[k] = acl[k] - t[k];
+          om[k] = aca[k];
+          if (with_contacts) ps0.m[k] = ps0.md[k];
+        }
+        write_state(A.state_out, 0, P.n_rows);
+      }
+      return;
+    } else if (kRigid && stage == kImpactStage) {
       // impact stage: the velocities were reset above, nothing to integrate
     } else if (!kRK4) {
     // ---- C: semi-implicit Euler (api/integrators.py:14-88) ---------------------------------
@@ -2367,7 +2419,7 @@ struct Core {
   // state m0 + dt/6 * (k1 + 2 k2 + 2 k3 + k4) is stored at the last stage (api/integrators.py:91-167).  The rate of
   // the previous stage and the weighted sum live in the LDS, eight words per slot (`sc`: word offset of this lane's
   // slot), touched by the slot's own lane only -- no synchronisation beyond program order.
-  template <bool kFirst, bool kStages = false>
+  template <bool kFirst, bool kStages = false, bool kRates = false>
   JXS_HD void contact_chunk(const VI& lane, PointSlot& ps, const V* R, const V* r, const V* vl, const V* va,
                             const V* ra, const V* pB, const V* doff, const V* vBc, const V* om, V* fl, V* fa,
                             int stage = 0, const VI* sc = nullptr) const {
@@ -2414,13 +2466,15 @@ struct Core {
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       if (kFirst) ps.md[k] = md[k];
-      else ln.gstore(A.state_out, ps.prow * 3 + (P.row_m + k), m[k] + P.dt * md[k], valid, P.n_rows);
+      else if (kRates) {  // MODE_DYN: the rate itself is the output (row of m -> mdot), where the derivative block is asked for
+        if (A.state_out != nullptr) ln.gstore(A.state_out, ps.prow * 3 + (P.row_m + k), md[k], valid, P.n_rows);
+      } else ln.gstore(A.state_out, ps.prow * 3 + (P.row_m + k), m[k] + P.dt * md[k], valid, P.n_rows);
     }
     }
     link_wrench_sums(lane, ps.tail, ps.hd, w6, fl, fa);
   }
 
-  template <bool kStages = false>
+  template <bool kStages = false, bool kRates = false>
   JXS_HD void contacts(const VI& lane, PointSlot& ps0, const V* R, const V* r, const V* vl, const V* va,
                        const V* ra, const V* pB, const V* doff, const V* vBc, const V* om, V* fl, V* fa, int stage = 0) const {
     contact_chunk<true>(lane, ps0, R, r, vl, va, ra, pB, doff, vBc, om, fl, fa);  // sets ps0.md
@@ -2429,7 +2483,7 @@ struct Core {
       load_slot_tables(lane, ch, ps);
       load_slot_state(ps);
       const VI sc = (lane + (ch - 1) * G) * kRk4SlotWords + rk4_chunk_off(G);
-      contact_chunk<false, kStages>(lane, ps, R, r, vl, va, ra, pB, doff, vBc, om, fl, fa, stage, &sc);
+      contact_chunk<false, kStages, kRates>(lane, ps, R, r, vl, va, ra, pB, doff, vBc, om, fl, fa, stage, &sc);
     }
   }
 

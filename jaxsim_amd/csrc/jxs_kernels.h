@@ -30,6 +30,7 @@ struct KTail {
   long long* dbg;
   int* faults;
   int flags;
+  T fparam;
 };
 
 // OCC2 (rigid contact modes only): compiled for two waves per SIMD (at most 256 registers; a few values go
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(64, VARIANT == KV_OCC2 ? 2 : JXS_MIN_WAVES) void jx
   A.rti = reinterpret_cast<const int*>(pre_mblk + jxs::mblk_off_rti<T>(G));
   A.chunks = pre_mblk + jxs::mblk_off_chunks<T>(G);
   A.in_a = tail.in_a, A.out_a = tail.out_a, A.out_H = tail.out_H, A.out_V = tail.out_V, A.out_tau = tail.out_tau;
-  A.id_zero_vel = tail.id_zero_vel, A.dbg = tail.dbg, A.faults = tail.faults, A.flags = tail.flags;
+  A.id_zero_vel = tail.id_zero_vel, A.dbg = tail.dbg, A.faults = tail.faults, A.flags = tail.flags, A.fparam = tail.fparam;
   if constexpr (VARIANT == KV_OCC2) A.flags |= 1;  // two waves per SIMD: 256 registers, no room for MFMA accumulator tiles
   // the state-block rows of SURVEY section 8(a) row D, derived from the preloaded joint count instead of loaded
   P.n_rows = pre_n_rows, P.n = pre_n;
@@ -91,10 +92,10 @@ __global__ __launch_bounds__(64, VARIANT == KV_OCC2 ? 2 : JXS_MIN_WAVES) void jx
 #else
   A.spec_consts = 0;
 #endif
-  A.has_lds = (kFlagsKnown && P.row_mode && (MODE == jxs::MODE_STEP || MODE == jxs::MODE_ROLLOUT || MODE == jxs::MODE_FD || MODE == jxs::MODE_STEP_RK4)) ? 1 : 0;
+  A.has_lds = (kFlagsKnown && P.row_mode && (MODE == jxs::MODE_STEP || MODE == jxs::MODE_ROLLOUT || MODE == jxs::MODE_FD || MODE == jxs::MODE_STEP_RK4 || MODE == jxs::MODE_DYN)) ? 1 : 0;
   extern __shared__ __align__(16) unsigned char jxs_smem[];
   const jxs::DeviceLanes<T, G> ln(A.N, reinterpret_cast<T*>(jxs_smem),
-                                  (MODE == jxs::MODE_STEP_RIGID || MODE == jxs::MODE_STEP_RK4_RIGID) ? jxs::rigid_lds_words_per_env(P.n_cp, P.rigid, P.ct_tree, P.n_chunks, G)
+                                  (MODE == jxs::MODE_STEP_RIGID || MODE == jxs::MODE_STEP_RK4_RIGID || MODE == jxs::MODE_DYN_RIGID) ? jxs::rigid_lds_words_per_env(P.n_cp, P.rigid, P.ct_tree, P.n_chunks, G)
                                   : MODE == jxs::MODE_STEP_RK4 ? jxs::rk4_lds_words_per_env(G, P.n_chunks)
                                                                : jxs::lds_words_per_env(G));
   jxs::Core<jxs::DeviceLanes<T, G>> core(P, A, ln);
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(256, 1) void jxs_kernel_duo(const T* pre_state_in, 
   A.rti = reinterpret_cast<const int*>(pre_mblk + jxs::mblk_off_rti<T>(G));
   A.chunks = pre_mblk + jxs::mblk_off_chunks<T>(G);
   A.in_a = tail.in_a, A.out_a = tail.out_a, A.out_H = tail.out_H, A.out_V = tail.out_V, A.out_tau = tail.out_tau;
-  A.id_zero_vel = tail.id_zero_vel, A.dbg = tail.dbg, A.faults = tail.faults, A.flags = tail.flags;
+  A.id_zero_vel = tail.id_zero_vel, A.dbg = tail.dbg, A.faults = tail.faults, A.flags = tail.flags, A.fparam = tail.fparam;
   P.n_rows = pre_n_rows, P.n = pre_n;
   P.row_pos = 0, P.row_quat = 3, P.row_s = 7, P.row_vlin = 7 + pre_n, P.row_vang = 10 + pre_n, P.row_sd = 13 + pre_n;
   P.row_m = 13 + 2 * pre_n;
@@ -152,15 +153,15 @@ hipError_t launch_one(const jxs::KParams<T>& P, const unsigned char* mblk, const
   const int envs_per_wave = 64 / G;  // = the tile of every batched array: block b owns tile b
   const int blocks = (A.N + envs_per_wave - 1) / envs_per_wave;
   const bool rows = P.row_mode && (MODE == jxs::MODE_STEP || MODE == jxs::MODE_ROLLOUT || MODE == jxs::MODE_FD ||
-                                   MODE == jxs::MODE_STEP_RK4);
+                                   MODE == jxs::MODE_STEP_RK4 || MODE == jxs::MODE_DYN);
   size_t lds_bytes = rows ? sizeof(T) * (size_t)envs_per_wave * jxs::lds_words_per_env(G) : 0;
   // RungeKutta4 with several point chunks keeps its per-slot stage data in the LDS (jxs_params.h rk4_lds_words_per_env)
   if (MODE == jxs::MODE_STEP_RK4 && P.n_chunks > 1) lds_bytes = sizeof(T) * (size_t)envs_per_wave * jxs::rk4_lds_words_per_env(G, P.n_chunks);
   // (developer knobs arrive in A.knobs: the library reads the environment once, jxs_api.hip debug_knobs -- no getenv on the
   // launch path, no race with a Python thread that edits os.environ)
   const KTail<T> tail{A.in_a, A.out_a, A.out_H, A.out_V, A.out_tau, A.id_zero_vel, A.dbg, A.faults,
-                      A.flags | ((A.knobs & jxs::KNOB_NO_MFMA) ? 1 : 0)};  // KNOB_NO_MFMA: A/B of the vector path of the contact solvers' Cholesky
-  if (MODE == jxs::MODE_STEP_RIGID || MODE == jxs::MODE_STEP_RK4_RIGID) {
+                      A.flags | ((A.knobs & jxs::KNOB_NO_MFMA) ? 1 : 0), A.fparam};  // KNOB_NO_MFMA: A/B of the vector path of the contact solvers' Cholesky
+  if (MODE == jxs::MODE_STEP_RIGID || MODE == jxs::MODE_STEP_RK4_RIGID || MODE == jxs::MODE_DYN_RIGID) {
     lds_bytes = sizeof(T) * (size_t)envs_per_wave * jxs::rigid_lds_words_per_env(P.n_cp, P.rigid, P.ct_tree, P.n_chunks, G);
     if (lds_bytes > 64 * 1024) {  // beyond the default dynamic-LDS window (gfx950 has 160 KiB per CU)
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&jxs_kernel<T, G, MODE>),

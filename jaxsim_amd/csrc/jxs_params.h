@@ -206,10 +206,16 @@ enum Mode : int {
   MODE_CRBA = 8,  // free_floating_mass_matrix: composite-rigid-body algorithm  rbda/crba.py:10-170, api/model.py:1553-1590
   MODE_JAC = 9,   // doubly-left full Jacobian and its derivative  rbda/jacobian.py:128-339
   MODE_MINV = 10,  // free_floating_mass_matrix_inverse  rbda/mass_inverse.py:11-233, api/model.py:1593-1631
-  MODE_GRAV = 11   // joint torques of free_floating_gravity_forces (RNEA at zero velocity and acceleration,
+  MODE_GRAV = 11,  // joint torques of free_floating_gravity_forces (RNEA at zero velocity and acceleration,
                    // api/model.py:1897-1931): a dedicated kernel -- kinematics, subtree sums of the link weights, S . f
+  // [round 6] js.ode.system_dynamics / system_acceleration (api/ode.py:16-131,174-225) and js.contact.link_contact_forces
+  // (api/contact.py:514-603): the step up to -- not including -- the actuation model and the integrator.  Writes the
+  // state DERIVATIVE in the layout of the state block (KArgs::state_out: pdot_B, Qdot, sdot, W_vdot_WB, sddot, mdot) and,
+  // on request, the inertial 6D contact wrench of every link (KArgs::out_H, [nL * 6][N]).
+  MODE_DYN = 12,        // SoftContacts / no collidable points
+  MODE_DYN_RIGID = 13   // RigidContacts / RelaxedRigidContacts (contact forces solved like stage 0 of the step, no impact)
 };
-constexpr int kNumModes = 12;
+constexpr int kNumModes = 14;
 
 enum ForceRepr : int { REPR_INERTIAL = 0, REPR_BODY = 1, REPR_MIXED = 2 };  // api/common.py:39-47
 
@@ -313,7 +319,7 @@ struct KArgs {
   int force_repr;      // ForceRepr of link_f
   const T* in_a;       // MODE_ID: [6+n][N] inertial base acceleration + joint accelerations, or null
   T* out_a;            // MODE_FD: [6+n][N] ; MODE_ID: [6+n][N] (base wrench, joint torques)
-  T* out_H;            // MODE_KIN: [nL*12][N] rows of [R|p] per link (row-major 3x4)
+  T* out_H;            // MODE_KIN: [nL*12][N] rows of [R|p] per link (row-major 3x4); MODE_DYN*: [nL*6][N] inertial link contact wrenches, or null
   T* out_V;            // MODE_KIN: [nL*6][N] inertial-fixed link velocities
   int N;               // batch size (leading dimension of every [row][N] array)
   int n_steps;         // MODE_STEP: consecutive steps fused in this launch (state carried in registers)
@@ -328,6 +334,7 @@ struct KArgs {
   int knobs;           // host only: developer knobs of the launcher (KNOB_*), read from the environment ONCE by the
                        // library (jxs_api.hip debug_knobs; jxs_debug_reload_env re-reads them for the tests)
   int duo_max_blocks;  // host only: largest grid the two-wave variant is used for (JXS_DUO_MAX_BLOCKS)
+  T fparam;            // MODE_DYN / MODE_DYN_RIGID: Baumgarte gain of the quaternion derivative (api/ode.py:136-169; default 1.0)
   int has_lds;         // the launch has the per-environment LDS area of the row layout (known when the wave starts: a
                        // compile-time constant in the specialised / common-feature kernels): the thirteen
                        // environment-uniform rows of the state are fetched by ONE load instruction and spread through it

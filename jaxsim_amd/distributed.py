@@ -238,6 +238,18 @@ def all_gather_state_blocks_host(local_block: np.ndarray) -> np.ndarray:
     return concat_shards(np.stack([o.numpy() for o in outs], axis=0))
 
 
+def untile_gathered_on_device(gathered: runtime.DeviceArray, rows: int, n_total: int, tile: int) -> np.ndarray:
+    """The storage of an all-gather of whole-tile shards, read as the tiled ``[rows][n_total]`` array it is: untiled by
+    the device kernel behind ``jxs_tile_to_env_major`` and returned as a host ``[rows, n_total]`` array."""
+    env_major = runtime.DeviceArray(1, rows * n_total, gathered.dtype, tile=1)
+    _lib.check(
+        _lib.load().jxs_tile_to_env_major(C.c_void_p(gathered.ptr), C.c_void_p(env_major.ptr), int(rows), int(n_total), int(tile),
+                                          _lib.dtype_code(gathered.dtype), runtime._sp()),
+        "jxs_tile_to_env_major",
+    )  # fmt: skip
+    return np.ascontiguousarray(env_major.to_host_raw().reshape(n_total, rows).T)
+
+
 def all_gather_state(comm: Communicator, data) -> np.ndarray:
     """GPU path of the final concat: RCCL all-gather of the device state, returned on the
     host as one ``[rows, N_total]`` block (every rank gets the full batch)."""
@@ -251,5 +263,10 @@ def all_gather_state(comm: Communicator, data) -> np.ndarray:
         raise _lib.JaxsimAmdError(f"all_gather_state needs equal shards, got {cols.astype(int).tolist()} environments per rank; "
                                   "pad the batch to a multiple of the world size")
     gathered = comm.all_gather(st)  # storage: [world][n_tiles][rows][tile]
+    if st.cols % st.tile == 0:
+        # [round 6] whole tiles per rank: the gathered storage IS the tiled storage of a [rows][world * cols] array, rank
+        # r's environments at columns r * cols ... -- untiled ON THE DEVICE (jxs_tile_to_env_major) into [N_total][rows]
+        # and downloaded once; the host only takes a transposed view (round 5 untiled every rank's block on the host)
+        return untile_gathered_on_device(gathered, st.rows, st.cols * comm.world_size, st.tile)
     raw = gathered.to_host_raw().reshape(comm.world_size, -1)
     return concat_shards(np.stack([untile_block(raw[r], st.rows, st.cols, st.tile) for r in range(comm.world_size)]))

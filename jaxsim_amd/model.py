@@ -32,7 +32,7 @@ class VelRepr(enum.IntEnum):
     Mixed = 2
 
 
-@dataclasses.dataclass
+@dataclasses.dataclass(frozen=True)
 class SoftContactsParams:
     """``SoftContactsParams`` (``src/jaxsim/rbda/contacts/soft.py:24-123``)."""
 
@@ -74,7 +74,7 @@ class SoftContactsParams:
         return cls.build(K=stiffness, D=damping, mu=static_friction_coefficient, p=p, q=q)
 
 
-@dataclasses.dataclass
+@dataclasses.dataclass(frozen=True)
 class ActuationParams:
     """``ActuationParams`` (``src/jaxsim/rbda/actuation/common.py:10-19``)."""
 
@@ -84,7 +84,7 @@ class ActuationParams:
     enable_friction: bool = True
 
 
-@dataclasses.dataclass
+@dataclasses.dataclass(frozen=True)
 class FlatTerrain:
     """``FlatTerrain`` (``src/jaxsim/terrain/terrain.py:65-124``): constant height, normal +z."""
 
@@ -103,7 +103,7 @@ class FlatTerrain:
         return n
 
 
-@dataclasses.dataclass
+@dataclasses.dataclass(frozen=True)
 class PlaneTerrain(FlatTerrain):
     """``PlaneTerrain`` (``src/jaxsim/terrain/terrain.py:127-238``): plane ``A x + B y + C z + D = 0``
     with unit normal ``(A, B, C)`` and height ``-D / C`` over the origin."""
@@ -140,7 +140,7 @@ class SoftContacts:
         return cls()
 
 
-@dataclasses.dataclass
+@dataclasses.dataclass(frozen=True)
 class RigidContactsParams:
     """``RigidContactsParams`` (``src/jaxsim/rbda/contacts/rigid.py:28-98``): friction coefficient
     and the Baumgarte gains of the contact constraint (both 0 by default)."""
@@ -183,7 +183,7 @@ class RigidContacts:
         return {"solver_tol": self.solver_tol}
 
 
-@dataclasses.dataclass
+@dataclasses.dataclass(frozen=True)
 class RelaxedRigidContactsParams:
     """``RelaxedRigidContactsParams`` (``src/jaxsim/rbda/contacts/relaxed_rigid.py:29-75``).  ``K`` and
     ``D`` are accepted and stored like in the reference, where they do not influence the forces

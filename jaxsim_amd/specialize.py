@@ -153,7 +153,10 @@ def compile_text(text: str, *, force: bool = False) -> pathlib.Path:
 
 
 def _compile_locked(text: str, fields: dict, assign: str, out: pathlib.Path) -> pathlib.Path:
-    tmp = out.with_suffix(f".tmp{os.getpid()}.so")
+    import threading
+
+    # (unique per builder: two threads of one process may build the same object -- the lock file of a finished build is unlinked)
+    tmp = out.with_suffix(f".tmp{os.getpid()}_{threading.get_ident()}.so")
     cmd = [_HIPCC, *_flags(), f"-DJXS_SPEC_T={fields['T']}", f"-DJXS_SPEC_G={fields['G']}", f"-DJXS_SPEC_MODE={fields['MODE']}",
            f"-DJXS_SPEC_ASSIGN={assign}", f'-DJXS_SPEC_STRING="{text}"', "jxs_spec.hip", "-o", str(tmp)]  # fmt: skip
     # (JAXSIM_AMD_SPEC_CSRC, developer aid of tools/gpu/*.sh: the kernel sources of another directory -- a copy of an earlier

@@ -60,6 +60,8 @@ void run_group(const jxs::Packed<T>& pk, jxs::KArgs<T> a, int mode) {
       case jxs::MODE_JAC: core.template run<jxs::MODE_JAC>(); break;
       case jxs::MODE_MINV: core.template run<jxs::MODE_MINV>(); break;
       case jxs::MODE_GRAV: core.template run<jxs::MODE_GRAV>(); break;
+      case jxs::MODE_DYN: core.template run<jxs::MODE_DYN>(); break;
+      case jxs::MODE_DYN_RIGID: core.template run<jxs::MODE_DYN_RIGID>(); break;
       default: core.template run<jxs::MODE_KIN>(); break;
     }
   }
@@ -111,6 +113,11 @@ int run_typed(const jxs_model_desc* d, int mode, const void* state_in, void* sta
       g_err = "the two-wave variant does not apply to this model";
       return JXS_EINVAL;
     }
+  }
+  if (mode == jxs::MODE_DYN) {  // like the library (jxs_api.hip run_typed)
+    if (pk.P.rigid) mode = jxs::MODE_DYN_RIGID;
+    a.fparam = T(1);  // (the harness has no argument for the Baumgarte gain: the reference's default)
+    if (pk.P.n_chunks == 0) a.out_H = nullptr;  // (the caller's buffer is zero-initialised)
   }
   const bool rk4 = (mode == jxs::MODE_STEP && pk.integrator == JXS_INTEGRATOR_RUNGE_KUTTA4);
   if (rk4) mode = pk.P.rigid ? jxs::MODE_STEP_RK4_RIGID : jxs::MODE_STEP_RK4;

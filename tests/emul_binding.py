@@ -21,6 +21,7 @@ _SRC = _HERE / "emul" / "jxs_emul.cpp"
 _SO = _HERE / "emul" / "libjxs_emul.so"
 _ROOT = _HERE.parent
 MODE_STEP, MODE_FD, MODE_ID, MODE_KIN, MODE_CRBA, MODE_JAC, MODE_MINV, MODE_GRAV = 0, 1, 2, 3, 8, 9, 10, 11
+MODE_DYN = 12  # system_dynamics / link_contact_forces (the harness picks MODE_DYN_RIGID for the rigid contact models, like the library)
 MODE_STEP_DUO = MODE_STEP | 0x100  # the two-wave workgroup variant of the step kernel (inertia wave, then main wave)
 
 
@@ -101,12 +102,14 @@ def run(model, mode, state, *, tau=None, link_forces=None, force_repr=0, in_acc=
 
     st, tau, link_forces, in_acc = up(state), up(tau), up(link_forces), up(in_acc)
     state_out = st.copy() if mode in (MODE_STEP, MODE_STEP_DUO) else None
+    if mode == MODE_DYN:  # the derivative block (rows the kernel does not write stay zero, like the library's memset)
+        state_out = alloc(rows_state)
     out_a = alloc(6 + n) if mode in (MODE_FD, MODE_ID, MODE_GRAV) else (alloc((6 + n) ** 2) if mode in (MODE_CRBA, MODE_MINV) else None)
     if mode == MODE_JAC:
         out_a = alloc(12 * (6 + n))
     if record:
         out_a = alloc(int(n_steps) * rows_state)
-    out_H = alloc(nL * 12) if mode in (MODE_KIN, MODE_JAC) else None
+    out_H = alloc(nL * 12) if mode in (MODE_KIN, MODE_JAC) else (alloc(nL * 6) if mode == MODE_DYN else None)
     out_V = alloc(nL * 6) if mode == MODE_KIN else None
     rc = lib().jxs_emul_run(
         C.byref(d), mode | (0x200 if tau_seq else 0) | (0x400 if record else 0), _p(st), _p(state_out), _p(tau), _p(link_forces), int(force_repr), _p(in_acc),
@@ -118,6 +121,8 @@ def run(model, mode, state, *, tau=None, link_forces=None, force_repr=0, in_acc=
         return untile_block(state_out, rows_state, N, tile), untile_block(out_a, int(n_steps) * rows_state, N, tile).reshape(int(n_steps), rows_state, N)
     if mode in (MODE_STEP, MODE_STEP_DUO):
         return untile_block(state_out, rows_state, N, tile)
+    if mode == MODE_DYN:  # (state derivative [rows, N], inertial link contact wrenches [nL * 6, N])
+        return untile_block(state_out, rows_state, N, tile), untile_block(out_H, nL * 6, N, tile)
     if mode == MODE_KIN:
         return untile_block(out_H, nL * 12, N, tile), untile_block(out_V, nL * 6, N, tile)
     if mode in (MODE_CRBA, MODE_MINV):
