@@ -101,6 +101,18 @@ typedef struct jxs_model_desc {
   /* JXS_CONTACT_RELAXED_RIGID: RelaxedRigidContactsParams (rbda/contacts/relaxed_rigid.py:29-75); mu above is
      its friction coefficient, K and D are ignored exactly as the reference ignores them (:567-568) */
   double rr_time_constant, rr_damping_coefficient, rr_d_min, rr_d_max, rr_width, rr_midpoint, rr_power;
+  /* [round 6] Height-field terrain: the reference's generic `Terrain` (terrain/terrain.py:15-62: any height(x, y), the
+     normal by central differences with delta = 0.01) in the form a C ABI can carry -- heights sampled on a regular
+     grid, sample [ix][iy] at (origin + (ix dx, iy dy)), row-major with x outer; height(x, y) is the BILINEAR
+     interpolant (clamped to the border samples outside the grid) and the normal is
+     n = [(h(x-d,y) - h(x+d,y)) / 2d, (h(x,y-d) - h(x,y+d)) / 2d, 1] / |.| of THAT function, d = terrain_delta
+     (terrain.py:52-62).  NULL: the flat / plane terrain above.  With a grid `terrain_height` / `terrain_normal` are
+     not used.  All three contact models.                                                                           */
+  const double* terrain_grid;     /* [terrain_nx][terrain_ny] or NULL                                               */
+  int32_t terrain_nx, terrain_ny; /* >= 2 each                                                                      */
+  double terrain_origin[2];       /* (x, y) of sample [0][0]                                                        */
+  double terrain_spacing[2];      /* (dx, dy), both > 0                                                             */
+  double terrain_delta;           /* step of the central difference (Terrain.delta = 0.010, terrain.py:23); 0 = 0.01 */
 } jxs_model_desc;
 
 typedef struct jxs_model jxs_model; /* opaque, immutable after creation, shareable */

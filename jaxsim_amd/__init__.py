@@ -7,6 +7,7 @@ kernels (``jaxsim_amd/csrc``, ``include/jaxsim_amd.h``).  No PyTorch, no JAX.
 from .model import (  # noqa: F401
     ActuationParams,
     FlatTerrain,
+    HeightFieldTerrain,
     IntegratorType,
     JaxSimModel,
     PlaneTerrain,

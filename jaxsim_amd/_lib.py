@@ -71,6 +71,12 @@ class ModelDesc(C.Structure):
         ("rr_width", C.c_double),
         ("rr_midpoint", C.c_double),
         ("rr_power", C.c_double),
+        ("terrain_grid", C.POINTER(C.c_double)),
+        ("terrain_nx", C.c_int32),
+        ("terrain_ny", C.c_int32),
+        ("terrain_origin", C.c_double * 2),
+        ("terrain_spacing", C.c_double * 2),
+        ("terrain_delta", C.c_double),
     ]
 
 
@@ -145,6 +151,13 @@ def make_desc(model, dtype) -> tuple[ModelDesc, list]:
     d.K, d.D, d.mu = float(cp.K), float(cp.D), float(cp.mu)
     d.p, d.q = float(getattr(cp, "p", 0.5)), float(getattr(cp, "q", 0.5))  # RigidContactsParams has no exponents
     d.terrain_height = float(model.terrain._height)
+    grid = getattr(model.terrain, "_heights", None)
+    if grid is not None:  # HeightFieldTerrain: heights[ix, iy], x outer
+        d.terrain_grid = dptr(grid, (grid.size,))
+        d.terrain_nx, d.terrain_ny = int(grid.shape[0]), int(grid.shape[1])
+        d.terrain_origin = (C.c_double * 2)(*[float(v) for v in model.terrain._origin])
+        d.terrain_spacing = (C.c_double * 2)(*[float(v) for v in model.terrain._spacing])
+        d.terrain_delta = float(model.terrain.delta)
     ap = model.actuation_params
     d.torque_max, d.omega_th, d.omega_max = float(ap.torque_max), float(ap.omega_th), float(ap.omega_max)
     d.enable_friction = int(bool(ap.enable_friction))
@@ -175,6 +188,9 @@ def model_signature(model, dtype) -> tuple:
         type(model.contact_model).__name__, getattr(model.contact_model, "regularization_delassus", None),
         getattr(model.contact_model, "solver_tol", None),
         tuple(getattr(cp, k, None) for k in ("time_constant", "damping_coefficient", "d_min", "d_max", "width", "midpoint", "power")),
+        # height-field terrain: the (read-only) sample array by identity, its placement by value
+        (id(getattr(model.terrain, "_heights", None)), getattr(model.terrain, "_origin", None), getattr(model.terrain, "_spacing", None),
+         getattr(model.terrain, "delta", None)) if getattr(model.terrain, "_heights", None) is not None else None,
     )  # fmt: skip
 
 

@@ -156,14 +156,14 @@ def specialize(model: JaxSimModel, dtype=np.float32, *, queries: bool = False) -
     """Build (hipcc, seconds) and attach the step / rollout kernels specialised on this model's kinematic tree --
     the counterpart of the reference compiling ``step`` per model under ``jax.jit`` (api/model.py:36-120 static
     fields).  Physical parameters stay run-time data.  ``queries=True`` does the same for the kernels behind
-    ``forward_dynamics_aba``, ``inverse_dynamics``, the cached kinematics, the mass matrix, its inverse and the
-    Jacobians.  ``JAXSIM_AMD_SPECIALIZE=1`` specialises the step kernels of every model on first use."""
+    ``forward_dynamics_aba``, ``inverse_dynamics``, the cached kinematics, the mass matrix, its inverse, the
+    Jacobians and ``js.ode.system_dynamics``.  ``JAXSIM_AMD_SPECIALIZE=1`` specialises the step kernels of every model on first use."""
     from .. import specialize as _sp
 
     dm = runtime.device_model(model, np.dtype(dtype))
     done = _sp.attach(dm, model, build=True)
     if queries:
-        done = _sp.attach(dm, model, _sp.QUERY_MODES, build=True) or done
+        done = _sp.attach(dm, model, _sp.QUERY_MODES + (_sp.dyn_mode_of(model),), build=True) or done
     return done
 
 

@@ -46,6 +46,11 @@ def system_dynamics_device(
     st = data._state
     dtype, N = st.dtype, st.cols
     dm = _m._device_model_fast(model, dtype)
+    if "_dyn_mode" not in dm.__dict__:  # first call: the model-specialised kernel of this mode, following specialize.policy()
+        from .. import specialize as _sp
+
+        dm.__dict__["_dyn_mode"] = _sp.dyn_mode_of(model)
+        _sp.ensure_mode(dm, model, dm.__dict__["_dyn_mode"])
     if _m._exceptions_enabled():
         _m._check_quaternion(model, data, normalized=False)  # ABA receives data.base_orientation (normalised)
     nL, n = model.number_of_links(), model.dofs()
@@ -97,9 +102,10 @@ def system_acceleration(model: JaxSimModel, data: JaxSimModelData, *, link_force
         fields = unpack_state(StateLayout.of(model), xdot.to_host())
         W_vd = np.concatenate([fields["base_linear_velocity"], fields["base_angular_velocity"]], -1)
         return data._out(W_vd), data._out(fields["joint_velocities"]), _contact_state_of(model, data, fields)
+    # (the derivative block is only needed for the deformation rates of SoftContacts; without it that model stops before ABA)
     xdot, W_f = system_dynamics_device(model, data, link_forces=link_forces, joint_torques=joint_torques, force_repr=rep,
-                                       want_link_contact_forces=True)  # fmt: skip
-    fields = unpack_state(StateLayout.of(model), xdot.to_host())
+                                       want_derivative=_is_soft(model), want_link_contact_forces=True)  # fmt: skip
+    fields = unpack_state(StateLayout.of(model), xdot.to_host()) if xdot is not None else None
     W_f_L = W_f.to_host().T.reshape(N, nL, 6).astype(np.float64)
     f_L = np.zeros((N, nL, 6)) if link_forces is None else np.broadcast_to(np.asarray(_host_link_forces(link_forces, N, nL), np.float64), (N, nL, 6))
     vd, sdd = _m.forward_dynamics_aba(model, data, joint_forces=joint_torques, link_forces=f_L + W_f_L)

@@ -2291,6 +2291,42 @@ struct Core {
     }
   }
 
+  // ---- terrain (rbda/contacts/common.py:25-63, terrain/terrain.py:15-238) --------------------------------------------
+  // [round 6] Height field: the bilinear interpolant of the samples hf[ix * ny + iy] at (x0 + ix dx, y0 + iy dy), clamped to
+  // the border samples outside the grid.  Four gathers per evaluation from the model block (L2-resident).
+  JXS_HD V hf_height(const V& x, const V& y) const {
+    const V zero = V(T(0)), one = V(T(1));
+    const V fx = vmin(vmax((x - P.hf_x0) * P.hf_idx, zero), V(T(P.hf_nx - 1)));
+    const V fy = vmin(vmax((y - P.hf_y0) * P.hf_idy, zero), V(T(P.hf_ny - 1)));
+    // cell index: floor, with the last sample belonging to the last cell (t = 1 there)
+    const VI ix = L::to_int(vmin(fx, V(T(P.hf_nx - 2)))), iy = L::to_int(vmin(fy, V(T(P.hf_ny - 2))));
+    const V tx = fx - L::to_real(ix), ty = fy - L::to_real(iy);
+    const VI b = ix * P.hf_ny + iy;
+    const V h00 = ln.tgather(A.hf, b), h01 = ln.tgather(A.hf, b + 1);
+    const V h10 = ln.tgather(A.hf, b + P.hf_ny), h11 = ln.tgather(A.hf, b + (P.hf_ny + 1));
+    const V a = h00 + (h01 - h00) * ty, c = h10 + (h11 - h10) * ty;
+    (void)one;
+    return a + (c - a) * tx;
+  }
+  // Unit normal n at the point's (x, y) and h . n with h = [0, 0, height(x, y) - z] (the penetration depth is its
+  // positive part) for the terrains that are not flat: PlaneTerrain (constant normal, terrain.py:127-238) and the height
+  // field, whose normal is the reference's central difference of the height function (terrain.py:40-62).
+  JXS_HD void terrain_normal_and_depth(const V* pw, V* nh, V& hn) const {
+    if (P.hf) {
+      const V d = V(P.hf_delta);
+      const V hxp = hf_height(pw[0] + d, pw[1]), hxm = hf_height(pw[0] - d, pw[1]);
+      const V hyp = hf_height(pw[0], pw[1] + d), hym = hf_height(pw[0], pw[1] - d);
+      const V nx = (hxm - hxp) * P.hf_inv_2delta, ny = (hym - hyp) * P.hf_inv_2delta;
+      const V inv = vrsqrt(nx * nx + ny * ny + V(T(1)));
+      nh[0] = nx * inv, nh[1] = ny * inv, nh[2] = inv;
+      hn = (hf_height(pw[0], pw[1]) - pw[2]) * nh[2];
+    } else {
+      nh[0] = V(P.nrm[0]), nh[1] = V(P.nrm[1]), nh[2] = V(P.nrm[2]);
+      const V height = V(P.terrain_h) - (P.nrm[0] * pw[0] + P.nrm[1] * pw[1]) * (T(1) / P.nrm[2]);
+      hn = (height - pw[2]) * P.nrm[2];
+    }
+  }
+
   // Kinematics, penetration and Hunt-Crossley force of one collidable point per lane, given the
   // kinematics (Rb, rb, vbl, vba) of its parent link in frame C: the wrench w6 in C and the rate md of
   // the tangential deformation (rbda/collidable_points.py:9-65, rbda/contacts/common.py:25-63,
@@ -2332,9 +2368,9 @@ struct Core {
       pdn = pd[2];
       mdn = m[2];
     } else {
-      nh[0] = V(P.nrm[0]), nh[1] = V(P.nrm[1]), nh[2] = V(P.nrm[2]);
-      const V height = V(P.terrain_h) - (P.nrm[0] * pw[0] + P.nrm[1] * pw[1]) * (T(1) / P.nrm[2]);
-      delta = vmax(zero, (height - pw[2]) * P.nrm[2]);
+      V hn;
+      terrain_normal_and_depth(pw, nh, hn);
+      delta = vmax(zero, hn);
       pdn = pd[0] * nh[0] + pd[1] * nh[1] + pd[2] * nh[2];
       mdn = m[0] * nh[0] + m[1] * nh[1] + m[2] * nh[2];
     }

@@ -67,6 +67,7 @@ __global__ __launch_bounds__(64, VARIANT == KV_OCC2 ? 2 : JXS_MIN_WAVES) void jx
   A.lti = reinterpret_cast<const int*>(pre_mblk + jxs::mblk_off_lti<T>(G));
   A.rti = reinterpret_cast<const int*>(pre_mblk + jxs::mblk_off_rti<T>(G));
   A.chunks = pre_mblk + jxs::mblk_off_chunks<T>(G);
+  A.hf = reinterpret_cast<const T*>(pre_mblk + P.hf_off);
   A.in_a = tail.in_a, A.out_a = tail.out_a, A.out_H = tail.out_H, A.out_V = tail.out_V, A.out_tau = tail.out_tau;
   A.id_zero_vel = tail.id_zero_vel, A.dbg = tail.dbg, A.faults = tail.faults, A.flags = tail.flags, A.fparam = tail.fparam;
   if constexpr (VARIANT == KV_OCC2) A.flags |= 1;  // two waves per SIMD: 256 registers, no room for MFMA accumulator tiles
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(64, VARIANT == KV_OCC2 ? 2 : JXS_MIN_WAVES) void jx
   P.row_m = 13 + 2 * pre_n;
   if constexpr (VARIANT == KV_COMMON) {
     P.floating = 1, P.any_suc = 0, P.seg_dpp_ok = 1, P.row_mode = 1, P.flat = 1, P.pq_half = 1, P.anchored = 1, P.rigid = 0;
-    P.rk4fast = 0, P.n_chunks = 1;
+    P.rk4fast = 0, P.n_chunks = 1, P.hf = 0;
   }
 #ifdef JXS_SPEC_ASSIGN
   // model-specialised build (jxs_spec.hip): the integer model flags are compile-time constants from here on
@@ -121,6 +122,7 @@ __global__ __launch_bounds__(256, 1) void jxs_kernel_duo(const T* pre_state_in, 
   A.lti = reinterpret_cast<const int*>(pre_mblk + jxs::mblk_off_lti<T>(G));
   A.rti = reinterpret_cast<const int*>(pre_mblk + jxs::mblk_off_rti<T>(G));
   A.chunks = pre_mblk + jxs::mblk_off_chunks<T>(G);
+  A.hf = reinterpret_cast<const T*>(pre_mblk + P.hf_off);
   A.in_a = tail.in_a, A.out_a = tail.out_a, A.out_H = tail.out_H, A.out_V = tail.out_V, A.out_tau = tail.out_tau;
   A.id_zero_vel = tail.id_zero_vel, A.dbg = tail.dbg, A.faults = tail.faults, A.flags = tail.flags, A.fparam = tail.fparam;
   P.n_rows = pre_n_rows, P.n = pre_n;
@@ -210,7 +212,7 @@ hipError_t launch_one(const jxs::KParams<T>& P, const unsigned char* mblk, const
 #ifndef JXS_SPEC_ASSIGN  // (a model-specialised build has these constants anyway)
   constexpr bool kHasCommon = (MODE == jxs::MODE_STEP || MODE == jxs::MODE_ROLLOUT) && G >= 8;
   const bool common_off = (A.knobs & jxs::KNOB_NO_COMMON_VARIANT) != 0;  // developer knob: A/B against KV_GENERIC
-  if (kHasCommon && !common_off && P.floating == 1 && P.any_suc == 0 && P.seg_dpp_ok == 1 && P.row_mode == 1 && P.flat == 1 && P.pq_half == 1 &&
+  if (kHasCommon && !common_off && P.floating == 1 && P.any_suc == 0 && P.seg_dpp_ok == 1 && P.row_mode == 1 && P.flat == 1 && P.hf == 0 && P.pq_half == 1 &&
       P.anchored == 1 && P.rigid == 0 && P.rk4fast == 0 && P.n_chunks == 1) {
     hipLaunchKernelGGL((jxs_kernel<T, G, MODE, kHasCommon ? KV_COMMON : KV_GENERIC>), dim3(blocks), dim3(64), lds_bytes, s, A.state_in,
                        A.state_out, mblk, A.tau, A.link_f, A.N, P.n_rows, P.n, A.force_repr, A.n_steps, tail);

@@ -384,20 +384,20 @@ struct DeviceLanes {
     static_assert(N >= 1 && N <= 6 && K >= 0 && K < 16, "fmac_row_bcast: one to six values, lane 0..15 of the row");
 #define JXS_FB(i) "v_fmac_f32_dpp %" #i ", %" #i ", %[m] row_newbcast:%[k] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
     if constexpr (N == 1)
-      asm volatile(JXS_FB(0) : "+v"(x[0]) : [m] "v"(m), [k] "n"(K));
+      asm volatile(JXS_FB(0) : "+&v"(x[0]) : [m] "v"(m), [k] "n"(K));
     else if constexpr (N == 2)
-      asm volatile(JXS_FB(0) JXS_FB(1) : "+v"(x[0]), "+v"(x[1]) : [m] "v"(m), [k] "n"(K));
+      asm volatile(JXS_FB(0) JXS_FB(1) : "+&v"(x[0]), "+&v"(x[1]) : [m] "v"(m), [k] "n"(K));
     else if constexpr (N == 3)
-      asm volatile(JXS_FB(0) JXS_FB(1) JXS_FB(2) : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]) : [m] "v"(m), [k] "n"(K));
+      asm volatile(JXS_FB(0) JXS_FB(1) JXS_FB(2) : "+&v"(x[0]), "+&v"(x[1]), "+&v"(x[2]) : [m] "v"(m), [k] "n"(K));
     else if constexpr (N == 4)
       asm volatile(JXS_FB(0) JXS_FB(1) JXS_FB(2) JXS_FB(3)
-                   : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]) : [m] "v"(m), [k] "n"(K));
+                   : "+&v"(x[0]), "+&v"(x[1]), "+&v"(x[2]), "+&v"(x[3]) : [m] "v"(m), [k] "n"(K));
     else if constexpr (N == 5)
       asm volatile(JXS_FB(0) JXS_FB(1) JXS_FB(2) JXS_FB(3) JXS_FB(4)
-                   : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]) : [m] "v"(m), [k] "n"(K));
+                   : "+&v"(x[0]), "+&v"(x[1]), "+&v"(x[2]), "+&v"(x[3]), "+&v"(x[4]) : [m] "v"(m), [k] "n"(K));
     else
       asm volatile(JXS_FB(0) JXS_FB(1) JXS_FB(2) JXS_FB(3) JXS_FB(4) JXS_FB(5)
-                   : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]) : [m] "v"(m), [k] "n"(K));
+                   : "+&v"(x[0]), "+&v"(x[1]), "+&v"(x[2]), "+&v"(x[3]), "+&v"(x[4]), "+&v"(x[5]) : [m] "v"(m), [k] "n"(K));
 #undef JXS_FB
   }
   template <int K, int N>
@@ -417,7 +417,7 @@ struct DeviceLanes {
     static_assert(OFF >= 1 && OFF <= 15, "row shift");
 #define JXS_S6(i) "v_fmac_f32_dpp %" #i ", %" #i ", %[m] row_shl:%[off] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
     asm volatile("s_nop 1\n\t" JXS_S6(0) JXS_S6(1) JXS_S6(2) JXS_S6(3) JXS_S6(4) JXS_S6(5)
-                 : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5])
+                 : "+&v"(w[0]), "+&v"(w[1]), "+&v"(w[2]), "+&v"(w[3]), "+&v"(w[4]), "+&v"(w[5])
                  : [m] "v"(m), [off] "n"(OFF));
 #undef JXS_S6
   }
@@ -436,15 +436,15 @@ struct DeviceLanes {
 #define JXS_RS(i, j) "v_fmac_f32_dpp %" #i ", %" #j ", %[m] row_shl:%[off] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
     if constexpr (N == 3)
       asm volatile("s_nop 1\n\t" JXS_RS(0, 3) JXS_RS(1, 4) JXS_RS(2, 5)
-                   : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]) : "v"(x[0]), "v"(x[1]), "v"(x[2]), [m] "v"(m), [off] "n"(OFF));
+                   : "+&v"(a[0]), "+&v"(a[1]), "+&v"(a[2]) : "v"(x[0]), "v"(x[1]), "v"(x[2]), [m] "v"(m), [off] "n"(OFF));
     else if constexpr (N == 6)
       asm volatile("s_nop 1\n\t" JXS_RS(0, 6) JXS_RS(1, 7) JXS_RS(2, 8) JXS_RS(3, 9) JXS_RS(4, 10) JXS_RS(5, 11)
-                   : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5])
+                   : "+&v"(a[0]), "+&v"(a[1]), "+&v"(a[2]), "+&v"(a[3]), "+&v"(a[4]), "+&v"(a[5])
                    : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), [m] "v"(m), [off] "n"(OFF));
     else
       asm volatile("s_nop 1\n\t" JXS_RS(0, 9) JXS_RS(1, 10) JXS_RS(2, 11) JXS_RS(3, 12) JXS_RS(4, 13) JXS_RS(5, 14) JXS_RS(6, 15)
                    JXS_RS(7, 16) JXS_RS(8, 17)
-                   : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8])
+                   : "+&v"(a[0]), "+&v"(a[1]), "+&v"(a[2]), "+&v"(a[3]), "+&v"(a[4]), "+&v"(a[5]), "+&v"(a[6]), "+&v"(a[7]), "+&v"(a[8])
                    : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]), "v"(x[8]), [m] "v"(m),
                      [off] "n"(OFF));
 #undef JXS_RS
@@ -474,6 +474,10 @@ struct DeviceLanes {
   // acc[k] += x[k](lane+1) * m for 9 values: nine v_fmac_f32_dpp in one asm block.  hipcc does not
   // fuse mov_dpp + fma itself; inside an asm block it does not see the "VALU write -> DPP read"
   // hazard either, hence the leading s_nop 1 (2 wait states) -- operands are not rewritten inside.
+  // [round 6] Every in/out operand of the multi-instruction blocks of this file is EARLY-CLOBBER ("+&v"): with a plain
+  // "+v" the compiler may give an input that it knows to hold the same VALUE as the input half of an in/out operand
+  // (two zeros, say) the same register -- and the first instruction of the block then overwrites the input of the
+  // second.  Found by the ISA lint in the MODE_DYN_RIGID kernels (v_fmac_f32_dpp v8, v8, v2 ... v_fmac_f32_dpp v10, v8, v2).
   // `active`: the lanes that take part -- a lane that does not is not written, and reads as 0 from its neighbour
   // (bound_ctrl).  The callers switch the LAST lane of every environment off: its lane + 1 is the base link of the
   // NEXT environment, and 0 x (a non-finite value of a diverged neighbour) is not 0.
@@ -489,7 +493,7 @@ struct DeviceLanes {
         "v_fmac_f32_dpp %6, %15, %18 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
         "v_fmac_f32_dpp %7, %16, %18 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
         "v_fmac_f32_dpp %8, %17, %18 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
-        : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8])
+        : "+&v"(a[0]), "+&v"(a[1]), "+&v"(a[2]), "+&v"(a[3]), "+&v"(a[4]), "+&v"(a[5]), "+&v"(a[6]), "+&v"(a[7]), "+&v"(a[8])
         : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]), "v"(x[8]), "v"(m));
   }
   // six values (a spatial force): the sweeps of the rigid contact models hand the first child's share to its parent
@@ -502,7 +506,7 @@ struct DeviceLanes {
         "v_fmac_f32_dpp %3, %9, %12 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
         "v_fmac_f32_dpp %4, %10, %12 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
         "v_fmac_f32_dpp %5, %11, %12 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
-        : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5])
+        : "+&v"(a[0]), "+&v"(a[1]), "+&v"(a[2]), "+&v"(a[3]), "+&v"(a[4]), "+&v"(a[5])
         : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(m));
   }
   __device__ __forceinline__ void fmac6_from_next(double* a, const double* x, double m, bool active) const {
@@ -534,7 +538,7 @@ struct DeviceLanes {
                  "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
                  "s_nop 1\n\t"
                  "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1"
-                 : "+v"(x));
+                 : "+&v"(x));
     return x;
   }
   // seven independent 8-lane reductions advanced stage by stage: consecutive DPP instructions never read a
@@ -553,7 +557,7 @@ struct DeviceLanes {
     // one block: the stages follow each other without further wait states (a value is read six instructions
     // after it was written); only the first DPP needs the s_nop behind the VALU that produced its source
     asm volatile("s_nop 1\n\t" JXS_DPP7("quad_perm:[1,0,3,2]") JXS_DPP7("quad_perm:[2,3,0,1]") JXS_DPP7("row_half_mirror")
-                 : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]));
+                 : "+&v"(x[0]), "+&v"(x[1]), "+&v"(x[2]), "+&v"(x[3]), "+&v"(x[4]), "+&v"(x[5]), "+&v"(x[6]));
 #undef JXS_DPP7
   }
   // two independent 8-lane reductions, stage by stage (d = S.U and S.pA of a tree level)
@@ -563,7 +567,7 @@ struct DeviceLanes {
   "v_add_f32_dpp %1, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
     // (two values: each stage reads what its predecessor wrote one instruction earlier -- one wait state more)
     asm volatile("s_nop 1\n\t" JXS_DPP2("quad_perm:[1,0,3,2]") "s_nop 0\n\t" JXS_DPP2("quad_perm:[2,3,0,1]") "s_nop 0\n\t" JXS_DPP2("row_half_mirror")
-                 : "+v"(x[0]), "+v"(x[1]));
+                 : "+&v"(x[0]), "+&v"(x[1]));
 #undef JXS_DPP2
   }
   __device__ __forceinline__ void allreduce8x2(double* x) const {
@@ -577,7 +581,7 @@ struct DeviceLanes {
   "v_add_f32_dpp %1, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
   "v_add_f32_dpp %2, %2, %2 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
     asm volatile("s_nop 1\n\t" JXS_DPP3("quad_perm:[1,0,3,2]") JXS_DPP3("quad_perm:[2,3,0,1]") JXS_DPP3("row_half_mirror")
-                 : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]));
+                 : "+&v"(x[0]), "+&v"(x[1]), "+&v"(x[2]));
 #undef JXS_DPP3
   }
   __device__ __forceinline__ void allreduce8x3(double* x) const {
@@ -599,7 +603,7 @@ struct DeviceLanes {
 #define JXS_A7_B1(i, X) "v_fmac_f32_dpp %" #i ", %" #X ", %[c1] quad_perm:[0,1,2,3] row_mask:0xf bank_mask:0xa\n\t"
 #define JXS_A7_B2(i, X) "v_fmac_f32_dpp %" #i ", %" #X ", %[c2] quad_perm:[2,0,2,3] row_mask:0xf bank_mask:0xa\n\t"
     asm volatile("s_nop 1\n\t" JXS_A7(JXS_A7_SHR) JXS_A7(JXS_A7_A1) JXS_A7(JXS_A7_A2) JXS_A7(JXS_A7_B1) JXS_A7(JXS_A7_B2)
-                 : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "=&v"(X0), "=&v"(X1), "=&v"(X2),
+                 : "+&v"(x[0]), "+&v"(x[1]), "+&v"(x[2]), "+&v"(x[3]), "+&v"(x[4]), "+&v"(x[5]), "+&v"(x[6]), "=&v"(X0), "=&v"(X1), "=&v"(X2),
                    "=&v"(X3), "=&v"(X4), "=&v"(X5), "=&v"(X6)
                  : [c1] "v"(c1), [c2] "v"(c2));
 #undef JXS_A7
@@ -624,7 +628,7 @@ struct DeviceLanes {
   __device__ __forceinline__ void fmac7_from_next_slot(float* acc, const float* x, float m) const {
 #define JXS_P8(i, j) "v_fmac_f32_dpp %" #i ", %" #j ", %[m] row_shl:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
     asm volatile("s_nop 1\n\t" JXS_P8(0, 7) JXS_P8(1, 8) JXS_P8(2, 9) JXS_P8(3, 10) JXS_P8(4, 11) JXS_P8(5, 12) JXS_P8(6, 13)
-                 : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6])
+                 : "+&v"(acc[0]), "+&v"(acc[1]), "+&v"(acc[2]), "+&v"(acc[3]), "+&v"(acc[4]), "+&v"(acc[5]), "+&v"(acc[6])
                  : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), [m] "v"(m));
 #undef JXS_P8
   }
@@ -643,7 +647,7 @@ struct DeviceLanes {
                  JXS_R1(3, "u", "3,3,3,3", "0x5") JXS_R1(4, "u", "0,0,0,0", "0xa") JXS_R1(5, "u", "1,1,1,1", "0xa")
                  JXS_R1(0, "mir", "3,3,3,3", "0xa") JXS_R1(1, "mir", "2,2,2,2", "0xa") JXS_R1(2, "mir", "1,1,1,1", "0xa")
                  JXS_R1(3, "mir", "0,0,0,0", "0xa") JXS_R1(4, "mir", "3,3,3,3", "0x5") JXS_R1(5, "mir", "2,2,2,2", "0x5")
-                 : "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3]), "+v"(m[4]), "+v"(m[5]), [mir] "=&v"(mir)
+                 : "+&v"(m[0]), "+&v"(m[1]), "+&v"(m[2]), "+&v"(m[3]), "+&v"(m[4]), "+&v"(m[5]), [mir] "=&v"(mir)
                  : [u] "v"(u), [s] "v"(s));
 #undef JXS_R1
   }
@@ -666,7 +670,7 @@ struct DeviceLanes {
   "v_add_f32_dpp %4, %4, %4 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                           \
   "v_add_f32_dpp %5, %5, %5 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
     asm volatile("s_nop 1\n\t" JXS_DPP6("quad_perm:[1,0,3,2]") JXS_DPP6("quad_perm:[2,3,0,1]") JXS_DPP6("row_half_mirror")
-                 : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]));
+                 : "+&v"(x[0]), "+&v"(x[1]), "+&v"(x[2]), "+&v"(x[3]), "+&v"(x[4]), "+&v"(x[5]));
 #undef JXS_DPP6
   }
   __device__ __forceinline__ void allreduce8x6(double* x) const {
@@ -931,6 +935,8 @@ struct DeviceLanes {
     return rti_unpack((unsigned)al16(tbl)[lane_ * kRtiPackWords + rti_word(field)], field);
   }
   __device__ __forceinline__ VI hconsti(const int* head, int chunk) const { return head[chunk * G + lane_]; }
+  // one element of a table in device memory per lane, by a per-lane index (height-field samples: L2-resident)
+  __device__ __forceinline__ V tgather(const T* tbl, int idx) const { return tbl[idx]; }
   // per-slot point tables (slot-major, stride 4)
   __device__ __forceinline__ V ploadf(const T* tbl, int field, int slot) const { return al16(tbl)[slot * kPtStride + field]; }
   __device__ __forceinline__ VI ploadi(const int* tbl, int field, int slot) const { return al16(tbl)[slot * kPtStride + field]; }

@@ -28,9 +28,12 @@ struct Packed {
   std::vector<int> head;  // [chunks][G]
   std::vector<unsigned char> chunks;  // point-chunk records (jxs_params.h)
   std::vector<int> rti;
-  // the device model block (jxs_params.h): KParams | ltf | lti | rti | chunks
+  std::vector<T> hf;      // [hf_nx][hf_ny] height-field samples (empty: flat / plane terrain)
+  // the device model block (jxs_params.h): KParams | ltf | lti | rti | chunks | height field (16-byte aligned, KParams::hf_off)
+  static int hf_offset(int G_, size_t chunk_bytes_) { return (int)(((size_t)mblk_off_chunks<T>(G_) + chunk_bytes_ + 15) / 16 * 16); }
   std::vector<unsigned char> block() const {
-    std::vector<unsigned char> b((size_t)mblk_off_chunks<T>(G) + chunks.size(), 0);
+    std::vector<unsigned char> b((size_t)hf_offset(G, chunks.size()) + hf.size() * sizeof(T), 0);
+    if (!hf.empty()) std::memcpy(b.data() + hf_offset(G, chunks.size()), hf.data(), hf.size() * sizeof(T));
     std::memcpy(b.data(), &P, sizeof(P));
     std::memcpy(b.data() + mblk_off_ltf<T>(), ltf.data(), ltf.size() * sizeof(T));
     std::memcpy(b.data() + mblk_off_lti<T>(G), lti_packed.data(), lti_packed.size() * sizeof(int));
@@ -64,7 +67,7 @@ std::string kernel_spec_string(const Packed<T>& pk, int mode) {
     std::snprintf(nm, sizeof nm, "maxch_nib[%d]", k);
     add(nm, P.maxch_nib[k], true);
   }
-  add("flat", P.flat), add("enable_friction", P.enable_friction), add("pq_half", P.pq_half), add("anchored", P.anchored);
+  add("flat", P.flat), add("hf", P.hf), add("enable_friction", P.enable_friction), add("pq_half", P.pq_half), add("anchored", P.anchored);
   add("rigid", P.rigid), add("n_cp", P.n_cp), add("rg_merge", P.rg_merge), add("rr_refine", P.rr_refine), add("rk4fast", P.rk4fast);
   add("jump_pad", P.jump_pad), add("jrow_seq", P.jrow_seq), add("prow_seq", P.prow_seq);
   add("ct_tree", P.ct_tree), add("qp_warm", P.qp_warm);
@@ -338,6 +341,23 @@ std::string pack_model(const jxs_model_desc& d, Packed<T>& out) {
   P.terrain_h = (T)d.terrain_height;
   for (int k = 0; k < 3; ++k) P.nrm[k] = (T)d.terrain_normal[k];
   P.flat = (d.terrain_normal[0] == 0.0 && d.terrain_normal[1] == 0.0 && d.terrain_normal[2] == 1.0) ? 1 : 0;
+  P.hf = 0, P.hf_nx = 0, P.hf_ny = 0, P.hf_off = 0;
+  P.hf_x0 = P.hf_y0 = P.hf_idx = P.hf_idy = T(0), P.hf_delta = T(0.01), P.hf_inv_2delta = T(50);
+  if (d.terrain_grid != nullptr) {  // [round 6] height-field terrain
+    if (d.terrain_nx < 2 || d.terrain_ny < 2) return "terrain_grid needs at least 2 x 2 samples";
+    if ((long long)d.terrain_nx * d.terrain_ny > (1ll << 24)) return "terrain_grid is limited to 2^24 samples";
+    if (!(d.terrain_spacing[0] > 0.0) || !(d.terrain_spacing[1] > 0.0)) return "terrain_spacing must be positive";
+    const double delta = d.terrain_delta > 0.0 ? d.terrain_delta : 0.01;
+    P.hf = 1, P.flat = 0, P.hf_nx = d.terrain_nx, P.hf_ny = d.terrain_ny;
+    P.hf_x0 = (T)d.terrain_origin[0], P.hf_y0 = (T)d.terrain_origin[1];
+    P.hf_idx = (T)(1.0 / d.terrain_spacing[0]), P.hf_idy = (T)(1.0 / d.terrain_spacing[1]);
+    P.hf_delta = (T)delta, P.hf_inv_2delta = (T)(1.0 / (2.0 * delta));
+    out.hf.resize((size_t)d.terrain_nx * d.terrain_ny);
+    for (size_t i = 0; i < out.hf.size(); ++i) {
+      if (!std::isfinite(d.terrain_grid[i])) return "terrain_grid holds a non-finite height";
+      out.hf[i] = (T)d.terrain_grid[i];
+    }
+  }
   P.tau_max = (T)d.torque_max;
   P.w_th = (T)d.omega_th;
   P.w_max = (T)d.omega_max;
@@ -677,6 +697,7 @@ std::string pack_model(const jxs_model_desc& d, Packed<T>& out) {
   while ((1 << seg_steps) < max_seg) ++seg_steps;
   P.seg_steps = seg_steps;
   P.seg_dpp_ok = seg_dpp;
+  P.hf_off = Packed<T>::hf_offset(G, out.chunks.size());  // (always a valid offset: the kernels form the pointer unconditionally)
   if (std::getenv("JXS_PRINT_PARAMS") != nullptr)  // developer aid: the wave-uniform flags the kernels branch on
     std::fprintf(stderr, "jxs params: G=%d nL=%d n=%d n_chunks=%d seg_steps=%d n_rounds=%d max_depth=%d floating=%d any_suc=%d row_mode=%d "
                  "cross=0x%x ppull=0x%x pulls=0x%x seg_dpp_ok=%d flat=%d friction=%d anchored=%d nonadj=0x%llx pq_half=%d\n",

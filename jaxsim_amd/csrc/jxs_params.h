@@ -263,6 +263,12 @@ struct KParams {
   T terrain_h;                   // terrain height over the origin       terrain/terrain.py:65-238
   T nrm[3];                      // PlaneTerrain unit normal (0,0,1 for FlatTerrain)
   int flat;                      // normal == +z: specialised contact arithmetic
+  // [round 6] height-field terrain (include/jaxsim_amd.h jxs_model_desc::terrain_grid; reference: the generic Terrain of
+  // terrain/terrain.py:15-62): heights hf[ix * hf_ny + iy] (KArgs::hf, behind the point chunks in the model block)
+  int hf;                        // 1: the terrain is a height field (flat = 0 then)
+  int hf_nx, hf_ny, hf_off;      // samples per axis; byte offset of the samples in the model block
+  T hf_x0, hf_y0, hf_idx, hf_idy;  // origin, 1 / spacing
+  T hf_delta, hf_inv_2delta;     // central-difference step of the normal (Terrain.delta = 0.010) and 1 / (2 delta)
   T tau_max, w_th, w_max;        // ActuationParams                      rbda/actuation/common.py:16-19
   T inv_w_range;                 // 1 / (w_max - w_th)
   int enable_friction;
@@ -334,6 +340,7 @@ struct KArgs {
   int knobs;           // host only: developer knobs of the launcher (KNOB_*), read from the environment ONCE by the
                        // library (jxs_api.hip debug_knobs; jxs_debug_reload_env re-reads them for the tests)
   int duo_max_blocks;  // host only: largest grid the two-wave variant is used for (JXS_DUO_MAX_BLOCKS)
+  const T* hf;         // height-field samples [hf_nx][hf_ny] (model block + KParams::hf_off), or null
   T fparam;            // MODE_DYN / MODE_DYN_RIGID: Baumgarte gain of the quaternion derivative (api/ode.py:136-169; default 1.0)
   int has_lds;         // the launch has the per-environment LDS area of the row layout (known when the wave starts: a
                        // compile-time constant in the specialised / common-feature kernels): the thirteen

@@ -130,6 +130,65 @@ class PlaneTerrain(FlatTerrain):
         return np.asarray(-(A * np.asarray(x) + B * np.asarray(y) + D) / Cc, dtype=float)
 
 
+@dataclasses.dataclass(frozen=True, eq=False)
+class HeightFieldTerrain:
+    """[round 6] The reference's generic ``Terrain`` (``src/jaxsim/terrain/terrain.py:15-62``: any ``height(x, y)``, the
+    normal by central differences with ``delta = 0.010``) in the form the C-ABI can carry: heights sampled on a regular
+    grid -- ``heights[ix, iy]`` at ``origin + (ix dx, iy dy)`` -- with ``height(x, y)`` the BILINEAR interpolant (clamped
+    to the border samples outside the grid) and ``normal(x, y)`` the reference's central difference of that function.
+    A user of the reference who subclasses ``Terrain`` samples their ``height`` onto a grid fine enough for their
+    terrain; between samples the two agree to the interpolation error, at the samples exactly."""
+
+    _heights: np.ndarray = None
+    _origin: tuple = (0.0, 0.0)
+    _spacing: tuple = (1.0, 1.0)
+    delta: float = 0.010  # Terrain.delta (terrain.py:23)
+
+    @staticmethod
+    def build(heights, *, origin=(0.0, 0.0), spacing=(1.0, 1.0), delta: float = 0.010) -> "HeightFieldTerrain":
+        h = np.array(heights, dtype=np.float64)
+        if h.ndim != 2 or min(h.shape) < 2:
+            raise ValueError(f"Expected a 2D grid of at least 2 x 2 heights, got '{h.shape}'.")
+        if not np.all(np.isfinite(h)):
+            raise ValueError("The height field contains non-finite values.")
+        sp = tuple(float(v) for v in np.broadcast_to(np.asarray(spacing, dtype=float), (2,)))
+        if not (sp[0] > 0 and sp[1] > 0):
+            raise ValueError("The grid spacing must be positive.")
+        h.setflags(write=False)  # (frozen like every other model constant: a changed terrain is a new object)
+        return HeightFieldTerrain(_heights=h, _origin=tuple(float(v) for v in origin), _spacing=sp, delta=float(delta))
+
+    @staticmethod
+    def from_function(height_fn, *, x_range, y_range, spacing, delta: float = 0.010) -> "HeightFieldTerrain":
+        """Sample ``height_fn(x, y)`` (vectorised over NumPy arrays) on the grid covering the two ranges."""
+        sp = tuple(float(v) for v in np.broadcast_to(np.asarray(spacing, dtype=float), (2,)))
+        nx = int(np.ceil((x_range[1] - x_range[0]) / sp[0])) + 1
+        ny = int(np.ceil((y_range[1] - y_range[0]) / sp[1])) + 1
+        X, Y = np.meshgrid(x_range[0] + sp[0] * np.arange(nx), y_range[0] + sp[1] * np.arange(ny), indexing="ij")
+        return HeightFieldTerrain.build(height_fn(X, Y), origin=(x_range[0], y_range[0]), spacing=sp, delta=delta)
+
+    @property
+    def _height(self) -> float:  # (what model-level code reads of a flat terrain: not used by the device for a grid)
+        return 0.0
+
+    def height(self, x, y):
+        h = self._heights
+        nx, ny = h.shape
+        fx = np.clip((np.asarray(x, dtype=float) - self._origin[0]) / self._spacing[0], 0.0, nx - 1)
+        fy = np.clip((np.asarray(y, dtype=float) - self._origin[1]) / self._spacing[1], 0.0, ny - 1)
+        ix = np.minimum(fx, nx - 2).astype(int)
+        iy = np.minimum(fy, ny - 2).astype(int)
+        tx, ty = fx - ix, fy - iy
+        a = h[ix, iy] + (h[ix, iy + 1] - h[ix, iy]) * ty
+        c = h[ix + 1, iy] + (h[ix + 1, iy + 1] - h[ix + 1, iy]) * ty
+        return a + (c - a) * tx
+
+    def normal(self, x, y):
+        x, y, d = np.asarray(x, dtype=float), np.asarray(y, dtype=float), self.delta
+        n = np.stack([(self.height(x - d, y) - self.height(x + d, y)) / (2 * d),
+                      (self.height(x, y - d) - self.height(x, y + d)) / (2 * d), np.ones(np.shape(x))], axis=-1)  # fmt: skip
+        return n / np.linalg.norm(n, axis=-1, keepdims=True)
+
+
 class SoftContacts:
     """Marker for the Hunt-Crossley soft-contact model (``rbda/contacts/soft.py:126-444``)."""
 

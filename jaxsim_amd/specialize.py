@@ -76,6 +76,16 @@ def modes_of(model) -> list[int]:
     return [MODE_STEP_RIGID] if rigid else [MODE_STEP, MODE_ROLLOUT]
 
 
+MODE_DYN, MODE_DYN_RIGID = 12, 13
+
+
+def dyn_mode_of(model) -> int:
+    """The kernel mode behind ``js.ode.system_dynamics`` / ``js.contact.link_contact_forces`` for this model [round 6]."""
+    desc, _keep = _lib.make_desc(model, np.float32)
+    enabled = desc.n_points > 0 and any(desc.point_enabled[k] for k in range(desc.n_points))
+    return MODE_DYN_RIGID if (desc.contact_model != 0 and enabled) else MODE_DYN
+
+
 def mode_of(model) -> int:
     """The mode of a single ``js.model.step``."""
     return modes_of(model)[0]

@@ -725,6 +725,31 @@ def system_acceleration(model, data: OracleData, *, link_forces=None, joint_torq
     return W_vd_WB, sdd, md
 
 
+def system_acceleration_active(model, data: OracleData, *, link_forces=None, joint_torques=None):
+    """``system_acceleration`` (ode.py:16-131) AS WRITTEN for data in any velocity representation: ``link_forces`` are
+    in the representation of ``data`` (ode.py:30-33), the contact wrenches come back inertial (contact.py:527-530), the
+    two are added as they are (ode.py:77) and the sum is handed to ABA through a references object built in the data's
+    representation (ode.py:103-122) -- so with Body / Mixed data the inertial contact wrenches are READ as wrenches of that
+    representation.  Identical to ``system_acceleration`` above for inertial data, which is how the integrators call it
+    (integrators.py:22, ode.py:204).  Returns ``(vdot_WB in the data's representation, sddot, mdot)``."""
+    kdp = model.kin_dyn_parameters
+    N, nL = data.batch_size, kdp.number_of_links()
+    dtype = data.dtype
+    f_L = link_forces if link_forces is not None else np.zeros((N, nL, 6), dtype=dtype)
+    W_f_L_terrain = np.zeros_like(f_L)
+    md = np.zeros_like(data.tangential_deformation)
+    if kdp.number_of_collidable_points() > 0:  # ode.py:57
+        if is_rigid_contact_model(model) or is_relaxed_rigid_contact_model(model):
+            from . import refrelaxed, refrigid
+
+            impl = refrigid if is_rigid_contact_model(model) else refrelaxed
+            W_f_L_terrain, _ = impl.link_contact_forces(model, data, link_forces=f_L, joint_torques=joint_torques)
+        else:
+            W_f_L_terrain, md = link_contact_forces(model, data)
+    vd, sdd = forward_dynamics_aba(model, data, joint_forces=joint_torques, link_forces=f_L + W_f_L_terrain)
+    return vd, sdd, md
+
+
 def semi_implicit_euler_integration(model, data: OracleData, link_forces, joint_torques) -> OracleData:
     dtype = data.dtype
     W_vd_WB, sdd, md = system_acceleration(model, data, link_forces=link_forces, joint_torques=joint_torques)

@@ -38,6 +38,7 @@ void run_group(const jxs::Packed<T>& pk, jxs::KArgs<T> a, int mode) {
   a.lti = pk.lti_packed.data();
   a.chunks = pk.chunks.data();
   a.rti = pk.rti_packed.data();
+  a.hf = pk.hf.empty() ? nullptr : pk.hf.data();
   for (int env = 0; env < a.N; ++env) {
     jxs::HostLanes<T, G> ln(a.N, env, (size_t)std::max({jxs::rigid_lds_words_per_env(pk.P.n_cp, pk.P.rigid), jxs::rigid_lds_words_per_env(pk.P.n_cp, pk.P.rigid, pk.P.ct_tree, pk.P.n_chunks, G), jxs::duo_words_per_env(G), jxs::rk4_lds_words_per_env(G, pk.P.n_chunks)}));
     jxs::Core<jxs::HostLanes<T, G>> core(pk.P, a, ln);

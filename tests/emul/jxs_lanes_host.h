@@ -379,6 +379,11 @@ struct HostLanes {
     for (int i = 0; i < G; ++i) r.v[i] = head[chunk * G + i];
     return r;
   }
+  V tgather(const T* tbl, const VI& idx) const {
+    V r;
+    for (int i = 0; i < G; ++i) r.v[i] = tbl[idx.v[i]];
+    return r;
+  }
   V ploadf(const T* tbl, int field, const VI& slot) const {
     V r;
     for (int i = 0; i < G; ++i) r.v[i] = tbl[slot.v[i] * kPtStride + field];

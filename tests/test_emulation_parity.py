@@ -1289,3 +1289,184 @@ def test_fifty_point_sphere_matches_oracle(models, reduced_qp, kind, path, monke
     ref = oracle.step(model, d)
     out = eb.run(model, eb.MODE_STEP, helpers.odata_to_block(model, d))
     assert helpers.rel_err(out, helpers.odata_to_block(model, ref)) < (1e-7 if kind == "rigid" else 1e-9)
+
+
+# ---- [round 6] system_dynamics / link_contact_forces (SURVEY section 8(a) rows E and I as callable entries) -----------
+# reference: src/jaxsim/api/ode.py:16-225, src/jaxsim/api/contact.py:514-603; the kernel modes MODE_DYN / MODE_DYN_RIGID
+def _dyn_reference(model, d, tau, f):
+    """(derivative block [rows, N], link contact wrenches [N, nL, 6]) of the oracle for inertial data."""
+    xd = oracle.refstep.system_dynamics(model, d, link_forces=f, joint_torques=tau)
+    blk = helpers.st.pack_state(
+        helpers.st.StateLayout.of(model), base_position=xd["base_position"], base_quaternion=xd["base_quaternion"],
+        joint_positions=xd["joint_positions"], base_linear_velocity=xd["base_linear_velocity"],
+        base_angular_velocity=xd["base_angular_velocity"], joint_velocities=xd["joint_velocities"],
+        tangential_deformation=xd["tangential_deformation"], dtype=np.float64,
+    )  # fmt: skip
+    if oracle.refstep.is_rigid_contact_model(model):
+        from oracle import refrigid
+
+        W_f_L, _ = refrigid.link_contact_forces(model, d, link_forces=f, joint_torques=tau)
+    elif oracle.refstep.is_relaxed_rigid_contact_model(model):
+        from oracle import refrelaxed
+
+        W_f_L, _ = refrelaxed.link_contact_forces(model, d, link_forces=f, joint_torques=tau)
+    elif model.kin_dyn_parameters.number_of_collidable_points() > 0:
+        W_f_L, _ = oracle.refstep.link_contact_forces(model, d)
+    else:
+        W_f_L = np.zeros((d.batch_size, model.number_of_links(), 6))
+    return blk, W_f_L
+
+
+def helpers_dyn_err(a, ref, dtype):
+    """Metric of the derivative / wrench comparisons ([rows, N] blocks).  fp64: helpers.rel_err, element by element.
+    fp32: the worst element error of an environment relative to the LARGEST entry of that environment's reference block
+    (at least 1).  A 1e6 N/m^1.5 contact turns the 6e-8 m an fp32 foot height is known to into a force error of 1e-3 of
+    the contact force, which reaches every acceleration of the tree -- the small ones included; the step's gates see the
+    same error times dt = 1e-3 against states of order one, i.e. the same scale."""
+    if np.dtype(dtype) == np.float64:
+        return helpers.rel_err(a, ref)
+    a, ref = np.asarray(a, np.float64), np.asarray(ref, np.float64)
+    return float(np.max(np.abs(a - ref).max(axis=0) / np.maximum(1.0, np.abs(ref).max(axis=0)))) if a.size else 0.0
+
+
+@pytest.mark.parametrize("name", ALL)
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_system_dynamics_matches_oracle(models, name, dtype):
+    model = models(name)
+    N = 32
+    d = models.random_data(name, N, seed=4, dtype=dtype, rep=VelRepr.Inertial)
+    tau, f = helpers.random_inputs(model, N, 15, dtype)
+    ref_blk, ref_W = _dyn_reference(model, helpers.upcast(d), tau.astype(np.float64), f.astype(np.float64))
+    xdot, W = eb.run(model, eb.MODE_DYN, helpers.odata_to_block(model, d), tau=tau.T, link_forces=f.reshape(N, -1).T, force_repr=0)
+    assert xdot.dtype == dtype
+    tol = helpers.tol_of(dtype, name, evaluation=True)
+    assert helpers_dyn_err(xdot, ref_blk, dtype) < tol
+    assert helpers_dyn_err(W, ref_W.reshape(N, -1).T, dtype) < tol
+    if name in models.contact_z:
+        assert np.abs(ref_W).max() > 1.0  # contacts really act in this sample
+
+
+def test_system_dynamics_takes_the_torques_as_they_are(models):
+    """No actuation model in system_dynamics (api/ode.py:117-122): with limits, friction and a torque-speed curve that all
+    bite (helpers.actuation_variant), the joint torques go to ABA unchanged -- while `step` applies the model to them."""
+    model = helpers.actuation_variant(models("anymal"), seed=3)
+    N = 5
+    d = helpers.actuation_state(models, "anymal", model, N, seed=4, dtype=np.float64)
+    d = dataclasses.replace(d, velocity_representation=VelRepr.Inertial)
+    tau, f = helpers.random_inputs(model, N, 5, np.float64)
+    ref_blk, _ = _dyn_reference(model, d, tau, None)
+    xdot, _ = eb.run(model, eb.MODE_DYN, helpers.odata_to_block(model, d), tau=tau.T)
+    assert helpers.rel_err(xdot, ref_blk) < 1e-10
+
+
+@pytest.mark.parametrize("key", ["box4", "anymal16", "anymal4", "chain9f6", "icub8", "planar_biped"])
+def test_rigid_system_dynamics_matches_oracle(models, reduced_qp, key):
+    model, d = _rigid_case(models, key, 8, seed=5)
+    d = dataclasses.replace(d, velocity_representation=VelRepr.Inertial)
+    tau, f = helpers.random_inputs(model, 8, 7, np.float64)
+    ref_blk, ref_W = _dyn_reference(model, d, tau, f)
+    xdot, W = eb.run(model, eb.MODE_DYN, helpers.odata_to_block(model, d), tau=tau.T, link_forces=f.reshape(8, -1).T, force_repr=0)
+    assert helpers.rel_err(xdot, ref_blk) < 1e-6  # (accelerations: the step's 1e-7 gate is on dt x these)
+    assert helpers.rel_err(W.T.reshape(8, -1, 6), ref_W) < 1e-6
+    assert np.abs(ref_W).max() > 1.0
+
+
+@pytest.mark.parametrize("key", ["box8", "anymal16", "chain9f6", "icub16", "planar_biped"])
+def test_relaxed_system_dynamics_matches_oracle(models, key):
+    model, d = _relaxed_case(models, key, 8, seed=5)
+    d = dataclasses.replace(d, velocity_representation=VelRepr.Inertial)
+    tau, f = helpers.random_inputs(model, 8, 7, np.float64)
+    ref_blk, ref_W = _dyn_reference(model, d, tau, f)
+    xdot, W = eb.run(model, eb.MODE_DYN, helpers.odata_to_block(model, d), tau=tau.T, link_forces=f.reshape(8, -1).T, force_repr=0)
+    assert helpers.rel_err(xdot, ref_blk) < 1e-8
+    assert helpers.rel_err(W.T.reshape(8, -1, 6), ref_W) < 1e-8
+    assert np.abs(ref_W).max() > 1.0
+
+
+# ---- [round 6] height-field terrain (SURVEY section 8(f) row 2: the generic finite-difference normal, terrain.py:40-62) --
+def _sine_field(extent=4.0, spacing=0.05, amp=0.04):
+    """A rolling terrain: z = amp (sin(2.1 x + 0.3) cos(1.7 y) + 0.3 sin(3.3 y)), sampled on a 5 cm grid over [-extent, extent]^2
+    (slopes up to ~10 degrees: the normal is far from +z).  Returns (product terrain, oracle terrain of the SAME grid)."""
+    import jaxsim_amd as ja
+    from oracle import refterrain
+
+    fn = lambda x, y: amp * (np.sin(2.1 * x + 0.3) * np.cos(1.7 * y) + 0.3 * np.sin(3.3 * y))  # noqa: E731
+    t = ja.HeightFieldTerrain.from_function(fn, x_range=(-extent, extent), y_range=(-extent, extent), spacing=spacing)
+    return t, refterrain.GridTerrain(np.array(t._heights), t._origin, t._spacing, t.delta), fn
+
+
+def test_height_field_host_class_matches_the_restatement():
+    """jaxsim_amd.HeightFieldTerrain (product, host) against oracle.refterrain.GridTerrain (independent statement of the
+    bilinear interpolant; normal inherited from the reference's Terrain base class), inside, on and outside the grid; and
+    against the sampled function itself at the sample points (exact) and between them (interpolation error only)."""
+    t, g, fn = _sine_field(extent=1.0, spacing=0.1)
+    rng = np.random.default_rng(0)
+    x, y = rng.uniform(-1.4, 1.4, 4000), rng.uniform(-1.4, 1.4, 4000)
+    np.testing.assert_allclose(t.height(x, y), g.height(x, y), rtol=0, atol=1e-15)
+    np.testing.assert_allclose(t.normal(x, y), g.normal(x, y), rtol=0, atol=1e-13)
+    xs = -1.0 + 0.1 * np.arange(21)
+    X, Y = np.meshgrid(xs, xs, indexing="ij")
+    np.testing.assert_allclose(t.height(X, Y), fn(X, Y), rtol=0, atol=1e-15)
+    inside = (np.abs(x) < 1) & (np.abs(y) < 1)
+    assert np.abs(t.height(x[inside], y[inside]) - fn(x[inside], y[inside])).max() < 0.04 * (2.1**2 + 1.7**2) * 0.1**2 / 4  # |f''| h^2 / 8 per axis
+    # clamped outside: the border sample extends outwards
+    np.testing.assert_allclose(t.height(np.array([5.0]), np.array([0.3])), t.height(np.array([1.0]), np.array([0.3])))
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("name", ["box", "anymal", "icub"])
+def test_height_field_terrain_soft(models, name, dtype):
+    t, g, _ = _sine_field()
+    model = helpers.with_params(models(name), terrain=t)
+    N = 12
+    d = models.random_data(name, N, seed=23, dtype=dtype)
+    ref = oracle.step(helpers.with_params(model, terrain=g), helpers.upcast(d, model))
+    out = eb.run(model, eb.MODE_STEP, helpers.odata_to_block(model, d))
+    # (fp32: the slope is a difference of two heights 2 cm apart, known to 1e-8 of 0.04 m: 1e-7 in the normal -- nothing)
+    assert helpers.rel_err(out, helpers.odata_to_block(model, ref)) < helpers.tol_of(dtype, name)
+    flat = eb.run(models(name), eb.MODE_STEP, helpers.odata_to_block(model, d))
+    assert helpers.rel_err(flat, helpers.odata_to_block(model, ref)) > 1e-5  # the terrain really changes the answer
+    # and the derivative / link wrenches of system_dynamics see the same terrain
+    d_in = dataclasses.replace(helpers.upcast(d, model), velocity_representation=VelRepr.Inertial)
+    ref_blk, ref_W = _dyn_reference(helpers.with_params(model, terrain=g), d_in, None, None)
+    xdot, W = eb.run(model, eb.MODE_DYN, helpers.odata_to_block(model, d))
+    assert helpers_dyn_err(xdot, ref_blk, dtype) < max(helpers.tol_of(dtype, name), 1e-3 if dtype == np.float32 else 0)
+    assert np.abs(ref_W[..., :2]).max() > 0.1  # tilted normals: horizontal contact forces
+
+
+@pytest.mark.parametrize("kind,key", [("rigid", "box4"), ("rigid", "anymal4"), ("relaxed", "box8"), ("relaxed", "anymal16")])
+def test_height_field_terrain_rigid_models(models, reduced_qp, kind, key):
+    t, g, _ = _sine_field()
+    base, d = (_rigid_case if kind == "rigid" else _relaxed_case)(models, key, 24, seed=5)
+    model = helpers.with_params(base, terrain=t)
+    ref = oracle.step(helpers.with_params(model, terrain=g), d)
+    out = eb.run(model, eb.MODE_STEP, helpers.odata_to_block(model, d))
+    assert helpers.rel_err(out, helpers.odata_to_block(model, ref)) < (1e-7 if kind == "rigid" else 1e-9)
+    flat = eb.run(base, eb.MODE_STEP, helpers.odata_to_block(model, d))
+    assert helpers.rel_err(flat, helpers.odata_to_block(model, ref)) > 1e-5
+
+
+def test_height_field_known_answer_box_rests_on_a_ramp(models):
+    """Known answer without the oracle: a height field that IS a plane (z = tan(a) x) must reproduce PlaneTerrain -- the
+    bilinear interpolant of a linear function is that function, its central difference the exact slope."""
+    import jaxsim_amd as ja
+
+    a = np.deg2rad(8.0)
+    hf = ja.HeightFieldTerrain.from_function(lambda x, y: np.tan(a) * x + 0.0 * y, x_range=(-3, 3), y_range=(-3, 3), spacing=0.25)
+    plane = ja.PlaneTerrain.build(height=0.0, normal=[-np.sin(a), 0.0, np.cos(a)])
+    box = models("box")
+    d = models.random_data("box", 16, seed=3)
+    o1 = eb.run(helpers.with_params(box, terrain=hf), eb.MODE_STEP, helpers.odata_to_block(box, d))
+    o2 = eb.run(helpers.with_params(box, terrain=plane), eb.MODE_STEP, helpers.odata_to_block(box, d))
+    assert helpers.rel_err(o1, o2) < 1e-11
+
+
+def test_height_field_is_validated(models):
+    import jaxsim_amd as ja
+
+    with pytest.raises(ValueError):
+        ja.HeightFieldTerrain.build(np.zeros((1, 5)))
+    with pytest.raises(ValueError):
+        ja.HeightFieldTerrain.build(np.zeros((3, 3)), spacing=(0.1, 0.0))
+    with pytest.raises(ValueError):
+        ja.HeightFieldTerrain.build(np.full((3, 3), np.nan))

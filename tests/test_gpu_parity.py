@@ -1737,3 +1737,208 @@ def test_a_non_finite_environment_does_not_touch_its_neighbours(models, case, dt
         others = [e for e in range(N) if e != bad_env]
         assert not np.isfinite(out[:, bad_env]).all()
         assert np.array_equal(out[:, others], clean[:, others]), (case, bad_env, np.argwhere(out[:, others] != clean[:, others])[:4])
+
+
+# ---- [round 6] js.ode.system_dynamics / system_acceleration, js.contact.link_contact_forces ---------------------------
+# SURVEY section 8(a) rows E and I as callable entries (jxs_system_dynamics, jxs_link_contact_forces; kernel modes MODE_DYN /
+# MODE_DYN_RIGID).  Reference: src/jaxsim/api/ode.py:16-225, src/jaxsim/api/contact.py:514-603 -- what the reference's
+# contact-model benchmarks time (tests/test_benchmark.py:103-139).
+def _dyn_err(a, ref, dtype):
+    """fp64: helpers.rel_err element by element.  fp32: the worst element error of an environment relative to the largest
+    entry of that environment's reference (at least 1) -- see tests/test_emulation_parity.py helpers_dyn_err."""
+    a, ref = np.asarray(a, np.float64), np.asarray(ref, np.float64)
+    if np.dtype(dtype) == np.float64:
+        return helpers.rel_err(a, ref)
+    a, ref = a.reshape(a.shape[0], -1), ref.reshape(ref.shape[0], -1)
+    return float(np.max(np.abs(a - ref).max(axis=1) / np.maximum(1.0, np.abs(ref).max(axis=1)))) if a.size else 0.0
+
+
+def _oracle_link_contact_forces(model, d, tau, f):
+    if oracle.refstep.is_rigid_contact_model(model):
+        from oracle import refrigid
+
+        return refrigid.link_contact_forces(model, d, link_forces=f, joint_torques=tau)[0]
+    if oracle.refstep.is_relaxed_rigid_contact_model(model):
+        from oracle import refrelaxed
+
+        return refrelaxed.link_contact_forces(model, d, link_forces=f, joint_torques=tau)[0]
+    if model.kin_dyn_parameters.number_of_collidable_points() == 0:
+        return np.zeros((d.batch_size, model.number_of_links(), 6))
+    return oracle.refstep.link_contact_forces(model, d)[0]
+
+
+def _check_dynamics(model, d, tau, f, dtype, tol):
+    """system_dynamics (every key), link_contact_forces and system_acceleration of the device against the oracle."""
+    N = d.batch_size
+    d64 = helpers.upcast(d, model)
+    tau64 = None if tau is None else tau.astype(np.float64)
+    f64 = None if f is None else f.astype(np.float64)
+    g = to_gpu(model, d)
+    # --- system_dynamics: evaluated in inertial representation whatever the data's (api/ode.py:204)
+    d_in = dataclasses.replace(d64, velocity_representation=VelRepr.Inertial)
+    ref = oracle.refstep.system_dynamics(model, d_in, link_forces=f64, joint_torques=tau64)
+    got = js.ode.system_dynamics(model, g, link_forces=f, joint_torques=tau)
+    for key in ("base_position", "base_quaternion", "joint_positions", "base_linear_velocity", "base_angular_velocity", "joint_velocities"):
+        assert np.asarray(got[key]).dtype == dtype
+        assert _dyn_err(got[key], ref[key], dtype) < tol, key
+    if oracle.refstep.is_rigid_contact_model(model) or oracle.refstep.is_relaxed_rigid_contact_model(model):
+        assert got["contact_state"] == {}
+    elif model.kin_dyn_parameters.number_of_collidable_points() > 0:
+        assert _dyn_err(got["contact_state"]["tangential_deformation"], ref["tangential_deformation"], dtype) < tol
+    # --- link_contact_forces: link forces in the data's representation (rigid models; SoftContacts ignores the inputs)
+    ref_W = _oracle_link_contact_forces(model, d64, tau64, f64)
+    W, aux = js.contact.link_contact_forces(model, g, link_forces=f, joint_torques=tau)
+    assert np.asarray(W).shape == (N, model.number_of_links(), 6)
+    assert _dyn_err(W, ref_W, dtype) < tol
+    # --- system_acceleration in the data's representation, as written (oracle.refstep.system_acceleration_active)
+    vd, sdd, md = oracle.refstep.system_acceleration_active(model, d64, link_forces=f64, joint_torques=tau64)
+    gvd, gsdd, gcs = js.ode.system_acceleration(model, g, link_forces=f, joint_torques=tau)
+    assert _dyn_err(np.concatenate([np.asarray(gvd), np.asarray(gsdd)], -1), np.concatenate([vd, sdd], -1), dtype) < tol
+    return ref_W, aux, gcs, md
+
+
+@pytest.mark.parametrize("name", ALL)
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("rep", [VelRepr.Inertial, VelRepr.Body, VelRepr.Mixed])
+def test_system_dynamics_matches_oracle_gpu(models, name, dtype, rep):
+    if rep != VelRepr.Inertial and name not in ("box", "chain9f", "anymal", "icub"):
+        pytest.skip("the three representations are covered on the four contact models")
+    model = models(name)
+    N = 70  # not a multiple of the environments per wave
+    d = models.random_data(name, N, seed=4, dtype=dtype, rep=rep)
+    tau, f = helpers.random_inputs(model, N, 15, dtype)
+    tol = helpers.tol_of(dtype, name, evaluation=True)
+    if dtype == np.float32 and name in models.contact_z:
+        # forces and accelerations, not dt x them: a point that barely touches has dF / d delta = D delta_dot / (2 sqrt(delta))
+        # -> 1e3 .. 1e4 N/m per ulp-sized (7e-9 m) error of its height, i.e. 1e-3 N on a force of order one (measured on
+        # MI355X, sphere, one environment of 70: 8.0e-4; the reference formulation in fp32: 3.8e-4 on the same states) --
+        # the ceiling of the fp32 gates applies (helpers.FP32_TOL); the step's per-model gates see dt = 1e-3 times this
+        tol = max(tol, helpers.FP32_TOL)
+    ref_W, aux, gcs, md = _check_dynamics(model, d, tau, f, dtype, tol)
+    if name in models.contact_z:
+        assert np.abs(ref_W).max() > 1.0  # contacts really act in this sample
+        assert _dyn_err(aux["m_dot"], md, dtype) < tol
+        assert _dyn_err(gcs["tangential_deformation"], md, dtype) < tol
+
+
+def test_system_dynamics_without_inputs_and_one_environment_gpu(models):
+    """The reference idiom of its benchmarks: `js.ode.system_dynamics(model, data)` -- no inputs, unbatched data."""
+    model = models("icub")
+    d = models.random_data("icub", 1, seed=4, rep=VelRepr.Inertial)
+    g = js.data.JaxSimModelData.build(
+        model, base_position=d.base_position[0], base_quaternion=d.base_quaternion[0], joint_positions=d.joint_positions[0],
+        base_linear_velocity=d.base_linear_velocity[0], base_angular_velocity=d.base_angular_velocity[0],
+        joint_velocities=d.joint_velocities[0], velocity_representation=ja.VelRepr.Inertial, dtype=np.float64,
+    )  # fmt: skip
+    ref = oracle.refstep.system_dynamics(model, dataclasses.replace(d, tangential_deformation=np.zeros_like(d.tangential_deformation)).update_caches(model))
+    got = js.ode.system_dynamics(model, g)
+    assert np.asarray(got["joint_velocities"]).shape == (model.dofs(),)
+    for key in ("base_position", "base_quaternion", "joint_positions", "base_linear_velocity", "base_angular_velocity", "joint_velocities"):
+        assert helpers.rel_err(got[key], ref[key][0]) < helpers.FP64_TOL, key
+    pd, Qd, sd = js.ode.system_position_dynamics(g)
+    assert helpers.rel_err(pd, ref["base_position"][0]) < 1e-12 and helpers.rel_err(Qd, ref["base_quaternion"][0]) < 1e-12
+    np.testing.assert_array_equal(sd, np.asarray(g.joint_velocities))
+
+
+def test_system_dynamics_baumgarte_gain_and_raw_torques_gpu(models):
+    """(a) the Baumgarte gain reaches the quaternion derivative: with a non-unit stored quaternion the reference
+    normalises first (data.base_orientation), so the term vanishes to rounding and every gain gives the same Qdot;
+    (b) no actuation model (api/ode.py:117-122): limits, friction and the torque-speed curve of
+    helpers.actuation_variant all bite in `step` and must not touch the torques here."""
+    model = helpers.actuation_variant(models("anymal"), seed=3)
+    N = 9
+    d = helpers.actuation_state(models, "anymal", model, N, seed=4, dtype=np.float64)
+    d = dataclasses.replace(d, velocity_representation=VelRepr.Inertial, base_quaternion=d.base_quaternion * 1.3).update_caches(model)
+    tau, _ = helpers.random_inputs(model, N, 5, np.float64)
+    ref = oracle.refstep.system_dynamics(model, d, joint_torques=tau)
+    g = to_gpu(model, d)
+    for K in (1.0, 0.1, 25.0):
+        got = js.ode.system_dynamics(model, g, joint_torques=tau, baumgarte_quaternion_regularization=K)
+        assert helpers.rel_err(got["base_quaternion"], ref["base_quaternion"]) < 1e-12
+        assert helpers.rel_err(got["joint_velocities"], ref["joint_velocities"]) < helpers.FP64_TOL
+
+
+DYN_RIGID_KEYS = ["box4", "anymal16", "anymal4", "icub8"]
+
+
+@pytest.mark.parametrize("key", DYN_RIGID_KEYS)
+@pytest.mark.parametrize("rep", [VelRepr.Inertial, VelRepr.Mixed])
+def test_rigid_system_dynamics_matches_oracle_gpu(models, reduced_qp, key, rep):
+    name, idx, params = RIGID_CASES[key]
+    model = helpers.rigid_model(models(name), idx, **params)
+    N = 21
+    d = models.random_data(name, N, seed=5, rep=rep)
+    tau, f = helpers.random_inputs(model, N, 7, np.float64)
+    ref_W, aux, gcs, _ = _check_dynamics(model, d, tau, f, np.float64, 1e-6)  # (accelerations: the step's 1e-7 gate sees dt x these)
+    assert np.abs(ref_W).max() > 1.0 and aux == {} and gcs == {}
+
+
+@pytest.mark.parametrize("key", ["anymal4", "icub8", "anymal16"])
+def test_rigid_system_dynamics_fp32_gpu(models, reduced_qp, key):
+    name, idx, params = RIGID_CASES[key]
+    model = helpers.rigid_model(models(name), idx, **params)
+    d = models.random_data(name, 40, seed=5, dtype=np.float32, rep=VelRepr.Inertial)
+    tau, f = helpers.random_inputs(model, 40, 7, np.float32)
+    _check_dynamics(model, d, tau, f, np.float32, 3e-3)
+
+
+DYN_RELAXED_KEYS = ["box8", "anymal16", "icub16"]
+
+
+@pytest.mark.parametrize("key", DYN_RELAXED_KEYS)
+@pytest.mark.parametrize("rep", [VelRepr.Inertial, VelRepr.Body])
+def test_relaxed_system_dynamics_matches_oracle_gpu(models, key, rep):
+    name, idx, params = RELAXED_CASES[key]
+    model = helpers.relaxed_model(models(name), idx, **params)
+    N = 21
+    d = models.random_data(name, N, seed=5, rep=rep)
+    tau, f = helpers.random_inputs(model, N, 7, np.float64)
+    ref_W, aux, gcs, _ = _check_dynamics(model, d, tau, f, np.float64, 1e-8)
+    assert np.abs(ref_W).max() > 1.0 and aux == {} and gcs == {}
+
+
+@pytest.mark.parametrize("key", ["anymal16", "icub16"])
+def test_relaxed_system_dynamics_fp32_gpu(models, key):
+    name, idx, params = RELAXED_CASES[key]
+    model = helpers.relaxed_model(models(name), idx, **params)
+    d = models.random_data(name, 40, seed=5, dtype=np.float32, rep=VelRepr.Inertial)
+    tau, f = helpers.random_inputs(model, 40, 7, np.float32)
+    _check_dynamics(model, d, tau, f, np.float32, 2e-3)
+
+
+def test_link_contact_forces_are_what_the_step_applies_gpu(models):
+    """Force-level consistency of rows I / K / L with the step: one semi-implicit Euler step from the device equals
+    the state integrated by hand from the device's own system_dynamics evaluated with the actuation model's torques
+    (api/model.py:2658) -- nu+ = nu + dt nudot, m+ = m + dt mdot (api/integrators.py:35-71)."""
+    model = models("icub")
+    N = 33
+    d = models.random_data("icub", N, seed=4, rep=VelRepr.Inertial)
+    g = to_gpu(model, d)
+    tau = oracle.refstep.compute_resultant_torques(model, d)  # what `step` hands to system_dynamics (api/model.py:2658)
+    xd = js.ode.system_dynamics(model, g, joint_torques=tau)
+    out = js.model.step(model, g)
+    dt = model.time_step
+    np.testing.assert_allclose(np.asarray(out.joint_velocities), d.joint_velocities + dt * np.asarray(xd["joint_velocities"]), rtol=0, atol=1e-11)
+    np.testing.assert_allclose(np.asarray(out.contact_state["tangential_deformation"]),
+                               d.tangential_deformation + dt * np.asarray(xd["contact_state"]["tangential_deformation"]), rtol=0, atol=1e-12)  # fmt: skip
+    W, _ = js.contact.link_contact_forces(model, g)
+    # Newton: total contact force + weight = d/dt of the linear momentum; cross-check with the CoM acceleration is left to
+    # the oracle comparison above -- here only: the wrenches sit on the links that carry enabled points
+    kdp = model.kin_dyn_parameters
+    has = np.zeros(model.number_of_links(), dtype=bool)
+    has[np.asarray(kdp.contact_body)[kdp.indices_of_enabled_collidable_points]] = True
+    assert np.all(np.asarray(W)[:, ~has] == 0) and np.abs(np.asarray(W)[:, has]).max() > 1.0
+
+
+def test_link_forces_from_contact_forces_host(models):
+    model = models("icub16")
+    kdp = model.kin_dyn_parameters
+    body = np.asarray(kdp.contact_body)[kdp.indices_of_enabled_collidable_points]
+    rng = np.random.default_rng(0)
+    W_f_C = rng.normal(size=(len(body), 6))
+    W_f_L = js.contact.link_forces_from_contact_forces(model, contact_forces=W_f_C)
+    assert W_f_L.shape == (model.number_of_links(), 6)
+    for l in range(model.number_of_links()):
+        np.testing.assert_allclose(W_f_L[l], W_f_C[body == l].sum(axis=0), atol=1e-14)
+    with pytest.raises(ValueError):
+        js.contact.link_forces_from_contact_forces(model, contact_forces=W_f_C[:-1])
