@@ -1942,3 +1942,59 @@ def test_link_forces_from_contact_forces_host(models):
         np.testing.assert_allclose(W_f_L[l], W_f_C[body == l].sum(axis=0), atol=1e-14)
     with pytest.raises(ValueError):
         js.contact.link_forces_from_contact_forces(model, contact_forces=W_f_C[:-1])
+
+
+# ---- [round 6] height-field terrain (the generic finite-difference normal, terrain.py:40-62) --
+def _sine_field(extent=4.0, spacing=0.05, amp=0.04):
+    """(product terrain, oracle terrain of the same grid): see tests/test_emulation_parity.py _sine_field."""
+    from oracle import refterrain
+
+    fn = lambda x, y: amp * (np.sin(2.1 * x + 0.3) * np.cos(1.7 * y) + 0.3 * np.sin(3.3 * y))  # noqa: E731
+    t = ja.HeightFieldTerrain.from_function(fn, x_range=(-extent, extent), y_range=(-extent, extent), spacing=spacing)
+    return t, refterrain.GridTerrain(np.array(t._heights), t._origin, t._spacing, t.delta)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("name", ["box", "icub"])
+def test_height_field_terrain_soft_gpu(models, name, dtype):
+    t, g = _sine_field()
+    model = helpers.with_params(models(name), terrain=t)
+    N = 70
+    d = models.random_data(name, N, seed=23, dtype=dtype)
+    ref = oracle.step(helpers.with_params(model, terrain=g), helpers.upcast(d, model))
+    out = js.model.step(model, to_gpu(model, d))
+    assert helpers.rel_err(out.state_block(), helpers.odata_to_block(model, ref)) < helpers.tol_of(dtype, name)
+    flat = js.model.step(models(name), to_gpu(models(name), d))
+    assert helpers.rel_err(flat.state_block(), helpers.odata_to_block(model, ref)) > 1e-5  # the terrain changes the answer
+    # three steps in one fused launch see the same terrain
+    ref3 = helpers.upcast(d, model)
+    for _ in range(3):
+        ref3 = oracle.step(helpers.with_params(model, terrain=g), ref3)
+    out3 = js.model.rollout(model, to_gpu(model, d), 3)
+    assert helpers.rel_err(out3.state_block(), helpers.odata_to_block(model, ref3)) < 10 * helpers.tol_of(dtype, name)
+
+
+@pytest.mark.parametrize("kind,key", [("rigid", "box4"), ("rigid", "anymal4"), ("relaxed", "box8"), ("relaxed", "anymal16")])
+def test_height_field_terrain_rigid_models_gpu(models, reduced_qp, kind, key):
+    t, g = _sine_field()
+    name, idx, params = (RIGID_CASES if kind == "rigid" else RELAXED_CASES)[key]
+    base = (helpers.rigid_model if kind == "rigid" else helpers.relaxed_model)(models(name), idx, **params)
+    model = helpers.with_params(base, terrain=t)
+    d = models.random_data(name, 24, seed=5)
+    ref = oracle.step(helpers.with_params(model, terrain=g), d)
+    out = js.model.step(model, to_gpu(model, d))
+    assert helpers.rel_err(out.state_block(), helpers.odata_to_block(model, ref)) < (1e-7 if kind == "rigid" else 1e-9)
+
+
+def test_height_field_that_is_a_plane_equals_plane_terrain_gpu(models):
+    """Known answer without the oracle: the bilinear interpolant of z = tan(a) x is that plane and its central difference the
+    exact slope, so the height field must reproduce PlaneTerrain (RungeKutta4 as well: the stages see the terrain too)."""
+    a = np.deg2rad(8.0)
+    hf = ja.HeightFieldTerrain.from_function(lambda x, y: np.tan(a) * x + 0.0 * y, x_range=(-3, 3), y_range=(-3, 3), spacing=0.25)
+    plane = ja.PlaneTerrain.build(height=0.0, normal=[-np.sin(a), 0.0, np.cos(a)])
+    for integ in (ja.IntegratorType.SemiImplicitEuler, ja.IntegratorType.RungeKutta4):
+        box = helpers.with_params(models("box"), integrator=integ)
+        d = models.random_data("box", 33, seed=3)
+        o1 = js.model.step(helpers.with_params(box, terrain=hf), to_gpu(box, d)).state_block()
+        o2 = js.model.step(helpers.with_params(box, terrain=plane), to_gpu(box, d)).state_block()
+        assert helpers.rel_err(o1, o2) < 1e-11
