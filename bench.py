@@ -862,31 +862,41 @@ def main():
         except Exception as e:  # secondary: never lose the headline for it
             python_loop = {"error": repr(e)}
 
-    # secondary figure: the same kernel with the chip saturated (64 Ki environments on this GPU) -- what
-    # the step costs once enough waves hide each other's latencies.  Not the headline configuration.
+    # secondary figures: the same kernel at larger batches on THIS GPU -- 8192 environments (the one-GPU point of
+    # north_star's 1 / 2 / 4 / 8 curve) and the chip saturated (64 Ki environments: what the step
+    # costs once enough waves hide each other's latencies).  Not the headline configuration.
+    def one_gpu_batch(n_big):
+        reps_big = -(-n_big // n_local)
+        big = js.data.JaxSimModelData.from_state_block(
+            model, np.tile(initial_block, (1, reps_big))[:, :n_big].astype(dtype), data.velocity_representation
+        )
+        bp = C.c_void_p(big._state.ptr)
+        _lib.check(lib.jxs_step_repeat(dm.handle, bp, None, None, 2, n_big, 20, stream.handle), "jxs_step_repeat")
+        ev4, ev5 = runtime.Event(), runtime.Event()
+        ev4.record(stream)
+        _lib.check(lib.jxs_step_repeat(dm.handle, bp, None, None, 2, n_big, 200, stream.handle), "jxs_step_repeat")
+        ev5.record(stream)
+        runtime.synchronize(stream)
+        us = ev4.elapsed_ms(ev5) / 200 * 1e3
+        res = {"envs": n_big, "us_per_step": us, "env_steps_per_s": n_big / (us * 1e-6),
+               "finite_envs": float(np.isfinite(big.state_block()).all(axis=0).mean()), "steps_taken": 220}
+        del big
+        return res
+
     saturated = None
     if world == 1 and args.saturated_envs > 0:
         try:
-            n_sat = args.saturated_envs
-            reps_sat = -(-n_sat // n_local)
-            big = js.data.JaxSimModelData.from_state_block(
-                model, np.tile(initial_block, (1, reps_sat))[:, :n_sat].astype(dtype), data.velocity_representation
-            )
-            bp = C.c_void_p(big._state.ptr)
-            _lib.check(lib.jxs_step_repeat(dm.handle, bp, None, None, 2, n_sat, 20, stream.handle), "jxs_step_repeat")
-            ev4, ev5 = runtime.Event(), runtime.Event()
-            ev4.record(stream)
-            _lib.check(lib.jxs_step_repeat(dm.handle, bp, None, None, 2, n_sat, 200, stream.handle), "jxs_step_repeat")
-            ev5.record(stream)
-            runtime.synchronize(stream)
-            us = ev4.elapsed_ms(ev5) / 200 * 1e3
-            saturated = {"envs": n_sat, "us_per_step": us, "env_steps_per_s": n_sat / (us * 1e-6),
-                         "finite_envs": float(np.isfinite(big.state_block()).all(axis=0).mean()), "steps_taken": 220,
-                         "finite_note": "the rate at which environments leave is the explicit contact model's, the same in the fp64 oracle: "
-                                        "profiles/r04_divergence_audit.txt (65536 distinct states x 1000 steps: HIP fp32 47, HIP fp64 51, C port fp32 47, C port fp64 51 gone)"}
-            del big
+            saturated = one_gpu_batch(args.saturated_envs)
+            saturated["finite_note"] = ("the rate at which environments leave is the explicit contact model's, the same in the fp64 oracle: "
+                                        "profiles/r04_divergence_audit.txt (65536 distinct states x 1000 steps: HIP fp32 47, HIP fp64 51, C port fp32 47, C port fp64 51 gone)")
         except Exception as e:  # secondary: never lose the headline for it
             saturated = {"error": repr(e)}
+    batch_8192 = None
+    if world == 1 and args.saturated_envs > 0 and n_local != 8192:
+        try:
+            batch_8192 = one_gpu_batch(8192)
+        except Exception as e:
+            batch_8192 = {"error": repr(e)}
 
     # final state concat: ONE RCCL all-gather over xGMI, outside the timed region
     allgather_ms = None
@@ -1030,6 +1040,12 @@ def main():
                 saturated["note"] = "same step kernel, one GPU filled; secondary figure, not `value`"
                 saturated.update(issue_figures(valu_count, 64 // lay.group, saturated["envs"], saturated["us_per_step"]))
             out["saturated"] = saturated
+        if batch_8192 is not None:
+            if "env_steps_per_s" in batch_8192:
+                batch_8192["hbm_frac"] = alg_bytes_per_env * batch_8192["env_steps_per_s"] / 1e9 / HBM_PEAK_GBS
+                batch_8192["note"] = "north_star's batch 8192 on ONE GPU (the first point of the 1 / 2 / 4 / 8 strong-scaling curve); same step kernel; secondary figure, not `value`"
+                batch_8192.update(issue_figures(valu_count, 64 // lay.group, batch_8192["envs"], batch_8192["us_per_step"]))
+            out["global_batch_8192_one_gpu"] = batch_8192
         if world == 1 and not args.no_other_contact_models:
             try:
                 out["default_contact_params"] = default_contact_params_variant(args.model, n_local, dtype, stream)

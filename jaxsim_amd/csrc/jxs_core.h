@@ -1460,16 +1460,27 @@ struct Core {
   struct RowLevel {
     V Mrow[6], S[6], c[6], pr, S_r, c_r, tau, dp[3];
   };
+  // [round 6] address of the 8-word row group a row lane reads of record `rec`: +8 row in a link's record; a lane without
+  // a link reads zeros at +48 of lds_zero_rec (jxs_params.h: the zero area is 16 words, not a whole record)
+  JXS_HD VI row_group(const VI& rec, const VI& row6) const { return rec + vsel(rec != lds_zero_rec(P.nL), row6 * 8, row6 * 0 + RL_S); }
+  // record of this lane's link; lanes without a link (lane >= nL) publish nothing and read their result from the zero area
+  JXS_HD VI own_record(const VI& lane) const { return vsel(lane < P.nL, lane * kRowRec + ((lane + 1) >> 1) * 4, lane * 0 + lds_zero_rec(P.nL)); }  // (lds_rec_off)
+  // the zero area [Z, Z + kRowZero): kRowZero / 4 lanes write four words each
+  JXS_HD void write_zero_area(const VI& lane, int area) const {
+    const V z4[4] = {V(T(0)), V(T(0)), V(T(0)), V(T(0))};
+    static_assert(kRowZero % 4 == 0 && kRowZero / 4 <= 8, "zero area: whole 16-byte groups, written by the first lanes of the group (the row layout needs 8 lanes or more)");
+    ln.template lds_writev_if<4>(lane * 4 + (lds_zero_at(P.nL) + area), z4, lane < kRowZero / 4);
+  }
   JXS_HD void load_row_level(const VI& rec, const VI& row6, const VI& lane, RowLevel& o) const {
     // `rec`: the link's record for its six row lanes; the all-zero record for lanes without a link at this
     // level (empty slot, idle lanes 6 and 7 of a slot) -- resolved by the packer, no address selects here
     (void)lane;
-    const VI base = rec, brow = rec;
+    const VI base = rec;
     V rw[8], sc[12], td[4];
-    ln.template lds_readv<8>(brow + row6 * 8, rw);
+    ln.template lds_readv<8>(row_group(rec, row6), rw);
     ln.template lds_readv<12>(base + RL_S, sc);
     ln.template lds_readv<4>(base + RL_TAU, td);
-    o.c_r = ln.lds_read(brow + row6 + RL_C);
+    o.c_r = ln.lds_read(base + row6 + RL_C);
 #pragma unroll
     for (int j = 0; j < 6; ++j) o.Mrow[j] = rw[j], o.S[j] = sc[j], o.c[j] = sc[6 + j];
     o.pr = rw[RL_ROW_PA], o.S_r = rw[RL_ROW_S];
@@ -1481,28 +1492,21 @@ struct Core {
   JXS_HD void aba_rows(const VI& lane, const RowTabs& rt, const V* MA, const V* pA, const V* S6, const V* c6,
                        const V& tau, const bool anch, const V* dpl, V& sdd, V* a0) const {
     const V zero = V(T(0));
-    const VI rec_me = lane * kRowRec;
-    // ---- link lanes publish their record (128-bit writes) ---------------------------------
+    const VI rec_me = own_record(lane);
+    // ---- link lanes publish their record (128-bit writes; the lanes behind the last link publish nothing) ------------
+    ln.lds_masked(lane < P.nL, [&]() {
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const V rw[8] = {MA[sidx(i, 0)], MA[sidx(i, 1)], MA[sidx(i, 2)], MA[sidx(i, 3)], MA[sidx(i, 4)], MA[sidx(i, 5)], pA[i], S6[i]};
-      ln.template lds_writev<8>(rec_me + (RL_ROW + 8 * i), rw);
-    }
-    {
+      for (int i = 0; i < 6; ++i) {
+        const V rw[8] = {MA[sidx(i, 0)], MA[sidx(i, 1)], MA[sidx(i, 2)], MA[sidx(i, 3)], MA[sidx(i, 4)], MA[sidx(i, 5)], pA[i], S6[i]};
+        ln.template lds_writev<8>(rec_me + (RL_ROW + 8 * i), rw);
+      }
       const V sc[12] = {S6[0], S6[1], S6[2], S6[3], S6[4], S6[5], c6[0], c6[1], c6[2], c6[3], c6[4], c6[5]};
       ln.template lds_writev<12>(rec_me + RL_S, sc);
       const V td[4] = {tau, anch ? dpl[0] : zero, anch ? dpl[1] : zero, anch ? dpl[2] : zero};
       ln.template lds_writev<4>(rec_me + RL_TAU, td);
-    }
-    ln.lds_write(rec_me + RL_SDD, zero);
-    {  // the all-zero record: kRowRec / 4 lanes write four words each
-      const V z4[4] = {zero, zero, zero, zero};
-      static_assert(kRowRec % 4 == 0, "record = whole 16-byte groups");
-#pragma unroll
-      for (int k = 0; k < (kRowRec / 4 + G - 1) / G; ++k)
-        ln.template lds_writev_if<4>((lane + k * G) * 4 + lds_zero_rec(G), z4, lane + k * G < kRowRec / 4);
-    }
-    const int XB = G * kRowRec;  // base rows: [XB + 8 r + j], j < 6 inertia row, j = 6 bias force
+    });
+    write_zero_area(lane, 0);
+    const int XB = lds_base_rows(G);  // base rows: [XB + 8 r + j], j < 6 inertia row, j = 6 bias force (the row region of record 0)
 
     const VI row = lane & 7;
     const VM rowok = row < 6;
@@ -1541,8 +1545,8 @@ struct Core {
       Ur[Lv] = zero, Sr[Lv] = zero, cr[Lv] = zero, invd[Lv] = zero, uu[Lv] = zero;
       if (Lv >= 1) load_row_level(rt.rec[Lv - 1], row6, lane, nxt);  // prefetch the next level
       if (Lv <= max_depth && (Lv >= 1 || floating)) {
-        const VM has = rt.rec[Lv] != lds_zero_rec(G);
-        V MArow[6];  // (lanes without a link, and the idle lanes 6, 7 of a slot, read the all-zero record)
+        const VM has = rt.rec[Lv] != lds_zero_rec(P.nL);
+        V MArow[6];  // (lanes without a link, and the idle lanes 6, 7 of a slot, read the zero area)
         if (Lv == max_depth) {  // (the deepest level: nothing has been handed up yet -- IEEE arithmetic keeps x + 0)
 #pragma unroll
           for (int j = 0; j < 6; ++j) MArow[j] = cur.Mrow[j];
@@ -1732,7 +1736,8 @@ struct Core {
         // (no select: lanes without a link at this level carry c_r = S_r = 0 and 1 / d = 0, and their apar is acar)
         acar = ai + Sr[Lv] * sd;
         // every row lane of the slot holds the same sd: all of them store it to the link's record (same address, same
-        // value; lanes without a link store into the unread word of the all-zero record) -- no exec-mask bookkeeping
+        // value; lanes without a link store their zero -- 1 / d = 0 -- into the zero area) -- no exec-mask bookkeeping.
+        // [round 6] RL_SDD is the record's tau word: pass 2 has read it, pass 3 reads nothing from the records
         ln.lds_write(rt.rec[Lv] + RL_SDD, sd);
       }
     }
@@ -1877,25 +1882,20 @@ struct Core {
   // The inertia wave: aba_rows() without everything that depends on velocities or forces.
   JXS_HD void aba_rows_inertia(const VI& lane, const RowTabs& rt, const V* MA, const V* S6, const bool anch, const V* dpl) const {
     const V zero = V(T(0));
-    const VI rec_me = lane * kRowRec;
+    const VI rec_me = own_record(lane);
+    ln.lds_masked(lane < P.nL, [&]() {
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const V rw[8] = {MA[sidx(i, 0)], MA[sidx(i, 1)], MA[sidx(i, 2)], MA[sidx(i, 3)], MA[sidx(i, 4)], MA[sidx(i, 5)], zero, S6[i]};
-      ln.template lds_writev<8>(rec_me + (RL_ROW + 8 * i), rw);
-    }
-    {
+      for (int i = 0; i < 6; ++i) {
+        const V rw[8] = {MA[sidx(i, 0)], MA[sidx(i, 1)], MA[sidx(i, 2)], MA[sidx(i, 3)], MA[sidx(i, 4)], MA[sidx(i, 5)], zero, S6[i]};
+        ln.template lds_writev<8>(rec_me + (RL_ROW + 8 * i), rw);
+      }
       const V sc[6] = {S6[0], S6[1], S6[2], S6[3], S6[4], S6[5]};
       ln.template lds_writev<6>(rec_me + RL_S, sc);
       const V td[4] = {zero, anch ? dpl[0] : zero, anch ? dpl[1] : zero, anch ? dpl[2] : zero};
       ln.template lds_writev<4>(rec_me + RL_TAU, td);
-    }
-    {  // the all-zero record
-      const V z4[4] = {zero, zero, zero, zero};
-#pragma unroll
-      for (int k = 0; k < (kRowRec / 4 + G - 1) / G; ++k)
-        ln.template lds_writev_if<4>((lane + k * G) * 4 + lds_zero_rec(G), z4, lane + k * G < kRowRec / 4);
-    }
-    const int XB = G * kRowRec;
+    });
+    write_zero_area(lane, 0);
+    const int XB = lds_base_rows(G);
     const int XL = duo_xl_off(G);
     RowLaneIdx ix;
     row_lane_idx(lane, ix);
@@ -1908,7 +1908,7 @@ struct Core {
     };
     auto load_level = [&](const VI& rec, Lvl& o) {
       V rw[8], sc[6], td[4];
-      ln.template lds_readv<8>(rec + ix.row6 * 8, rw);
+      ln.template lds_readv<8>(row_group(rec, ix.row6), rw);
       ln.template lds_readv<6>(rec + RL_S, sc);
       ln.template lds_readv<4>(rec + RL_TAU, td);
 #pragma unroll
@@ -1926,7 +1926,7 @@ struct Core {
     for (int Lv = kRowLevels - 1; Lv >= 0; --Lv) {
       if (Lv >= 1) load_level(rt.rec[Lv - 1], nxt);
       if (Lv <= max_depth && (Lv >= 1 || floating)) {
-        const VM has = rt.rec[Lv] != lds_zero_rec(G);
+        const VM has = rt.rec[Lv] != lds_zero_rec(P.nL);
         V MArow[6];
         if (!L::add6_packed(cur.Mrow, accM, MArow)) {
 #pragma unroll
@@ -2033,26 +2033,20 @@ struct Core {
                             const bool anch, const V* dpl, V& sdd, V* a0) const {
     const V zero = V(T(0));
     constexpr int AR = duo_main_off(G);  // this wave's LDS area
-    const VI rec_me = lane * kRowRec + AR;
+    const VI rec_me = own_record(lane) + AR;
+    ln.lds_masked(lane < P.nL, [&]() {
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const V ps[2] = {pA[i], S6[i]};
-      ln.template lds_writev<2>(rec_me + (RL_ROW + 8 * i + RL_ROW_PA), ps);
-    }
-    {
+      for (int i = 0; i < 6; ++i) {
+        const V ps[2] = {pA[i], S6[i]};
+        ln.template lds_writev<2>(rec_me + (RL_ROW + 8 * i + RL_ROW_PA), ps);
+      }
       const V sc[12] = {S6[0], S6[1], S6[2], S6[3], S6[4], S6[5], c6[0], c6[1], c6[2], c6[3], c6[4], c6[5]};
       ln.template lds_writev<12>(rec_me + RL_S, sc);
       const V td[4] = {tau, anch ? dpl[0] : zero, anch ? dpl[1] : zero, anch ? dpl[2] : zero};
       ln.template lds_writev<4>(rec_me + RL_TAU, td);
-    }
-    ln.lds_write(rec_me + RL_SDD, zero);
-    {  // the all-zero record of this area
-      const V z4[4] = {zero, zero, zero, zero};
-#pragma unroll
-      for (int k = 0; k < (kRowRec / 4 + G - 1) / G; ++k)
-        ln.template lds_writev_if<4>((lane + k * G) * 4 + (lds_zero_rec(G) + AR), z4, lane + k * G < kRowRec / 4);
-    }
-    const int XB = G * kRowRec;  // base rows: the inertia wave's area holds the inertia, this area the bias force
+    });
+    write_zero_area(lane, AR);
+    const int XB = lds_base_rows(G);  // base rows: the inertia wave's area holds the inertia, this area the bias force
     const int XL = duo_xl_off(G);
     RowLaneIdx ix;
     row_lane_idx(lane, ix);
@@ -2067,7 +2061,7 @@ struct Core {
     auto load_level = [&](const VI& rec0, Lvl& o) {
       const VI rec = rec0 + AR;
       V ps[2], sc[8], td[4];
-      ln.template lds_readv<2>(rec + ix.row6 * 8 + RL_ROW_PA, ps);
+      ln.template lds_readv<2>(row_group(rec0, ix.row6) + (AR + RL_ROW_PA), ps);
       ln.template lds_readv<8>(rec + (RL_C - 2), sc);  // {S4, S5, c0..c5}: two aligned 128-bit reads
       ln.template lds_readv<4>(rec + RL_TAU, td);
       o.c_r = ln.lds_read(rec + ix.row6 + RL_C);
@@ -2186,7 +2180,7 @@ struct Core {
 #pragma unroll
     for (int Lv = 1; Lv < kRowLevels; ++Lv) {
       if (Lv <= max_depth) {
-        const VM has = rt.rec[Lv] != lds_zero_rec(G);
+        const VM has = rt.rec[Lv] != lds_zero_rec(P.nL);
         V apar = acar;
         if ((ppull_levels >> Lv) & 1u) {
           const VM pulled = rt.ppull[Lv] >= 0;

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(64, VARIANT == KV_OCC2 ? 2 : JXS_MIN_WAVES) void jx
   const jxs::DeviceLanes<T, G> ln(A.N, reinterpret_cast<T*>(jxs_smem),
                                   (MODE == jxs::MODE_STEP_RIGID || MODE == jxs::MODE_STEP_RK4_RIGID || MODE == jxs::MODE_DYN_RIGID) ? jxs::rigid_lds_words_per_env(P.n_cp, P.rigid, P.ct_tree, P.n_chunks, G)
                                   : MODE == jxs::MODE_STEP_RK4 ? jxs::rk4_lds_words_per_env(G, P.n_chunks)
-                                                               : jxs::lds_words_per_env(G));
+                                                               : jxs::lds_rows_words(G, P.nL));
   jxs::Core<jxs::DeviceLanes<T, G>> core(P, A, ln);
   core.template run<MODE>();
 }
@@ -156,11 +156,16 @@ hipError_t launch_one(const jxs::KParams<T>& P, const unsigned char* mblk, const
   const int blocks = (A.N + envs_per_wave - 1) / envs_per_wave;
   const bool rows = P.row_mode && (MODE == jxs::MODE_STEP || MODE == jxs::MODE_ROLLOUT || MODE == jxs::MODE_FD ||
                                    MODE == jxs::MODE_STEP_RK4 || MODE == jxs::MODE_DYN);
-  size_t lds_bytes = rows ? sizeof(T) * (size_t)envs_per_wave * jxs::lds_words_per_env(G) : 0;
+  size_t lds_bytes = rows ? sizeof(T) * (size_t)envs_per_wave * jxs::lds_rows_words(G, P.nL) : 0;
   // RungeKutta4 with several point chunks keeps its per-slot stage data in the LDS (jxs_params.h rk4_lds_words_per_env)
-  if (MODE == jxs::MODE_STEP_RK4 && P.n_chunks > 1) lds_bytes = sizeof(T) * (size_t)envs_per_wave * jxs::rk4_lds_words_per_env(G, P.n_chunks);
+  // (... and its row layout sits in an area of the G-wide upper bound, behind which the chunk data start: the kernel's
+  // words per environment are rk4_lds_words_per_env in both cases)
+  if (MODE == jxs::MODE_STEP_RK4 && (rows || P.n_chunks > 1)) lds_bytes = sizeof(T) * (size_t)envs_per_wave * jxs::rk4_lds_words_per_env(G, P.n_chunks);
   // (developer knobs arrive in A.knobs: the library reads the environment once, jxs_api.hip debug_knobs -- no getenv on the
   // launch path, no race with a Python thread that edits os.environ)
+#ifdef JXS_EXP_LDS_BYTES  // developer TIMING experiment only (results are garbage): allocate this many bytes whatever the kernel uses
+  if (rows) lds_bytes = JXS_EXP_LDS_BYTES;
+#endif
   const KTail<T> tail{A.in_a, A.out_a, A.out_H, A.out_V, A.out_tau, A.id_zero_vel, A.dbg, A.faults,
                       A.flags | ((A.knobs & jxs::KNOB_NO_MFMA) ? 1 : 0), A.fparam};  // KNOB_NO_MFMA: A/B of the vector path of the contact solvers' Cholesky
   if (MODE == jxs::MODE_STEP_RIGID || MODE == jxs::MODE_STEP_RK4_RIGID || MODE == jxs::MODE_DYN_RIGID) {

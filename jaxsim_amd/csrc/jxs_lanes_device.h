@@ -781,6 +781,12 @@ struct DeviceLanes {
     }
     if constexpr ((N - done) % 2 == 1) p[N - 1] = v[N - 1];
   }
+  // the LDS writes issued by `f` for the lanes inside `m` only: ONE exec-masked region around them
+  template <class F>
+  __device__ __forceinline__ void lds_masked(bool m, F&& f) const {
+    if (m) f();
+    lds_publish();
+  }
   template <int N>
   __device__ __forceinline__ void lds_writev_if(int addr, const T* v, bool mask) const {
     if (mask) lds_writev<N>(addr, v);

@@ -605,7 +605,7 @@ std::string pack_model(const jxs_model_desc& d, Packed<T>& out) {
         const int L = level[i], s2 = slot[i];
         for (int r = 0; r < 8; ++r) {
           const int lane = 8 * s2 + r;
-          if (r < 6) RI(RT_REC + L, lane) = lane_of[i] * kRowRec;  // (the two idle lanes of a slot: the zero record, below)
+          if (r < 6) RI(RT_REC + L, lane) = lds_rec_off(lane_of[i]);  // (the two idle lanes of a slot: the zero record, below)
           if (i != 0) {
             const int pi = d.parent[i];
             if (children[pi][0] == i) {
@@ -628,7 +628,7 @@ std::string pack_model(const jxs_model_desc& d, Packed<T>& out) {
       // all-zero record: the table holds its offset, the kernel never selects an address
       for (int lane = 0; lane < G; ++lane)
         for (int L = 0; L < kRowLevels; ++L)
-          if (RI(RT_REC + L, lane) < 0) RI(RT_REC + L, lane) = lds_zero_rec(G);
+          if (RI(RT_REC + L, lane) < 0) RI(RT_REC + L, lane) = lds_zero_rec(nL);
       // [round 3] "no extra child to pull" = pull from lane 6: an idle row lane (rows 6 and 7 of a slot read the zero
       // record at every level), whose row of Ma and whose pa are zero -- the pulled values are added without a select
       // [round 3] which pulls a DPP row shift can do: every real source eight lanes up in the puller's own 16-lane row
@@ -676,7 +676,7 @@ std::string pack_model(const jxs_model_desc& d, Packed<T>& out) {
     for (int f = 0; f < RT_COUNT; ++f) {
       int v = out.rti[(size_t)lane * kRtiStride + f];
       if (f < RT_FC) {
-        if (v < 0) v = lds_zero_rec(G);  // (tables of models outside the row layout are never read)
+        if (v < 0) v = lds_zero_rec(nL) > 0 ? lds_zero_rec(nL) : 0;  // (tables of models outside the row layout are never read)
         if (v > 0xffff) return "internal: LDS record offset out of the packed range";
         rb[2 * f] = (unsigned char)(v & 0xff), rb[2 * f + 1] = (unsigned char)(v >> 8);
       } else {

@@ -104,7 +104,7 @@ JXS_HD constexpr int chunk_bytes(int G) { return G * kPtStride * 4 + G * kPtStri
 // serial chain never leaves its lanes.
 constexpr int kRowLevels = 8;     // tree levels 0..7 (deeper trees use the link-per-lane sweeps)
 constexpr int kRowExtra = 3;      // extra (non-first) children per link handled by cross-slot pulls
-constexpr int kRowRec = 68;       // LDS words per link record (multiple of 16 bytes: 128-bit accesses)
+constexpr int kRowRec = 64;       // LDS words per link record (multiple of 16 bytes: 128-bit accesses)
 enum RowI : int {
   RT_REC = 0,                         // [kRowLevels] LDS word offset of the record this row lane reads at level L:
                                       // link(L, slot)'s for its six row lanes, the all-zero record (lds_zero_rec) otherwise
@@ -130,18 +130,42 @@ JXS_HD int rti_get(const int* rec, int field) { return rti_unpack((unsigned)rec[
 //   8 r + 0..5  row r of M (6x6),  8 r + 6  pA[r],  8 r + 7  S[r]      (r < 6: what row lane r reads, two b128)
 //   48..53 S, 54..59 c                                                   (slot-uniform, three b128)
 //   60 tau, 61..63 anchor of this link's chain minus the anchor of its parent's chain (zero for first children)
-//   64 sdd (result)
-// after the G records: the base rows, 6 x 8 words {row of MA_0, pA_0[r], -}, then one all-zero record
-enum RowLds : int { RL_ROW = 0, RL_ROW_PA = 6, RL_ROW_S = 7, RL_S = 48, RL_C = 54, RL_TAU = 60, RL_DP = 61, RL_SDD = 64 };
+//   sdd (the result of pass 3) takes the place of tau, which pass 2 has read by then: the record is 64 words
+// [round 6] ONE RECORD PER LINK (lanes >= nL publish nothing) OF 64 WORDS, then kRowZero words of zeros -- 12.4 KB per
+// humanoid wave instead of 18.3 KB (one 68-word record per LANE, 48 words of base rows, a 68-word zero record).  The LDS
+// of gfx950 is handed out in granules of 1280 bytes: 12.4 KB is ten granules, TWELVE waves per CU = three per SIMD, which
+// the kernel's 150 registers allowed all along (measured residency: profiles/r06_residency.txt).
+//   * the base rows (6 x 8 words {row of MA_0, pA_0[r], -}) ALIAS the row region of record 0 -- the base link's own, read
+//     for the last time at level 0, right before the base solve writes them (program order of a one-wave workgroup);
+//   * a row lane without a link at a level reads "the record" at lds_zero_rec = Z - 48, Z = nL * kRowRec: its row group
+//     at +48 instead of +8 row (one select per level), S | c at +48, tau | dp at +60, c_r at +54 + row, its sdd store
+//     (a zero: 1 / d = 0 there) at +60 -- everything inside [Z, Z + 16).
+enum RowLds : int { RL_ROW = 0, RL_ROW_PA = 6, RL_ROW_S = 7, RL_S = 48, RL_C = 54, RL_TAU = 60, RL_DP = 61, RL_SDD = RL_TAU };
+constexpr int kRowZero = 16;  // zeros behind the records: what the lanes without a link read (and store: zeros)
 // The link kinematics staged for the contact phase ([G][kKinRec] words) ALIAS the record area: the contact phase
 // has read them back before the ABA publishes its records (a single-wave workgroup executes its LDS
 // operations in program order).  20.6 KB -> 16 KB per humanoid wave: ten waves per CU instead of seven.
 constexpr int kKinRec = 24;  // R (9), r (3), v_lin (3), v_ang (3), anchor of the link's chain (3), padding to whole 128-bit groups
 JXS_HD constexpr int lds_kin_offset(int) { return 0; }
-// records + base rows (48 words) + one all-zero record: row lanes without a link at a level read
-// zeros from it instead of selecting them (nine v_cndmask per level saved)
-JXS_HD constexpr int lds_zero_rec(int G) { return G * kRowRec + 48; }
-JXS_HD constexpr int lds_words_per_env(int G) { return (lds_zero_rec(G) + kRowRec + 3) / 4 * 4; }
+// row lanes without a link at a level read zeros instead of selecting them (nine v_cndmask per level saved): the
+// "record" they read starts 48 words before the zero area (see above)
+// Where record k starts.  A stride of 64 words would put the same word of every record into the same bank (the 24 link
+// lanes of the humanoid publish with ONE address pattern: measured +40 % at 64 Ki environments, profiles/r06_experiments.md);
+// the 68 of round 5 does not fit ten granules.  So: 64 words and a skew of four words (one 128-bit group) per PAIR of
+// records -- 13 of the 16 alignments in use for 24 records, 48 words of padding per humanoid environment.
+JXS_HD constexpr int lds_rec_off(int k) { return k * kRowRec + 4 * ((k + 1) >> 1); }
+JXS_HD constexpr int lds_zero_at(int nL) { return lds_rec_off(nL); }
+JXS_HD constexpr int lds_zero_rec(int nL) { return lds_zero_at(nL) - RL_S; }
+JXS_HD constexpr int lds_base_rows(int) { return 0; }  // the base rows: the row region of record 0
+// words per environment of the row layout of a model with nL links in groups of G lanes: the records and the zeros, or
+// the kinematics staged for the contact phase ([G][kKinRec], aliasing the records), whichever is larger
+JXS_HD constexpr int lds_rows_words(int G, int nL) {
+  const int a = lds_zero_at(nL) + kRowZero, b = G * kKinRec, c = 64;
+  return ((a > b ? (a > c ? a : c) : (b > c ? b : c)) + 3) / 4 * 4;
+}
+// upper bound over the models of a lane-group size (nL = G): where the offset of an area behind the row layout has to be
+// a compile-time constant of G (two-wave workgroups, the RungeKutta4 chunk area)
+JXS_HD constexpr int lds_words_per_env(int G) { return lds_rows_words(G, G); }
 // [round 4] RungeKutta4 with more collidable points than lanes (SoftContacts): the points of the chunks behind the first
 // go through memory at every stage (jxs_core.h contact_chunk); what RungeKutta4 carries between its stages for them --
 // the deformation rate of the previous stage (3 words) and the weighted sum of the rates (3) -- sits in the LDS

@@ -40,7 +40,21 @@ void run_group(const jxs::Packed<T>& pk, jxs::KArgs<T> a, int mode) {
   a.rti = pk.rti_packed.data();
   a.hf = pk.hf.empty() ? nullptr : pk.hf.data();
   for (int env = 0; env < a.N; ++env) {
-    jxs::HostLanes<T, G> ln(a.N, env, (size_t)std::max({jxs::rigid_lds_words_per_env(pk.P.n_cp, pk.P.rigid), jxs::rigid_lds_words_per_env(pk.P.n_cp, pk.P.rigid, pk.P.ct_tree, pk.P.n_chunks, G), jxs::duo_words_per_env(G), jxs::rk4_lds_words_per_env(G, pk.P.n_chunks)}));
+    // what the device launch of this mode allocates per environment (jxs_kernels.h launch_one)
+    const bool rigid_mode = mode == jxs::MODE_STEP_RIGID || mode == jxs::MODE_STEP_RK4_RIGID || mode == jxs::MODE_DYN_RIGID;
+    const bool rows_mode = pk.P.row_mode && (mode == jxs::MODE_STEP || mode == jxs::MODE_ROLLOUT || mode == jxs::MODE_FD || mode == jxs::MODE_DYN);
+    size_t limit = (size_t)-1;  // (modes without an LDS area of their own use it only where has_lds says so: not checked)
+    if (rigid_mode) limit = (size_t)jxs::rigid_lds_words_per_env(pk.P.n_cp, pk.P.rigid, pk.P.ct_tree, pk.P.n_chunks, G);
+    else if (mode == (jxs::MODE_STEP | 0x100)) limit = (size_t)jxs::duo_words_per_env(G);
+    else if (mode == jxs::MODE_STEP_RK4 && (pk.P.row_mode || pk.P.n_chunks > 1)) limit = (size_t)jxs::rk4_lds_words_per_env(G, pk.P.n_chunks);
+    else if (rows_mode) limit = (size_t)jxs::lds_rows_words(G, pk.P.nL);
+    jxs::HostLanes<T, G> ln(a.N, env, (size_t)std::max({jxs::rigid_lds_words_per_env(pk.P.n_cp, pk.P.rigid), jxs::rigid_lds_words_per_env(pk.P.n_cp, pk.P.rigid, pk.P.ct_tree, pk.P.n_chunks, G), jxs::duo_words_per_env(G), jxs::rk4_lds_words_per_env(G, pk.P.n_chunks)}), limit);
+    struct OobCheck {
+      const jxs::HostLanes<T, G>& l;
+      ~OobCheck() {
+        if (l.lds_oob_ >= 0) g_err = "LDS access at word " + std::to_string(l.lds_oob_) + " beyond the " + std::to_string(l.lds_limit_) + " words this launch allocates per environment";
+      }
+    } oob_check{ln};
     jxs::Core<jxs::HostLanes<T, G>> core(pk.P, a, ln);
     if (mode == (jxs::MODE_STEP | 0x100)) {
       // two-wave workgroup: the inertia wave, then the main wave, on the same LDS image

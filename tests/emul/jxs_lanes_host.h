@@ -177,8 +177,21 @@ struct HostLanes {
   int env_;
   int N_;
   mutable std::vector<T_> lds_;
-  HostLanes(int N, int env, size_t lds_words = 0)
-      : env_(env), N_(N), lds_(std::max((size_t)G_ * kRowRec + 64 + G_, lds_words), T_(0)) {}
+  // `lds_limit`: the words per environment the DEVICE launch of this mode allocates -- an access beyond it is recorded
+  // (lds_oob_), which the harness turns into an error: the layout arithmetic of the kernels is checked on the CPU
+  size_t lds_limit_;
+  mutable long lds_oob_ = -1;
+  HostLanes(int N, int env, size_t lds_words = 0, size_t lds_limit = (size_t)-1)
+      : env_(env), N_(N), lds_(std::max((size_t)G_ * kRowRec + 64 + G_, lds_words), T_(0)), lds_limit_(lds_limit) {}
+  // LDS writes of the lanes inside `m` only (device: one exec-masked region around the writes)
+  mutable bool region_on_ = false;
+  mutable VM region_;
+  template <class F>
+  void lds_masked(const VM& m, F&& f) const {
+    region_on_ = true, region_ = m;
+    f();
+    region_on_ = false;
+  }
   void dbg_store(T* out, int stride, int idx, const V& v, const VM& mask) const {
     for (int i = 0; i < G; ++i)
       if (mask.v[i]) out[(size_t)env_ * stride + idx] = v.v[i];
@@ -304,16 +317,20 @@ struct HostLanes {
   }
   static unsigned pin(unsigned x) { return x; }
   static int pin(int x) { return x; }
+  void lds_touch(int a) const {
+    if (a < 0 || (size_t)a >= lds_limit_) lds_oob_ = a;
+  }
   void lds_write(const VI& addr, const V& v) const {
-    for (int i = 0; i < G; ++i) lds_[addr.v[i]] = v.v[i];
+    for (int i = 0; i < G; ++i)
+      if (!region_on_ || region_.v[i]) lds_touch(addr.v[i]), lds_[addr.v[i]] = v.v[i];
   }
   void lds_write(const VI& addr, const V& v, const VM& mask) const {
     for (int i = 0; i < G; ++i)
-      if (mask.v[i]) lds_[addr.v[i]] = v.v[i];
+      if (mask.v[i] && (!region_on_ || region_.v[i])) lds_touch(addr.v[i]), lds_[addr.v[i]] = v.v[i];
   }
   V lds_read(const VI& addr) const {
     V r;
-    for (int i = 0; i < G; ++i) r.v[i] = lds_[addr.v[i]];
+    for (int i = 0; i < G; ++i) lds_touch(addr.v[i]), r.v[i] = lds_[addr.v[i]];
     return r;
   }
   template <int N>

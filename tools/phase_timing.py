@@ -78,3 +78,22 @@ if out[:, 11].any():  # placement of the waves: HW_ID (wave 3:0, simd 5:4, cu 11
         same_simd = sum(1 for a, b in zip(ids[0], ids[1]) if place(int(a)) == place(int(b)))
         same_cu = sum(1 for a, b in zip(ids[0], ids[1]) if place(int(a))[0] == place(int(b))[0])
         print(f"  two-wave workgroups: {same_cu} of {blocks} on one CU (must be all), {same_simd} with both waves on the same SIMD")
+
+    # [round 6] residency: the largest number of waves of this launch that were on one SIMD / one CU at the same time
+    # (a wave is resident from its first stamp to its last).  VERDICT r5 weak 3: "prove residency, not just time".
+    def max_overlap(intervals):
+        ev = sorted([(a, 1) for a, _ in intervals] + [(b, -1) for _, b in intervals], key=lambda e: (e[0], e[1]))
+        cur = best = 0
+        for _, d in ev:
+            cur += d
+            best = max(best, cur)
+        return best
+    per_simd, per_cu = {}, {}
+    for h, a, b in zip(out[:, 11], out[:, 0], out[:, 10]):
+        cu, sd = place(int(h))
+        per_simd.setdefault((cu, sd), []).append((int(a), int(b)))
+        per_cu.setdefault(cu, []).append((int(a), int(b)))
+    ov_s = np.array([max_overlap(v) for v in per_simd.values()])
+    ov_c = np.array([max_overlap(v) for v in per_cu.values()])
+    slots = sorted({int(h) & 15 for h in out[:, 11]})
+    print(f"  residency: waves resident at once per SIMD: max {ov_s.max()}, mean of the per-SIMD maxima {ov_s.mean():.2f}; per CU: max {ov_c.max()}, mean {ov_c.mean():.2f}; wave slots seen {slots}")
