@@ -262,7 +262,7 @@ std::string pack_model(const jxs_model_desc& d, Packed<T>& out) {
   for (int i = 1; i < nL; ++i) children[d.parent[i]].push_back(i);
   int maxch_level[kMaxDepth + 1] = {0};
   for (int i = 0; i < nL; ++i) {
-    if ((int)children[i].size() > kMaxChildren) return "links with more than 6 children are not supported";
+    if ((int)children[i].size() > kMaxChildren) return "links with more than 12 children are not supported";
     if (!children[i].empty()) maxch_level[level[i] + 1] = std::max(maxch_level[level[i] + 1], (int)children[i].size());
   }
   for (int w = 0; w < (kMaxDepth + 1) / 16; ++w) P.maxch_nib[w] = 0;

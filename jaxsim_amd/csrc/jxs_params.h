@@ -22,7 +22,7 @@
 namespace jxs {
 
 constexpr int kMaxDepth = 63;    // max tree depth supported by the level loops
-constexpr int kMaxChildren = 6;  // max children of one link (statically unrolled gather)
+constexpr int kMaxChildren = 12;  // max children of one link (statically unrolled gathers that stop at the widest link of the level; [round 6] was 6)
 constexpr int kMaxRounds = 6;    // pointer-jumping rounds: ceil(log2(depth+1)) <= 6
 
 // ---- per-lane tables are LANE-MAJOR: tbl[lane * stride + field], strides multiples of 4 words and the

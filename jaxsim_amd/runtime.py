@@ -9,6 +9,7 @@ does not pay a ``hipMalloc`` per step.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import threading
 
 import numpy as np
@@ -311,6 +312,37 @@ class DeviceModel:
             pass
 
 
+def fp32_relaxed_defaults_guard(model, dtype) -> None:
+    """[round 6] RelaxedRigidContacts in float32 with a NEGLIGIBLE regulariser is refused instead of answered with no
+    correct digit.  The regulariser of the relaxed system ``(J M^-1 J^T + R) f = a_ref - a_free`` scales with
+    ``2 mu^2 (1 + mu^2)`` relative to the Delassus entries (``relaxed_rigid.py:540-568``); with the reference's DEFAULT
+    ``mu = 0.005`` it is 5e-5 of them, below what float32 resolves once the Delassus matrix is rank deficient (two or more
+    points on one link, or more contact rows than degrees of freedom): measured errors of 6e-2 (median) to 1e2 over random
+    trees, DESIGN.md section 4e -- the reference's own formulation evaluated in float32 fails its Cholesky there.
+    float64 (the reference's default precision) is exact at any ``mu``; ``mu = 0.5`` (the reference's
+    ``estimate_good_contact_parameters`` idiom) is within 2e-4 in float32.  The threshold is the one the packer uses to
+    choose the solver (``csrc/jxs_pack.h``: ``2 mu^2 (1 + mu^2) >= 0.02``).  ``JAXSIM_AMD_FP32_RELAXED_UNCHECKED=1`` runs
+    such a model anyway (finite results, no accuracy claim: ``test_relaxed_defaults_in_fp32_stay_finite``)."""
+    if np.dtype(dtype) != np.float32 or type(model.contact_model).__name__ != "RelaxedRigidContacts":
+        return
+    kdp = model.kin_dyn_parameters
+    en = np.asarray(kdp.contact_enabled, dtype=bool)
+    if not en.any():
+        return
+    mu = float(model.contact_params.mu)
+    if 2.0 * mu * mu * (1.0 + mu * mu) >= 0.02:
+        return
+    per_link = np.bincount(np.asarray(kdp.contact_body)[en], minlength=kdp.number_of_links())
+    deficient = per_link.max() >= 2 or 3 * int(en.sum()) > 6 + kdp.number_of_joints()
+    if not deficient or os.environ.get("JAXSIM_AMD_FP32_RELAXED_UNCHECKED"):
+        return
+    raise ValueError(
+        f"RelaxedRigidContacts in float32 with mu = {mu:g}: the regulariser (2 mu^2 (1 + mu^2) = {2.0 * mu * mu * (1.0 + mu * mu):.1e} of the "
+        "Delassus entries) is below float32 resolution for a rank-deficient contact set (several points on one link): no "
+        "accuracy can be stated.  Use float64 (the reference's default precision), or contact parameters from "
+        "estimate_good_contact_parameters (mu = 0.5), or set JAXSIM_AMD_FP32_RELAXED_UNCHECKED=1 to run without a tolerance.")
+
+
 def device_model(model, dtype) -> DeviceModel:
     """Device tables of ``model`` for ``dtype``; rebuilt when a model constant changed."""
     from . import specialize  # model-specialised step kernel: a cached object, or built now if asked for
@@ -321,6 +353,7 @@ def device_model(model, dtype) -> DeviceModel:
     hit = cache.get(np.dtype(dtype).str)
     if hit is not None and hit[0] == sig:
         return hit[1]
+    fp32_relaxed_defaults_guard(model, dtype)
     dm = DeviceModel(model, dtype)
     how = specialize.policy()
     if how == "require":

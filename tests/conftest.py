@@ -19,6 +19,10 @@ for p in (str(ROOT), str(ROOT / "tests")):
 # python -m pytest tests -m gpu, on the GPU box; tools/gpu/r04_record_manifest.sh).  No test waits for a compiler, and a
 # kernel never changes between two calls a test compares bitwise.  Outside the fixture (CPU tests) 'cached' is pinned.
 os.environ.setdefault("JAXSIM_AMD_SPECIALIZE", "cached")
+# [round 6] RelaxedRigidContacts in float32 with the reference's bare default mu = 0.005 is REFUSED by the product
+# (jaxsim_amd/runtime.py fp32_relaxed_defaults_guard: no accuracy can be stated).  The suite keeps its "finite, noise-limited"
+# and resting-box checks of exactly that configuration, so it opts out -- tests/test_host_logic.py checks the refusal itself.
+os.environ.setdefault("JAXSIM_AMD_FP32_RELAXED_UNCHECKED", "1")
 KERNEL_POLICIES = {"library": "0", "specialised": "cached" if os.environ.get("JAXSIM_AMD_TEST_RECORD") else "require"}
 
 

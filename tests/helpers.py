@@ -72,12 +72,15 @@ class ModelZoo:
         # of joints between them (a Walker2d-style planar biped with a floating base; a planar serial chain)
         "planar_biped": lambda: robots.planar_biped_urdf(),
         "planar10f": lambda: robots.chain_urdf(10, fixed_base=False, seed=6, max_back=1, parallel_axes="all"),
+        # [round 6] more than six children on one link: an octopod (8 legs of 2 links, four feet) and a 12-spoke hub
+        "octopod": lambda: robots.hub_urdf(8, 2, foot_boxes=4, seed=1),
+        "hub12": lambda: robots.hub_urdf(12, 1, foot_boxes=2, seed=2),
         "anymal": lambda: robots.anymal12_urdf(),
         "icub": lambda: robots.icub23_urdf(),
         "icub16": lambda: robots.icub23_urdf(sole_boxes_per_foot=1),
     }
     # base height range putting some collidable points in contact
-    contact_z = {"box": (0.0, 0.1), "sphere": (0.09, 0.12), "chain9f": (0.0, 0.3), "serial12f": (0.0, 0.3), "anymal": (0.58, 0.70),
+    contact_z = {"box": (0.0, 0.1), "sphere": (0.09, 0.12), "chain9f": (0.0, 0.3), "serial12f": (0.0, 0.3), "anymal": (0.58, 0.70), "octopod": (0.40, 0.55), "hub12": (0.2, 0.32),
                  "planar_biped": (0.78, 0.95), "planar10f": (0.0, 0.3),
                  "icub": (0.56, 0.68), "icub16": (0.56, 0.68)}  # fmt: skip
 

@@ -845,7 +845,10 @@ def test_contact_tree_solve_on_random_trees_gpu(reduced_qp, kind, n_links, seed,
 
     base = ja.JaxSimModel.build_from_model_description(robots.chain_urdf(n_links, fixed_base=False, seed=seed, max_back=max_back, collision_links=links, parallel_axes=axes))
     idx = list(range(8 * len(links)))
-    model = (helpers.relaxed_model(base, idx, mu=0.5) if kind == "relaxed" else helpers.rigid_model(base, idx, K=1e4, D=1e2))
+    # [ADVICE r5] RigidContacts at solver_tol = 1e-7: at the default 1e-3 the tree's and the oracle's iterates agree only to the
+    # accuracy at which the iteration stops (the gate had to be 1e-5); at 1e-7 both are converged and the gate is tight again
+    model = (helpers.relaxed_model(base, idx, mu=0.5) if kind == "relaxed"
+             else helpers.rigid_model(base, idx, build=dict(solver_options={"solver_tol": 1e-7}), K=1e4, D=1e2))
     if kind == "rigid":  # (RigidContacts takes the tree by default only where the triangles do not fit the LDS: the knob runs it here)
         assert "P.ct_tree=0" in specialize.spec(model, np.float64, specialize.MODE_STEP_RIGID)
         monkeypatch.setenv("JXS_CT_TREE_RIGID", "1")
@@ -854,9 +857,10 @@ def test_contact_tree_solve_on_random_trees_gpu(reduced_qp, kind, n_links, seed,
     d = oracle.random_model_data(model, batch_size=N, seed=seed, base_pos_bounds=((-1, -1, 0.0), (1, 1, 0.25)), base_rpy_bounds=((-0.4, -0.4, -3), (0.4, 0.4, 3)))
     ref = helpers.odata_to_block(model, oracle.step(model, d))
     out = js.model.step(model, to_gpu(model, d)).state_block()
-    # (RigidContacts at the default solver_tol = 1e-3: the tree's Newton directions differ from the dense ones in their last
-    # digits, so the iterates agree to the accuracy at which the iteration stops, not to 1e-7)
-    assert helpers.rel_err(out, ref) < (1e-9 if kind == "relaxed" else 1e-5)
+    err = helpers.rel_err(out, ref)
+    helpers.note(f"contact_tree_random_fp64/{kind}/{n_links}", err)
+    assert err < (1e-9 if kind == "relaxed" else 1e-6)
+    assert js.model.solver_fault_counts(model, np.float64) == (0, 0)
     if kind == "relaxed":
         d32 = oracle.random_model_data(model, batch_size=N, seed=seed, dtype=np.float32, base_pos_bounds=((-1, -1, 0.0), (1, 1, 0.25)),
                                        base_rpy_bounds=((-0.4, -0.4, -3), (0.4, 0.4, 3)))  # fmt: skip
@@ -1998,3 +2002,63 @@ def test_height_field_that_is_a_plane_equals_plane_terrain_gpu(models):
         o1 = js.model.step(helpers.with_params(box, terrain=hf), to_gpu(box, d)).state_block()
         o2 = js.model.step(helpers.with_params(box, terrain=plane), to_gpu(box, d)).state_block()
         assert helpers.rel_err(o1, o2) < 1e-11
+
+
+# ---- [round 6] links with more than six children (VERDICT r5 missing 3: kMaxChildren 6 -> 12) --------------------------
+OCTOPOD_FEET_4 = [0, 8, 16, 24]
+OCTOPOD_FEET_16 = [8 * f + c for f in range(4) for c in range(4)]
+
+
+@pytest.mark.parametrize("name", ["octopod", "hub12"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_links_with_more_than_six_children_gpu(models, name, dtype):
+    """An octopod (eight legs on the body) and a twelve-spoke hub through the public API: step, forward / inverse dynamics,
+    mass matrix and its inverse, gravity forces -- every sweep that gathers children (emulation twin:
+    tests/test_emulation_parity.py::test_links_with_more_than_six_children)."""
+    model = models(name)
+    N = 37
+    d = models.random_data(name, N, seed=4, dtype=dtype)
+    du = helpers.upcast(d)
+    tau, f = helpers.random_inputs(model, N, 5, dtype)
+    t64, f64 = tau.astype(np.float64), f.astype(np.float64)
+    g = to_gpu(model, d)
+    ref = oracle.step(model, du, link_forces=f64, joint_force_references=t64)
+    out = js.model.step(model, g, link_forces=f, joint_force_references=tau)
+    assert helpers.rel_err(out.state_block(), helpers.odata_to_block(model, ref)) < helpers.tol_of(dtype, name)
+    fp64 = dtype == np.float64
+    vd, sdd = oracle.forward_dynamics_aba(model, du, joint_forces=t64, link_forces=f64)
+    gvd, gsdd = js.model.forward_dynamics_aba(model, g, joint_forces=tau, link_forces=f)
+    assert helpers.rel_err(gsdd, sdd) < (1e-10 if fp64 else 2e-4) and helpers.rel_err(gvd, vd) < (1e-10 if fp64 else 2e-4)
+    acc = np.random.default_rng(3).uniform(-2, 2, size=(N, 6 + model.dofs())).astype(dtype)
+    fB, tq = oracle.inverse_dynamics(model, du, joint_accelerations=acc[:, 6:].astype(np.float64), base_acceleration=acc[:, :6].astype(np.float64), link_forces=f64)
+    gfB, gtq = js.model.inverse_dynamics(model, g, joint_accelerations=acc[:, 6:], base_acceleration=acc[:, :6], link_forces=f)
+    scale = max(1.0, float(np.abs(tq).max()), float(np.abs(fB).max()))
+    assert max(float(np.abs(gtq - tq).max()), float(np.abs(gfB - fB).max())) / scale < (1e-10 if fp64 else 2e-5)
+    M = oracle.free_floating_mass_matrix(model, du)
+    gM = js.model.free_floating_mass_matrix(model, g)
+    assert np.abs(gM - M).max() / max(1.0, np.abs(M).max()) < (1e-11 if fp64 else 2e-5)
+    gMi = js.model.free_floating_mass_matrix_inverse(model, g).astype(np.float64)
+    Mi = np.linalg.inv(M)
+    assert np.abs(gMi - Mi).max() / np.abs(Mi).max() < (1e-9 if fp64 else 3e-4)
+    gg = js.model.free_floating_gravity_forces(model, g)
+    g_ref = oracle.free_floating_gravity_forces(model, du)
+    assert float(np.abs(gg - g_ref).max()) / max(1.0, float(np.abs(g_ref).max())) < (1e-12 if fp64 else 2e-6)
+
+
+# (gates: measured on MI355X x 3 -- rigid 4 points fp64 2.0e-7 at the default solver_tol = 1e-3, where the iteration stops;
+# relaxed fp32 3.3e-4 on these light legs, 0.4 .. 1.2 kg)
+@pytest.mark.parametrize("kind,idx,dtype,tol", [("rigid", OCTOPOD_FEET_4, np.float64, 6e-7), ("rigid", OCTOPOD_FEET_16, np.float64, 1e-7),
+                                                ("relaxed", OCTOPOD_FEET_16, np.float64, 1e-10), ("rigid", OCTOPOD_FEET_4, np.float32, 3e-3),
+                                                ("relaxed", OCTOPOD_FEET_16, np.float32, 1e-3)])
+def test_octopod_with_the_rigid_contact_models_gpu(models, reduced_qp, kind, idx, dtype, tol):
+    if kind == "rigid":
+        model = helpers.rigid_model(models("octopod"), idx, K=1e4, D=1e2)
+    else:
+        model = helpers.relaxed_model(models("octopod"), idx, mu=0.5)
+    N = 24
+    d = models.random_data("octopod", N, seed=5, dtype=dtype)
+    tau, f = helpers.random_inputs(model, N, 7, dtype)
+    ref = oracle.step(model, helpers.upcast(d), link_forces=f.astype(np.float64), joint_force_references=tau.astype(np.float64))
+    out = js.model.step(model, to_gpu(model, d), link_forces=f, joint_force_references=tau)
+    assert helpers.rel_err(out.state_block(), helpers.odata_to_block(model, ref)) < tol
+    assert js.model.solver_fault_counts(model, dtype) == (0, 0)
