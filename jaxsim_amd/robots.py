@@ -355,6 +355,44 @@ def hub_urdf(n_legs: int = 8, links_per_leg: int = 2, foot_boxes: int = 4, seed:
     return "".join(out)
 
 
+def lumped_tree_urdf(n_links: int = 7, seed: int = 0, fixed_base: bool = False) -> str:
+    """Random tree whose every moving link carries one or two MASSIVE bodies on FIXED joints (sensor boxes, covers: offset,
+    rotated joint frame, rotated inertial frame) and a massless leaf frame: the lumping rule of the parser
+    (``kinematic_graph.py:379-611``: I += X^T I_removed X) under test -- tests/maxcoord.py treats the same fixed joints as
+    six constraints between separate bodies and never lumps."""
+    rng = np.random.default_rng(seed)
+    out = ['<robot name="lumped_tree">']
+    if fixed_base:
+        out.append('<link name="world"/>')
+
+    def body(name):
+        m = float(rng.uniform(0.3, 2.0))
+        com = tuple(float(v) for v in rng.uniform(-0.08, 0.08, 3))
+        dims = tuple(float(v) for v in rng.uniform(0.05, 0.25, 3))
+        rpy = tuple(float(v) for v in rng.uniform(-0.6, 0.6, 3))
+        return f'<link name="{name}">' + _inertial(m, com=com, I=_box_inertia(m, *dims), rpy=rpy) + "</link>"
+
+    for i in range(n_links):
+        out.append(body(f"link{i:02d}"))
+        for k in range(int(rng.integers(1, 3))):
+            out.append(body(f"link{i:02d}_payload{k}"))
+            out.append(_joint(f"link{i:02d}_mount{k}", "fixed", f"link{i:02d}", f"link{i:02d}_payload{k}",
+                              tuple(float(v) for v in rng.uniform(-0.15, 0.15, 3)), (0, 0, 0), rpy=tuple(float(v) for v in rng.uniform(-1.0, 1.0, 3))))
+        out.append(f'<link name="link{i:02d}_frame"/>')
+        out.append(_joint(f"link{i:02d}_frame_joint", "fixed", f"link{i:02d}", f"link{i:02d}_frame", (0.05, 0.0, 0.1), (0, 0, 0), rpy=(0.1, 0.2, 0.3)))
+    if fixed_base:
+        out.append(_joint("world_to_base", "fixed", "world", "link00", (0, 0, 0), (0, 0, 0)))
+    for i in range(1, n_links):
+        parent = int(rng.integers(max(0, i - 3), i))
+        jt = "prismatic" if rng.uniform() < 0.25 else "revolute"
+        axis = rng.normal(size=3)
+        axis = tuple(float(v) for v in axis / np.linalg.norm(axis))
+        out.append(_joint(f"joint{i:02d}", jt, f"link{parent:02d}", f"link{i:02d}", tuple(float(v) for v in rng.uniform(-0.3, 0.3, 3)), axis,
+                          rpy=tuple(float(v) for v in rng.uniform(-1.0, 1.0, 3)), lower=-1.5, upper=1.5))
+    out.append("</robot>")
+    return "".join(out)
+
+
 def chain_urdf(n_links: int = 5, fixed_base: bool = True, seed: int = 0, max_back: int = 3, collision_links=None,
                parallel_axes: str | None = None, base_offset=(0.1, -0.2, 0.5)) -> str:
     """Random serial/branching chain with mixed revolute/prismatic joints, skewed axes and
