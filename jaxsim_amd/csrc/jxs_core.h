@@ -871,7 +871,7 @@ struct Core {
         }
   #pragma unroll
         for (int k = 1; k < kMaxChildren; ++k) {
-          if (k >= nch) break;  // (wave-uniform: the copies beyond the widest link of the level cost nothing)
+          if (k >= P.max_children) break;  // (the widest link of the MODEL: a constant of a model-specialised kernel -- no copies, no child registers beyond it; the level's own width is tested below)
           if (k < nch) {
             // 1.0 where this lane is a parent of the current level with a k-th child, else 0.0
             const V okf = vsel(is_par && (child[k] >= 0), V(T(1)), V(T(0)));
@@ -2549,7 +2549,7 @@ struct Core {
       }
 #pragma unroll
       for (int k = 1; k < kMaxChildren; ++k) {
-        if (k >= nch) break;  // (wave-uniform: the copies beyond the widest link of the level cost nothing)
+        if (k >= P.max_children) break;  // (the widest link of the MODEL: a constant of a model-specialised kernel -- no copies, no child registers beyond it; the level's own width is tested below)
         if (k < nch) {
           const VM ok = is_par && (child[k] >= 0);
           V g3[3];
@@ -2634,7 +2634,7 @@ struct Core {
       }
 #pragma unroll
       for (int k = 1; k < kMaxChildren; ++k) {
-        if (k >= nch) break;  // (wave-uniform: the copies beyond the widest link of the level cost nothing)
+        if (k >= P.max_children) break;  // (the widest link of the MODEL: a constant of a model-specialised kernel -- no copies, no child registers beyond it; the level's own width is tested below)
         if (k < nch) {
           const VM ok = is_par && (child[k] >= 0);
           V g6[6];
@@ -2696,7 +2696,7 @@ struct Core {
       }
 #pragma unroll
       for (int k = 1; k < kMaxChildren; ++k) {
-        if (k >= nch) break;  // (wave-uniform: the copies beyond the widest link of the level cost nothing)
+        if (k >= P.max_children) break;  // (the widest link of the MODEL: a constant of a model-specialised kernel -- no copies, no child registers beyond it; the level's own width is tested below)
         if (k < nch) {
           const V okf = vsel(is_par && (child[k] >= 0), V(T(1)), V(T(0)));
           V g[21];

@@ -62,6 +62,7 @@ std::string kernel_spec_string(const Packed<T>& pk, int mode) {
   add("any_suc", P.any_suc), add("any_pri", P.any_pri), add("has_base_off", P.has_base_off), add("seg_dpp_ok", P.seg_dpp_ok), add("row_mode", P.row_mode);
   add("row_cross_levels", P.row_cross_levels, true), add("row_ppull_levels", P.row_ppull_levels, true);
   add("row_pull_counts", P.row_pull_counts, true), add("row_pull_dpp", P.row_pull_dpp, true), add("child_off", P.child_off, true), add("nonadj_levels", P.nonadj_levels, true);
+  add("max_children", P.max_children);
   for (int k = 0; k < (int)(sizeof(P.maxch_nib) / sizeof(P.maxch_nib[0])); ++k) {
     char nm[32];
     std::snprintf(nm, sizeof nm, "maxch_nib[%d]", k);
@@ -267,6 +268,8 @@ std::string pack_model(const jxs_model_desc& d, Packed<T>& out) {
   }
   for (int w = 0; w < (kMaxDepth + 1) / 16; ++w) P.maxch_nib[w] = 0;
   for (int L = 0; L <= kMaxDepth; ++L) P.maxch_nib[L / 16] |= (unsigned long long)maxch_level[L] << ((L % 16) * 4);
+  P.max_children = 0;
+  for (int L = 0; L <= kMaxDepth; ++L) P.max_children = std::max(P.max_children, maxch_level[L]);
   // depth-first pre-order lane assignment: first child of lane j is lane j+1
   std::vector<int> lane_of(nL, -1), link_of;
   {

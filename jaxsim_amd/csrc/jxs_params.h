@@ -251,6 +251,9 @@ struct KParams {
   // maxch(L): max #children (at level L) of any link at level L-1, 4 bits per level
   unsigned long long maxch_nib[(kMaxDepth + 1) / 16];
   unsigned long long nonadj_levels;  // bit L: some link at level L has its parent in a lane != lane-1
+  int max_children;                  // [round 6] the widest link of the model (max over the nibbles above): a model-specialised kernel
+                                     // keeps max_children child lanes in registers, not kMaxChildren (six more registers cost the rigid
+                                     // contact kernels, which spill already, 6 - 23 %: profiles/r06_experiments.md)
   int seg_dpp_ok;                    // every (chunk, link) point segment lies inside one 16-lane row
   int row_mode;                      // 1: ABA passes run row-distributed (tables in KArgs::rti)
   unsigned int row_cross_levels;     // bit L: some parent pulls an extra child of level L across slots

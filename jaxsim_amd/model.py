@@ -278,7 +278,7 @@ class RelaxedRigidContacts:
     from the regularised linear system ``(J M^-1 J^T + R) f = a_ref - a_free``, no velocity reset.
     ``solver_options`` keeps the reference's L-BFGS keys (``tol``, ``maxiter``, ``memory_size``,
     ``scale_init_precond``); the device solves the system the reference hands to
-    ``custom_linear_solve`` directly, so they select nothing."""
+    ``custom_linear_solve`` directly, so they select nothing (HISTORY.md section 4e)."""
 
     _solver_options_keys: tuple = ("tol", "maxiter", "memory_size", "scale_init_precond")
     _solver_options_values: tuple = (1e-6, 50, 10, False)
@@ -304,7 +304,7 @@ class IntegratorType(enum.IntEnum):
     """``IntegratorType`` (``src/jaxsim/api/model.py:32-40``); values are the C-ABI enum.
     ``RungeKutta4Fast`` (``api/integrators.py:170-276``: contact forces and position derivatives frozen
     at the initial state) is built for RigidContacts / RelaxedRigidContacts, where the reference's version
-    is well defined."""
+    is well defined (HISTORY.md section 4c)."""
 
     SemiImplicitEuler = 0
     RungeKutta4 = 1

@@ -318,7 +318,7 @@ def fp32_relaxed_defaults_guard(model, dtype) -> None:
     ``2 mu^2 (1 + mu^2)`` relative to the Delassus entries (``relaxed_rigid.py:540-568``); with the reference's DEFAULT
     ``mu = 0.005`` it is 5e-5 of them, below what float32 resolves once the Delassus matrix is rank deficient (two or more
     points on one link, or more contact rows than degrees of freedom): measured errors of 6e-2 (median) to 1e2 over random
-    trees, DESIGN.md section 4e -- the reference's own formulation evaluated in float32 fails its Cholesky there.
+    trees, HISTORY.md section 4e -- the reference's own formulation evaluated in float32 fails its Cholesky there.
     float64 (the reference's default precision) is exact at any ``mu``; ``mu = 0.5`` (the reference's
     ``estimate_good_contact_parameters`` idiom) is within 2e-4 in float32.  The threshold is the one the packer uses to
     choose the solver (``csrc/jxs_pack.h``: ``2 mu^2 (1 + mu^2) >= 0.02``).  ``JAXSIM_AMD_FP32_RELAXED_UNCHECKED=1`` runs

@@ -581,7 +581,7 @@ def test_relaxed_step_fp32(models, key, tol):
     """fp32 kernel arithmetic against the fp64 oracle on the same (fp32-representable) inputs.  box4 runs
     the bare default mu = 0.005: the regulariser sits at the fp32 rounding level of the Delassus entries
     (condition ~1e6..1e7), the result is noise-limited at 1e-2 .. 1e-1 whatever the solver does -- the fp32
-    NumPy restatement is 3e-2 away from fp64 there (use fp64 or the estimated
+    NumPy restatement is 3e-2 away from fp64 there (HISTORY.md section 4e: use fp64 or the estimated
     parameters, mu = 0.5, with fp32)."""
     model, d32 = _relaxed_case(models, key, 16, seed=5, dtype=np.float32)
     tau, f = helpers.random_inputs(model, 16, 7, np.float32)
@@ -606,7 +606,7 @@ def test_standing_on_every_sole_point(models, reduced_qp, kind, name, idx, dtype
     straight legs is left out for that model: the stance is a kinematic singularity, the contact Jacobian
     has a singular value at 1e-7 .. 1e-14 of the largest (measured), and whether the impact removes the
     velocity along it is decided by the rcond of the reference's SVD -- a knife edge, not a parity
-    statement; in fp32 that direction is below the rounding level altogether."""
+    statement (HISTORY.md section 4d); in fp32 that direction is below the rounding level altogether."""
     if kind == "relaxed":
         model = helpers.relaxed_model(models(name), idx, mu=0.5)
     else:

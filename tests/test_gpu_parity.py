@@ -1028,7 +1028,7 @@ def test_relaxed_step_matches_oracle_gpu(models, key):
 def test_relaxed_defaults_in_fp32_stay_finite_gpu(models):
     """[round 4] RelaxedRigidContacts with the reference's default parameters (mu = 0.005) in fp32 with every sole point
     of the humanoid active: the regulariser sits below the fp32 rounding of a Delassus matrix of rank 12 in 96
-    unknowns -- no fp32 solver has the digits (use fp64, or the estimated parameters).  Up to round 3
+    unknowns -- no fp32 solver has the digits (HISTORY.md 4e: use fp64, or the estimated parameters).  Up to round 3
     the factorisation floored its pivots and the refinement diverged: NON-FINITE states.  Now pivots at the rounding
     floor are dropped and the refinement keeps a correction only if it reduced the residual: finite states, a few
     per cent away from fp64 -- and fp64 (solved in the tree) is exact."""
@@ -1062,7 +1062,7 @@ def test_relaxed_bare_default_parameters_fp32_gpu(models):
     points of one rigid body in contact the converged solution carries internal forces of 1e6 N on a
     1 kg box (measured) and sits at the fp32 rounding level -- the result is noise-limited (worst
     environment 2e-1, the fp32 NumPy restatement 3e-2).  Finite everywhere and right for the typical
-    environment is what can be asserted; DESIGN.md section 4e says to use fp64 or the estimated
+    environment is what can be asserted; HISTORY.md section 4e says to use fp64 or the estimated
     parameters (mu = 0.5) instead."""
     model = helpers.relaxed_model(models("box"), [0, 1, 2, 3])
     d = models.random_data("box", 40, seed=5, dtype=np.float32)
@@ -1801,12 +1801,13 @@ def _check_dynamics(model, d, tau, f, dtype, tol):
     return ref_W, aux, gcs, md
 
 
-@pytest.mark.parametrize("name", ALL)
+# (every model in the inertial representation; the three representations on the four models with contacts -- no skips)
+DYN_NAME_REP = [(n, VelRepr.Inertial) for n in ALL] + [(n, r) for n in ("box", "chain9f", "anymal", "icub") for r in (VelRepr.Body, VelRepr.Mixed)]
+
+
+@pytest.mark.parametrize("name,rep", DYN_NAME_REP)
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
-@pytest.mark.parametrize("rep", [VelRepr.Inertial, VelRepr.Body, VelRepr.Mixed])
 def test_system_dynamics_matches_oracle_gpu(models, name, dtype, rep):
-    if rep != VelRepr.Inertial and name not in ("box", "chain9f", "anymal", "icub"):
-        pytest.skip("the three representations are covered on the four contact models")
     model = models(name)
     N = 70  # not a multiple of the environments per wave
     d = models.random_data(name, N, seed=4, dtype=dtype, rep=rep)

@@ -1,7 +1,7 @@
 """Developer tool: time BASELINE.json config 5 on one GPU -- synthetic ANYmal-like quadruped
 (13 links, 12 DoF), RigidContacts, tau = RNEA gravity term recomputed every step on the device,
 fp32, batch 4096.  Not the headline benchmark (bench.py measures config 3); the numbers feed
-DESIGN.md section 6.
+HISTORY.md section 6.
 
     python tools/bench_c5.py [--points 4|16] [--envs 4096] [--steps 200] [--contact rigid|relaxed]
 

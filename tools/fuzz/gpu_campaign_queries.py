@@ -12,7 +12,7 @@ API (`js.model.*`, the reference's names):
 
 fp64 gates are constants; an fp32 quantity is held to max(constant, 3 x what the REFERENCE'S formulation loses when the
 oracle evaluates it on float32 arrays) -- on random trees of light links the conditioning of a quantity is the model's.
-Known and listed by `run`: forward dynamics in fp32 on random trees of 15 to 40 links is up to
+Known and listed by `run` (HISTORY.md section 5 / 9): forward dynamics in fp32 on random trees of 15 to 40 links is up to
 100 x less accurate than the reference's link-coordinate formulation (4.9e-4 against 5e-6 in the worst of 600 trees): a
 first-child chain has ONE reference point (its leaf, section 4f), up to metres away from the joint axes near its head.
 The gate of FD in fp32 is the general fp32 tolerance (1e-3) for that reason; the cases are printed, not hidden.

@@ -16,7 +16,7 @@ rocprofv3 --output-format csv --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WA
   -d "$OUT/pmc_sq" -- $B > "$OUT/pmc_sq.log" 2>&1
 rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/c5" -- python "$R/tools/bench_c5.py" > "$OUT/c5.log" 2>&1
 rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/c5_relaxed" -- python "$R/tools/bench_c5.py" --contact relaxed --points 16 > "$OUT/c5_relaxed.log" 2>&1
-# the reference's own step-benchmark idiom: humanoid, all 32 points, RelaxedRigidContacts with estimated parameters (link space)
+# the reference's own step-benchmark idiom: humanoid, all 32 points, RelaxedRigidContacts with estimated parameters (link space, HISTORY.md 4m)
 rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/relaxed_humanoid" -- python "$R/tools/bench_c5.py" --contact relaxed --points 32 --envs 1024 > "$OUT/relaxed_humanoid.log" 2>&1
 cd "$R"
 python bench.py > "$OUT/bench_N1.json" 2> "$OUT/bench_N1.err"
