@@ -49,9 +49,18 @@ def kernel_source_sha():
     return h.hexdigest()[:16]
 
 
+def _pmc_tags():
+    """The rounds that committed a PMC record (profiles/rNN_pmc.json), newest first."""
+    import glob
+    import re
+
+    tags = [m.group(1) for m in (re.match(r"(r\d+)_pmc\.json$", os.path.basename(p)) for p in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json"))) if m]
+    return sorted(tags, reverse=True)
+
+
 def profiled_traffic(model_name, n_envs, dtype_name):
     """(bytes per launch | None, note) for the configuration that was profiled."""
-    for tag in ("r05", "r04", "r03", "r02", "r01"):
+    for tag in _pmc_tags():
         try:
             with open(os.path.join(ROOT, "profiles", f"{tag}_pmc.json")) as f:
                 prof = json.load(f)
@@ -70,7 +79,7 @@ def profiled_traffic(model_name, n_envs, dtype_name):
 def profiled_config5_traffic():
     """HBM-side bytes per launch of the config-5 step kernel (tools/profile_round.sh c5_pmc_* passes), or None when the
     committed profile was taken on other kernel sources."""
-    for tag in ("r05", "r04", "r03"):
+    for tag in _pmc_tags():
         try:
             with open(os.path.join(ROOT, "profiles", f"{tag}_pmc.json")) as f:
                 prof = json.load(f)

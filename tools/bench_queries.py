@@ -88,3 +88,53 @@ for dtype in (np.float32, np.float64):
         kb = rows_moved * sz / 1e3
         gbs = rows_moved * sz * N / (us * 1e-6) / 1e9
         print(f"  {name:44s} {np.dtype(dtype).name[-2:]:>5s} {us:10.2f} {N / us:9.1f} {kb:11.2f} {gbs:8.1f} {100 * gbs / 8000:6.2f}")
+
+# [round 6] the reference's three contact-model benchmarks (tests/test_benchmark.py:103-139): js.ode.system_dynamics on the humanoid
+# with SoftContacts / RigidContacts / RelaxedRigidContacts and estimate_good_contact_parameters -- ONE launch each here
+# (jxs_system_dynamics: contact forces, per-link sums, ABA, position derivatives), and js.contact.link_contact_forces alone
+import jaxsim_amd as ja  # noqa: E402
+import jaxsim_amd.api as js  # noqa: E402
+
+print(f"# system_dynamics / link_contact_forces (tests/test_benchmark.py:103-139), {args.model} synthetic humanoid with all its sole points, estimate_good_contact_parameters, N = {N}")
+for cname, cm in (("SoftContacts", ja.SoftContacts()), ("RigidContacts", ja.RigidContacts.build()), ("RelaxedRigidContacts", ja.RelaxedRigidContacts.build())):
+    for dtype in (np.float32, np.float64):
+        m = bench.build_model(args.model)
+        m.contact_model = cm
+        m.contact_params = js.contact.estimate_good_contact_parameters(m)
+        data = bench.synthetic_state(m, N, seed=0, dtype=dtype)
+        try:
+            dm = runtime.device_model(m, dtype)
+        except Exception as exc:  # (e.g. RigidContacts with 32 points in fp64 beyond the LDS budget: reported, not hidden)
+            print(f"  {'system_dynamics, ' + cname:44s} {np.dtype(dtype).name[-2:]:>5s}  refused: {str(exc)[:90]}")
+            continue
+        from jaxsim_amd import specialize
+
+        spec = specialize.ensure_mode(dm, m, specialize.dyn_mode_of(m))  # what js.ode.system_dynamics does on its first call
+        lay = dm.layout
+        Np = (N + lay.tile - 1) // lay.tile * lay.tile
+        sz = np.dtype(dtype).itemsize
+        rows_state = data.state_block().shape[0]
+        xdot, W = C.c_void_p(), C.c_void_p()
+        _lib.check(lib.jxs_malloc(C.byref(xdot), rows_state * Np * sz), "jxs_malloc")
+        _lib.check(lib.jxs_malloc(C.byref(W), lay.n_links * 6 * Np * sz), "jxs_malloc")
+        sp = C.c_void_p(data._state.ptr)
+        for name, call, rows_moved in (
+            ("system_dynamics, " + cname + ("" if spec else " (library kernel)"), lambda: lib.jxs_system_dynamics(dm.handle, sp, None, None, 2, C.c_double(1.0), xdot, None, N, stream.handle), 2 * rows_state),
+            ("link_contact_forces, " + cname, lambda: lib.jxs_link_contact_forces(dm.handle, sp, None, None, 2, W, None, N, stream.handle), rows_state + 6 * lay.n_links),
+        ):
+            for _ in range(20):
+                _lib.check(call(), name)
+            stream.synchronize()
+            best = []
+            for _ in range(5):
+                e0, e1 = runtime.Event(), runtime.Event()
+                e0.record(stream)
+                for _ in range(args.reps):
+                    _lib.check(call(), name)
+                e1.record(stream)
+                stream.synchronize()
+                best.append(e0.elapsed_ms(e1) / args.reps * 1e3)
+            us = float(np.median(best))
+            gbs = rows_moved * sz * N / (us * 1e-6) / 1e9
+            print(f"  {name:44s} {np.dtype(dtype).name[-2:]:>5s} {us:10.2f} {N / us:9.1f} {rows_moved * sz / 1e3:11.2f} {gbs:8.1f} {100 * gbs / 8000:6.2f}")
+        lib.jxs_free(xdot), lib.jxs_free(W)
