@@ -36,7 +36,10 @@ def make_model(case):
     import jaxsim_amd as ja
     from jaxsim_amd import robots
 
-    base = ja.JaxSimModel.build_from_model_description(robots.chain_urdf(**case["tree"]))
+    if "hub" in case["tree"]:  # [round 6] a hub with seven to twelve legs: more than six children on one link
+        base = ja.JaxSimModel.build_from_model_description(robots.hub_urdf(**case["tree"]["hub"]))
+    else:
+        base = ja.JaxSimModel.build_from_model_description(robots.chain_urdf(**case["tree"]))
     kind, idx = case["kind"], case["idx"]
     if kind == "relaxed":
         model = helpers.relaxed_model(base, idx, mu=case["mu"])
@@ -48,7 +51,11 @@ def make_model(case):
         model = helpers.with_params(model, integrator=ja.IntegratorType.RungeKutta4)
     if case.get("actuation") is not None:  # position limits with spring and damper, joint friction, torque-speed curve
         model = helpers.actuation_variant(model, case["actuation"])
-    if case.get("terrain") is not None:  # a tilted ground plane
+    if case.get("terrain") is not None and case["terrain"][0] == "hf":  # [round 6] a height field: a * sin(kx x + p) cos(ky y) on a 0.1 m grid
+        _, a, kx, ky, ph = case["terrain"]
+        model = helpers.with_params(model, terrain=ja.HeightFieldTerrain.from_function(lambda x, y: a * np.sin(kx * x + ph) * np.cos(ky * y),
+                                                                                        x_range=(-2.5, 2.5), y_range=(-2.5, 2.5), spacing=0.1))
+    elif case.get("terrain") is not None:  # a tilted ground plane
         model = helpers.with_params(model, terrain=ja.PlaneTerrain.build(height=case["terrain"][0], normal=list(case["terrain"][1:])))
     return model
 
@@ -74,6 +81,11 @@ def prepare(path, seed, trials):
             cl = (n_links - 1,)
         tree = dict(n_links=n_links, fixed_base=fixed, seed=20000 + trial, max_back=int(rng.integers(1, 4)), collision_links=cl,
                     parallel_axes=[None, "all", "aligned", None][trial % 4], base_offset=(0.0, 0.0, 0.0))
+        if trial % 10 == 7:  # [round 6] every tenth tree a hub with 7 .. 12 legs (kMaxChildren = 12)
+            legs, per = int(rng.integers(7, 13)), int(rng.integers(1, 3))
+            feet = int(rng.integers(1, min(4, legs) + 1))
+            tree = dict(hub=dict(n_legs=legs, links_per_leg=per, foot_boxes=feet, seed=20000 + trial), seed=20000 + trial)
+            cl = tuple(range(feet))
         npts = 8 * len(cl)
         k = int(rng.integers(1, npts + 1)) if trial % 2 else npts
         idx = sorted(int(v) for v in rng.choice(npts, size=k, replace=False))
@@ -88,6 +100,8 @@ def prepare(path, seed, trials):
         with_inputs = bool(rng.integers(0, 2))  # joint torques and link forces (given in the data's velocity representation)
         actuation = int(20000 + trial) if rng.integers(0, 4) == 0 else None
         terrain = (float(rng.uniform(-0.05, 0.05)), float(rng.uniform(-0.3, 0.3)), float(rng.uniform(-0.3, 0.3)), 1.0) if rng.integers(0, 4) == 0 else None
+        if terrain is None and rng.integers(0, 3) == 0:  # [round 6] a quarter of the cases on a height field
+            terrain = ("hf", float(rng.uniform(0.02, 0.15)), float(rng.uniform(0.5, 3.0)), float(rng.uniform(0.5, 3.0)), float(rng.uniform(0, 6.28)))
         for dtype in (np.float64, np.float32):
             if kind == "rigid" and dtype == np.float32:
                 continue  # (fp32 RigidContacts: the gate is the model's own sensitivity, measured elsewhere: tools/fp32_error_gpu.py)
