@@ -183,7 +183,10 @@ def _prebuild_one(args):
         case = pickle.load(f)["cases"][i]
     set_knobs(case)
     model = make_model(case)
-    return [specialize.compile(model, np.dtype(case["dtype"]), mode).name for mode in specialize.modes_of(model)]  # (`require` wants every mode of the model)
+    modes = list(specialize.modes_of(model))  # (`require` wants every mode of the model ...
+    if case.get("gravcomp") is not None:      # ... and the gravity-torque kernel behind js.model.gravity_compensation_torques of the fp64 extras)
+        modes.append(specialize.MODE_GRAV)
+    return [specialize.compile(model, np.dtype(case["dtype"]), mode).name for mode in modes]
 
 
 def prebuild(path, k):
