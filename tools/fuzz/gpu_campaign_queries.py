@@ -23,8 +23,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 
-TOL64 = dict(FD=1e-8, ID=1e-9, BIAS=1e-9, GRAV=1e-10, KIN_H=1e-10, KIN_V=1e-10, CRBA=1e-10, MINV=1e-6, JAC=1e-10, JACD=1e-10, ROLLOUT=1e-7, CONTROLLED=1e-7)
-TOL32 = dict(FD=1e-3, ID=2e-4, BIAS=2e-4, GRAV=2e-5, KIN_H=2e-5, KIN_V=2e-5, CRBA=2e-5, MINV=3e-2, JAC=2e-5, JACD=2e-5, ROLLOUT=3e-3, CONTROLLED=3e-3)
+TOL64 = dict(DYN=1e-7, LCF=1e-7, FD=1e-8, ID=1e-9, BIAS=1e-9, GRAV=1e-10, KIN_H=1e-10, KIN_V=1e-10, CRBA=1e-10, MINV=1e-6, JAC=1e-10, JACD=1e-10, ROLLOUT=1e-7, CONTROLLED=1e-7)
+TOL32 = dict(DYN=1e-3, LCF=1e-3, FD=1e-3, ID=2e-4, BIAS=2e-4, GRAV=2e-5, KIN_H=2e-5, KIN_V=2e-5, CRBA=2e-5, MINV=3e-2, JAC=2e-5, JACD=2e-5, ROLLOUT=3e-3, CONTROLLED=3e-3)
 
 
 def make_model(case):
@@ -32,13 +32,53 @@ def make_model(case):
     import jaxsim_amd as ja
     from jaxsim_amd import robots
 
-    model = ja.JaxSimModel.build_from_model_description(robots.chain_urdf(**case["tree"]))
+    if "hub" in case["tree"]:  # [round 6] a hub with 7 .. 12 legs: more than six children on one link
+        model = ja.JaxSimModel.build_from_model_description(robots.hub_urdf(**case["tree"]["hub"]))
+    else:
+        model = ja.JaxSimModel.build_from_model_description(robots.chain_urdf(**case["tree"]))
     if case["soft_contact"] is not None:  # (the default K = 1e6 on 0.5 kg links is at the stability limit of the step: rollouts use a softer ground)
         K, D, mu = case["soft_contact"]
         model = helpers.with_params(model, contact_params=ja.SoftContactsParams.build(K=K, D=D, mu=mu))
     if case["rk4"]:
         model = helpers.with_params(model, integrator=ja.IntegratorType.RungeKutta4)
     return model
+
+
+def make_dyn_model(case):
+    """[round 6] The model of the DYN / LCF quantities (js.ode.system_dynamics, js.contact.link_contact_forces): the tree of the
+    case with one of the three contact models on all its points, a quarter of them on a height-field terrain."""
+    import helpers
+    import jaxsim_amd as ja
+
+    model = make_model(dict(case, rk4=False))
+    kind = case.get("dyn_kind", "soft")
+    npts = model.kin_dyn_parameters.number_of_collidable_points()
+    if kind == "relaxed" and npts:
+        model = helpers.relaxed_model(model, list(range(npts)), mu=0.5)
+    elif kind == "rigid" and npts:
+        model = helpers.rigid_model(model, list(range(npts)), K=1e4, D=1e2, build=dict(solver_options={"solver_tol": 1e-9}))
+    if case.get("dyn_hf") is not None:
+        a, kx, ky, ph = case["dyn_hf"]
+        model = helpers.with_params(model, terrain=ja.HeightFieldTerrain.from_function(lambda x, y: a * np.sin(kx * x + ph) * np.cos(ky * y),
+                                                                                        x_range=(-2.5, 2.5), y_range=(-2.5, 2.5), spacing=0.1))
+    return model
+
+
+DYN_KEYS = ("base_position", "base_quaternion", "joint_positions", "base_linear_velocity", "base_angular_velocity", "joint_velocities")
+
+
+def oracle_lcf(model, d, tau, f, oracle):
+    if oracle.refstep.is_rigid_contact_model(model):
+        from oracle import refrigid
+
+        return refrigid.link_contact_forces(model, d, link_forces=f, joint_torques=tau)[0]
+    if oracle.refstep.is_relaxed_rigid_contact_model(model):
+        from oracle import refrelaxed
+
+        return refrelaxed.link_contact_forces(model, d, link_forces=f, joint_torques=tau)[0]
+    if model.kin_dyn_parameters.number_of_collidable_points() == 0:
+        return np.zeros((d.batch_size, model.number_of_links(), 6))
+    return oracle.refstep.link_contact_forces(model, d)[0]
 
 
 def scaled(a, ref):
@@ -71,6 +111,14 @@ def truths(model, d, case, oracle, refrigid, helpers):
     for s in range(case["k"]):
         dk = oracle.step(model, dk, joint_force_references=c(tau_seq[s]))
     out["CONTROLLED"] = helpers.odata_to_block(model, dk)
+    # [round 6] system_dynamics (inertial representation whatever the data's, api/ode.py:204) and link_contact_forces
+    import dataclasses
+
+    dm = make_dyn_model(case)
+    dd = dataclasses.replace(d, velocity_representation=oracle.VelRepr.Inertial)
+    ref = oracle.refstep.system_dynamics(dm, dd, link_forces=c(f), joint_torques=c(tau))
+    out["DYN"] = np.concatenate([np.asarray(ref[k]).reshape(N, -1) for k in DYN_KEYS], -1)
+    out["LCF"] = oracle_lcf(dm, d, c(tau), c(f), oracle)
     return out
 
 
@@ -88,9 +136,18 @@ def prepare(path, seed, trials):
         cl = tuple(sorted(set(int(v) for v in rng.integers(0, n_links, size=ncl))))
         tree = dict(n_links=n_links, fixed_base=fixed, seed=40000 + trial, max_back=int(rng.integers(1, 5)), collision_links=cl,
                     parallel_axes=[None, "all", "aligned", None][trial % 4])
+        if trial % 10 == 7:  # [round 6] every tenth tree a hub with 7 .. 12 legs (kMaxChildren = 12)
+            legs = int(rng.integers(7, 13))
+            feet = int(rng.integers(0, min(3, legs) + 1))
+            tree = dict(hub=dict(n_legs=legs, links_per_leg=int(rng.integers(1, 3)), foot_boxes=feet, seed=40000 + trial), seed=40000 + trial,
+                        n_links=-1, fixed_base=False)
+            cl = tuple(range(feet))
         rep = reps[int(rng.integers(0, 3))]
         N, k = 4, int(rng.integers(2, 7))
-        base = dict(trial=trial, tree=tree, rep=rep, k=k, rk4=bool(rng.integers(0, 3) == 0), soft_contact=(2e4, 60.0, 0.6) if cl else None)
+        base = dict(trial=trial, tree=tree, rep=rep, k=k, rk4=bool(rng.integers(0, 3) == 0), soft_contact=(2e4, 60.0, 0.6) if cl else None,
+                    # (the rigid contact models refuse the world -> base offset of these fixed-base chains, DESIGN.md section 1: SoftContacts there)
+                    dyn_kind=["soft", "relaxed", "rigid"][int(rng.integers(0, 3))] if not tree["fixed_base"] else ["soft"][int(rng.integers(0, 3)) * 0],
+                    dyn_hf=(float(rng.uniform(0.02, 0.15)), float(rng.uniform(0.5, 3.0)), float(rng.uniform(0.5, 3.0)), float(rng.uniform(0, 6.28))) if (cl and rng.integers(0, 4) == 0) else None)
         for dtype in (np.float64, np.float32):
             case = dict(base, dtype=np.dtype(dtype).name)
             model = make_model(case)
@@ -125,7 +182,7 @@ def run(path, out_path):
         blob = pickle.load(f_)
     REP = {oracle.VelRepr.Inertial: ja.VelRepr.Inertial, oracle.VelRepr.Body: ja.VelRepr.Body, oracle.VelRepr.Mixed: ja.VelRepr.Mixed}
     os.environ["JAXSIM_AMD_SPECIALIZE"] = "0"  # the library's kernels (a compiler run per random tree otherwise)
-    stats, lines, nfail, widened, outliers = {}, [], 0, 0, []
+    stats, lines, nfail, widened, outliers, exploded = {}, [], 0, 0, [], 0
     for case in blob["cases"]:
         model = make_model(case)
         g = js.data.JaxSimModelData.from_state_block(model, case["state"], REP[case["rep"]])
@@ -143,16 +200,26 @@ def run(path, out_path):
         got["JAC"], got["JACD"] = J, Jd
         got["ROLLOUT"] = js.model.rollout(model, g, case["k"]).state_block()
         got["CONTROLLED"] = js.model.rollout(model, g, case["k"], joint_force_references=case["tau_seq"]).state_block()
+        dmod = make_dyn_model(case)
+        gd = js.data.JaxSimModelData.from_state_block(dmod, case["state"], REP[case["rep"]])
+        dyn = js.ode.system_dynamics(dmod, gd, link_forces=f, joint_torques=tau)
+        got["DYN"] = np.concatenate([np.asarray(dyn[k_]).reshape(4, -1) for k_ in DYN_KEYS], -1)
+        got["LCF"] = np.asarray(js.contact.link_contact_forces(dmod, gd, link_forces=f, joint_torques=tau)[0])
         errs = {q: scaled(got[q], np.asarray(case["truth"][q], dtype=np.float64)) for q in got}
         Mi = np.asarray(js.model.free_floating_mass_matrix_inverse(model, g), dtype=np.float64)
         M = np.asarray(case["truth"]["CRBA"], dtype=np.float64)
         errs["MINV"] = float(np.abs(M @ Mi - np.eye(M.shape[-1])).max())
         f32 = case["dtype"] == "float32"
         for q, e in errs.items():
-            key = (q + ("/rk4" if case["rk4"] and q in ("ROLLOUT", "CONTROLLED") else ""), case["dtype"])
+            if q in ("ROLLOUT", "CONTROLLED") and not float(np.abs(np.asarray(case["truth"][q], dtype=np.float64)).max()) < 1e4:
+                exploded += 1  # (a trajectory that explodes within k steps -- the explicit integrator on a tree of light links -- is no truth:
+                continue       #  tools/fuzz/gpu_campaign.py drops them the same way)
+            key = (q + ("/rk4" if case["rk4"] and q in ("ROLLOUT", "CONTROLLED") else "") + ("/" + case.get("dyn_kind", "soft") if q in ("DYN", "LCF") else ""), case["dtype"])
             r32 = case.get("ref32_err", {}).get(q, float("nan")) if f32 else float("nan")
             stats.setdefault(key, []).append((e, r32))
             tol = (TOL32 if f32 else TOL64)[q]
+            if q in ("DYN", "LCF") and case.get("dyn_kind") == "rigid":
+                tol = 3e-3 if f32 else 1e-5  # (RigidContacts: where the interior-point iteration stops; fp32: the rigid models' own gate)
             bound = max(tol, 3.0 * r32) if (f32 and np.isfinite(r32)) else tol
             widened += int(e < bound and not e < tol)
             if f32 and np.isfinite(r32) and e > 1e-4 and e > 30.0 * r32:
@@ -162,6 +229,7 @@ def run(path, out_path):
                 lines.append("FAIL trial %d %s nL %d fixed %s %s: %.2e (reference formulation in fp32 %.2e)" % (case["trial"], key, case["tree"]["n_links"], case["tree"]["fixed_base"], case["rep"], e, r32))
     lines.append("query / rollout campaign seed %d, %d trees: %d cases on the device (%d the oracle could not evaluate); fails %d; fp32 quantities above their constant gate that pass by "
                  "3 x the reference formulation's own fp32 error: %d" % (blob["seed"], blob["trials"], len(blob["cases"]), blob["oracle_failed"], nfail, widened))
+    lines.append("rollouts whose fp64 truth exceeds 1e4 within its k steps (exploding trajectories: excluded): %d" % exploded)
     lines.append("fp32 quantities above 1e-4 AND more than 30 x what the reference's formulation loses in fp32 (the kernel's formulation, not the model): %d" % len(outliers))
     lines.extend(outliers)
     lines.append("%-16s %-8s %6s | %-30s | %s" % ("quantity", "dtype", "cases", "device: worst median above-gate", "reference formulation in fp32: worst median"))
