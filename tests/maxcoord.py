@@ -111,15 +111,17 @@ class Urdf:
 
 def forward_dynamics(text: str, *, base_position, base_quaternion, base_linear_velocity, base_angular_velocity,
                      joint_positions: dict, joint_velocities: dict, joint_forces: dict | None = None,
-                     link_wrenches: dict | None = None, gravity: float = -9.81):
+                     link_wrenches: dict | None = None, world_wrenches: dict | None = None, gravity: float = -9.81):
     """Accelerations of ONE configuration: ``(base_acc_mixed[6], {joint name: sdd})``.
 
     ``link_wrenches``: ``{link name: (force[3], torque[3])}``, world axes, the torque about the LINK ORIGIN (the mixed
-    representation of a link force).  ``gravity``: signed z acceleration.  A fixed base has zero velocity (what ABA assumes,
+    representation of a link force); ``world_wrenches``: the same with the torque about the WORLD ORIGIN (the
+    inertial-fixed representation: what ``js.contact.link_contact_forces`` returns).  ``gravity``: signed z acceleration.  A fixed base has zero velocity (what ABA assumes,
     ``rbda/aba.py:109-121``) and its returned base acceleration is zero."""
     U = Urdf(text)
     joint_forces = joint_forces or {}
     link_wrenches = link_wrenches or {}
+    world_wrenches = world_wrenches or {}
     # ---- kinematics of every link frame (massless ones too) ---------------------------------------------------------
     pose, vel = {}, {}  # name -> (o[3], R[3,3]);  name -> (v_origin[3], omega[3])
     w0 = np.zeros(3) if U.fixed_base else np.asarray(base_angular_velocity, dtype=float)
@@ -177,6 +179,13 @@ def forward_dynamics(text: str, *, base_position, base_quaternion, base_linear_v
         F, Nq = np.asarray(F, dtype=float), np.asarray(Nq, dtype=float)
         f[6 * k : 6 * k + 3] += F
         f[6 * k + 3 : 6 * k + 6] += Nq + np.cross(pose[n][0] - com[n], F)
+    for n, (F, Nq) in world_wrenches.items():
+        if n not in idx:
+            continue
+        k = idx[n]
+        F, Nq = np.asarray(F, dtype=float), np.asarray(Nq, dtype=float)
+        f[6 * k : 6 * k + 3] += F
+        f[6 * k + 3 : 6 * k + 6] += Nq - np.cross(com[n], F)
     # ---- constraints ------------------------------------------------------------------------------------------------
     rows, rhs = [], []
 

@@ -171,3 +171,51 @@ def test_hip_kernels_equal_maximal_coordinates_gpu(name, dtype, tol):
     assert rel(gsdd, sdd) < tol
     if model.floating_base():
         assert rel(gvd, vd) < tol
+
+
+# ---- [round 6] rows E / I (js.ode.system_acceleration, js.contact.link_contact_forces) against the same solver ------------
+CONTACT_CASES = [("box", "soft", None), ("anymal", "soft", None), ("icub", "soft", None), ("chain9f", "soft", None), ("octopod", "soft", None),
+                 ("anymal", "rigid", helpers.ANYMAL_FEET_4), ("box", "rigid", [0, 1, 2, 3]), ("anymal", "relaxed", helpers.ANYMAL_FEET_16),
+                 ("icub16", "relaxed", list(range(16))), ("octopod", "relaxed", [8 * f_ + c_ for f_ in range(4) for c_ in range(4)])]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,kind,idx", CONTACT_CASES)
+def test_contact_accelerations_follow_from_the_reported_wrenches_gpu(models, name, kind, idx):
+    """The device's ``link_contact_forces`` (inertial wrenches per link) fed to the maximal-coordinate solver together with
+    the same joint torques and external link wrenches must give the device's ``system_acceleration``: the forces the contact
+    model reports are the forces the dynamics used, and the dynamics under them are Newton-Euler -- for SoftContacts, RigidContacts
+    and RelaxedRigidContacts, without the oracle.  Inertial representation throughout (with Body / Mixed data the reference
+    adds inertial contact wrenches to link forces of the data's representation, api/ode.py:77-118: reproduced, not physics)."""
+    import jaxsim_amd.api as js
+
+    text = models._urdf[name]()
+    model = models(name)
+    if kind == "rigid":
+        model = helpers.rigid_model(model, idx, K=1e4, D=1e2, build=dict(solver_options={"solver_tol": 1e-9}))
+    elif kind == "relaxed":
+        model = helpers.relaxed_model(model, idx, mu=0.5)
+    N = 12
+    d = models.random_data(name, N, seed=9, rep=VelRepr.Inertial)
+    rng = np.random.default_rng(10)
+    tau = rng.uniform(-3, 3, size=(N, model.dofs()))
+    f = rng.uniform(-5, 5, size=(N, model.number_of_links(), 6))
+    g = js.data.JaxSimModelData.from_state_block(model, helpers.odata_to_block(model, d), ja.VelRepr.Inertial)
+    W, _aux = js.contact.link_contact_forces(model, g, link_forces=f, joint_torques=tau)
+    W = np.asarray(W, dtype=np.float64)
+    assert np.abs(W).max() > 1.0  # contacts act in this sample
+    gvd, gsdd, _cs = js.ode.system_acceleration(model, g, link_forces=f, joint_torques=tau)
+    jn, lnm = model.joint_names(), model.link_names()
+    bvm = d.base_velocity(VelRepr.Mixed)
+    worst = 0.0
+    for e in range(N):
+        ba, acc = maxcoord.forward_dynamics(
+            text, base_position=d.base_position[e], base_quaternion=d.base_quaternion[e], base_linear_velocity=bvm[e, :3], base_angular_velocity=bvm[e, 3:],
+            joint_positions=dict(zip(jn, d.joint_positions[e])), joint_velocities=dict(zip(jn, d.joint_velocities[e])), joint_forces=dict(zip(jn, tau[e])),
+            world_wrenches={n: (f[e, i, :3] + W[e, i, :3], f[e, i, 3:] + W[e, i, 3:]) for i, n in enumerate(lnm)}, gravity=model.gravity)  # fmt: skip
+        sdd = np.array([acc[n] for n in jn])
+        p, w, pd = d.base_position[e], bvm[e, 3:], bvm[e, :3]
+        vd_inertial = np.concatenate([ba[:3] - np.cross(ba[3:], p) - np.cross(w, pd), ba[3:]])  # vdot_O = pddot_B - wdot x p_B - w x pdot_B
+        scale = max(1.0, float(np.abs(sdd).max()) if sdd.size else 0.0, float(np.abs(vd_inertial).max()))
+        worst = max(worst, float(np.abs(np.asarray(gsdd)[e] - sdd).max()) / scale if sdd.size else 0.0, float(np.abs(np.asarray(gvd)[e] - vd_inertial).max()) / scale)
+    assert worst < 1e-9, worst
